@@ -1,0 +1,279 @@
+// xfm.hip -- batched 4x4 transform of points/vectors and its backward passes on gfx950.
+//
+// Replaces the four CUDA kernels of the reference plugin (diffdope/c_src/mesh.cu:22-214, host
+// wrappers torch_bindings.cpp:142-277).  Design for CDNA4:
+//   * one vertex per lane, 256-thread workgroups, grid (ceil(N/256), B);
+//   * the 4x4 . [p;1] product runs on the matrix core as four v_mfma_f32_4x4x1_16b_f32
+//     (16 independent 4x4 blocks per wave = 64 vertices per instruction group).  Lane l supplies
+//     A = M[l%4][k] and B = p_l[k]; accumulator register r of lane l is out[l][r], so the result
+//     leaves as one coalesced 16-byte store per lane.  The MFMA chain is bit-identical to a k-ordered
+//     fmaf chain, which is what the CPU oracle evaluates;
+//   * d_matrix = sum_n dout[n] (x) [p_n;1] uses the same instruction the other way round: each of the
+//     16 blocks consumes one vertex per MFMA (4 lanes = the 4 channels, fully coalesced dword loads),
+//     keeps a private 4x4 partial sum in its accumulator, and the 16 blocks are folded once at the
+//     end with 4 shuffle steps -> LDS across the 4 waves -> 16 atomics per WORKGROUP (the reference
+//     issues 16 global atomics per THREAD, mesh.cu:189-212).
+// A plain-VALU variant of every kernel is kept for A/B measurement (variant = 1).
+#include "ddx_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define XFM_BLOCK 256
+#define XFM_MTX_PTS_PER_BLOCK 4096  // points reduced by one workgroup in the d_matrix kernels
+
+// ---------------------------------------------------------------------------------------------
+template <bool MFMA, bool POINTS>
+__global__ __launch_bounds__(XFM_BLOCK) void xfm_fwd_kernel(const float* __restrict__ points, long long pbs,
+                                                            const float* __restrict__ matrix, int N,
+                                                            float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * XFM_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const float* M = matrix + (size_t)b * 16;
+    const bool live = n < N;
+    const float* p = points + (size_t)b * pbs + (size_t)(live ? n : 0) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    float o0, o1, o2, o3;
+    if (MFMA) {
+        // A operand: row (lane%4) of M, one k per instruction
+        const f32x4 mrow = *reinterpret_cast<const f32x4*>(M + (lane & 3) * 4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(mrow.x, px, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(mrow.y, py, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(mrow.z, pz, acc, 0, 0, 0);
+        if (POINTS) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(mrow.w, 1.0f, acc, 0, 0, 0);
+        o0 = acc.x; o1 = acc.y; o2 = acc.z; o3 = acc.w;
+    } else {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = __fmaf_rn(M[r * 4 + 0], px, 0.f);
+            a = __fmaf_rn(M[r * 4 + 1], py, a);
+            a = __fmaf_rn(M[r * 4 + 2], pz, a);
+            if (POINTS) a = __fmaf_rn(M[r * 4 + 3], 1.0f, a);
+            o[r] = a;
+        }
+        o0 = o[0]; o1 = o[1]; o2 = o[2]; o3 = o[3];
+    }
+    if (!live) return;
+    if (POINTS) {
+        f32x4 v = {o0, o1, o2, o3};
+        *reinterpret_cast<f32x4*>(out + ((size_t)b * N + n) * 4) = v;
+    } else {
+        float* q = out + ((size_t)b * N + n) * 3;
+        q[0] = o0; q[1] = o1; q[2] = o2;
+    }
+}
+
+// d_points[n][c] = sum_r dout[n][r] * M[r][c]
+template <bool MFMA, bool POINTS>
+__global__ __launch_bounds__(XFM_BLOCK) void xfm_bwd_points_kernel(const float* __restrict__ matrix, int N,
+                                                                   const float* __restrict__ dout,
+                                                                   float* __restrict__ dpoints)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * XFM_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const float* M = matrix + (size_t)b * 16;
+    const bool live = n < N;
+    float g0, g1, g2, g3 = 0.f;
+    if (POINTS) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)b * N + (live ? n : 0)) * 4);
+        g0 = g.x; g1 = g.y; g2 = g.z; g3 = g.w;
+    } else {
+        const float* q = dout + ((size_t)b * N + (live ? n : 0)) * 3;
+        g0 = q[0]; g1 = q[1]; g2 = q[2];
+    }
+    float d0, d1, d2;
+    if (MFMA) {
+        // A[i=c] = M[k=r][c]: lane supplies column (lane%4) of M
+        const int c = lane & 3;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(M[0 + c], g0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(M[4 + c], g1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(M[8 + c], g2, acc, 0, 0, 0);
+        if (POINTS) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(M[12 + c], g3, acc, 0, 0, 0);
+        d0 = acc.x; d1 = acc.y; d2 = acc.z;
+    } else {
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = __fmaf_rn(g0, M[0 + c], 0.f);
+            a = __fmaf_rn(g1, M[4 + c], a);
+            a = __fmaf_rn(g2, M[8 + c], a);
+            if (POINTS) a = __fmaf_rn(g3, M[12 + c], a);
+            d[c] = a;
+        }
+        d0 = d[0]; d1 = d[1]; d2 = d[2];
+    }
+    if (!live) return;
+    float* q = dpoints + ((size_t)b * N + n) * 3;
+    q[0] = d0; q[1] = d1; q[2] = d2;
+}
+
+// d_matrix[r][c] = sum_n dout[n][r] * [p_n;1][c]   (+ optionally d_points in the same pass)
+template <bool MFMA, bool POINTS, bool WITH_DPOINTS>
+__global__ __launch_bounds__(XFM_BLOCK) void xfm_bwd_mtx_kernel(const float* __restrict__ points, long long pbs,
+                                                                const float* __restrict__ matrix, int N,
+                                                                const float* __restrict__ dout,
+                                                                float* __restrict__ dpoints,
+                                                                float* __restrict__ dmatrix)
+{
+    constexpr int R = POINTS ? 4 : 3;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_begin = blockIdx.x * XFM_MTX_PTS_PER_BLOCK;
+    const int n_end = min(N, n_begin + XFM_MTX_PTS_PER_BLOCK);
+    const float* P = points + (size_t)b * pbs;
+    const float* G = dout + (size_t)b * N * R;
+    __shared__ float red[4][16];
+
+    float part[16];  // VALU path: per-lane partial sums; MFMA path: only [0..3] used (accumulator)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = 0.f;
+
+    if (MFMA) {
+        // each wave walks 16 vertices per MFMA: block q = lane/4 owns vertex base+q, lane%4 = channel
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int ch = lane & 3, q = lane >> 2;
+        for (int base = n_begin + wave * 16; base < n_end; base += 64) {
+            const int n = base + q;
+            const bool live = n < n_end;
+            float a = 0.f, bq = 0.f;
+            if (live) {
+                if (ch < R) a = G[(size_t)n * R + ch];
+                bq = (ch < 3) ? P[(size_t)n * 3 + ch] : (POINTS ? 1.0f : 0.0f);
+            }
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bq, acc, 0, 0, 0);
+        }
+        // fold the 16 blocks: lanes with equal lane%4 across lane/4
+        float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) v[r] += __shfl_xor(v[r], o, 64);
+        }
+        // lane c (<4) now holds column c of the wave total: dM[r][c] = v[r]
+        if (lane < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][r * 4 + lane] = v[r];
+        }
+    } else {
+        for (int n = n_begin + threadIdx.x; n < n_end; n += XFM_BLOCK) {
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < R; ++r) g[r] = G[(size_t)n * R + r];
+            const float p[4] = {P[(size_t)n * 3 + 0], P[(size_t)n * 3 + 1], P[(size_t)n * 3 + 2], POINTS ? 1.f : 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) part[r * 4 + c] = __fmaf_rn(g[r], p[c], part[r * 4 + c]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float s = wave_sum(part[i]);
+            if (lane == 0) red[wave][i] = s;
+        }
+    }
+
+    if (WITH_DPOINTS) {
+        // second walk, one vertex per lane (the lines were just touched: L2/L1 hits)
+        const float* M = matrix + (size_t)b * 16;
+        for (int n = n_begin + threadIdx.x; n < n_end; n += XFM_BLOCK) {
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < R; ++r) g[r] = G[(size_t)n * R + r];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a = __fmaf_rn(g[0], M[0 + c], 0.f);
+                a = __fmaf_rn(g[1], M[4 + c], a);
+                a = __fmaf_rn(g[2], M[8 + c], a);
+                if (POINTS) a = __fmaf_rn(g[3], M[12 + c], a);
+                dpoints[((size_t)b * N + n) * 3 + c] = a;
+            }
+        }
+    }
+
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (s != 0.f) atomicAdd(dmatrix + (size_t)b * 16 + threadIdx.x, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_common(const void* a, const void* b, const void* c, int B, int N)
+{
+    DDX_REQUIRE(a && b && c, DDX_E_NULL, "xfm: NULL pointer argument");
+    DDX_REQUIRE(B >= 1 && N >= 1 && B <= 65535, DDX_E_SHAPE, "xfm: bad shape B=%d N=%d (need 1<=B<=65535, N>=1)", B, N);
+    return 0;
+}
+
+extern "C" int ddx_xfm_fwd(const float* points, long long pbs, const float* matrix, int B, int N, int is_points,
+                           float* out, int variant, void* stream)
+{
+    if (int e = check_common(points, matrix, out, B, N)) return e;
+    DDX_REQUIRE(((uintptr_t)matrix & 15) == 0 && ((uintptr_t)out & 15) == 0, DDX_E_ALIGN, "xfm_fwd: matrix/out must be 16-byte aligned");
+    dim3 grid(ddx_cdiv(N, XFM_BLOCK), B), block(XFM_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == 0) {
+        if (is_points) xfm_fwd_kernel<true, true><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
+        else xfm_fwd_kernel<true, false><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
+    } else {
+        if (is_points) xfm_fwd_kernel<false, true><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
+        else xfm_fwd_kernel<false, false><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
+    }
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_xfm_bwd_points(const float* matrix, int B, int N, int is_points, const float* dout,
+                                  float* dpoints, int variant, void* stream)
+{
+    if (int e = check_common(matrix, dout, dpoints, B, N)) return e;
+    DDX_REQUIRE(((uintptr_t)dout & 15) == 0, DDX_E_ALIGN, "xfm_bwd_points: dout must be 16-byte aligned");
+    dim3 grid(ddx_cdiv(N, XFM_BLOCK), B), block(XFM_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == 0) {
+        if (is_points) xfm_bwd_points_kernel<true, true><<<grid, block, 0, s>>>(matrix, N, dout, dpoints);
+        else xfm_bwd_points_kernel<true, false><<<grid, block, 0, s>>>(matrix, N, dout, dpoints);
+    } else {
+        if (is_points) xfm_bwd_points_kernel<false, true><<<grid, block, 0, s>>>(matrix, N, dout, dpoints);
+        else xfm_bwd_points_kernel<false, false><<<grid, block, 0, s>>>(matrix, N, dout, dpoints);
+    }
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool WITH_DP>
+static int launch_bwd_mtx(const float* points, long long pbs, const float* matrix, int B, int N, int is_points,
+                          const float* dout, float* dpoints, float* dmatrix, int variant, hipStream_t s)
+{
+    DDX_HIP(hipMemsetAsync(dmatrix, 0, (size_t)B * 16 * sizeof(float), s));
+    dim3 grid(ddx_cdiv(N, XFM_MTX_PTS_PER_BLOCK), B), block(XFM_BLOCK);
+    if (variant == 0) {
+        if (is_points) xfm_bwd_mtx_kernel<true, true, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
+        else xfm_bwd_mtx_kernel<true, false, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
+    } else {
+        if (is_points) xfm_bwd_mtx_kernel<false, true, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
+        else xfm_bwd_mtx_kernel<false, false, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
+    }
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_xfm_bwd_mtx(const float* points, long long pbs, int B, int N, int is_points, const float* dout,
+                               float* dmatrix, int variant, void* stream)
+{
+    if (int e = check_common(points, dout, dmatrix, B, N)) return e;
+    return launch_bwd_mtx<false>(points, pbs, nullptr, B, N, is_points, dout, nullptr, dmatrix, variant, (hipStream_t)stream);
+}
+
+extern "C" int ddx_xfm_bwd_full(const float* points, long long pbs, const float* matrix, int B, int N, int is_points,
+                                const float* dout, float* dpoints, float* dmatrix, int variant, void* stream)
+{
+    if (int e = check_common(points, dout, dmatrix, B, N)) return e;
+    DDX_REQUIRE(matrix && dpoints, DDX_E_NULL, "xfm_bwd_full: NULL matrix/dpoints");
+    return launch_bwd_mtx<true>(points, pbs, matrix, B, N, is_points, dout, dpoints, dmatrix, variant, (hipStream_t)stream);
+}

@@ -1,0 +1,182 @@
+/*
+ * ddx.h -- C ABI of libddx.so, the MI355X (gfx950) native library behind diffdope_amd.
+ *
+ * This is the drop-in boundary for the render-and-compare hot path of NVlabs/diff-dope
+ * (SURVEY.md section 8b).  It replaces
+ *   - the reference's own plugin `renderutils_plugin` (diffdope/c_src/torch_bindings.cpp:279-284,
+ *     loaded by diffdope/ops.py:83-96):  xfm_fwd / xfm_bwd / xfm_bwd_full / xfm_bwd_mtx;
+ *   - the nvdiffrast entry points the reference calls (diffdope/diffdope.py:147,198,214,221,1312):
+ *     rasterize / interpolate / texture(linear) / antialias, forward and backward;
+ *   - the body of DiffDope.run_optimization (diffdope/diffdope.py:1656-1714) as one fused engine.
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no torch/ATen types anywhere;
+ *   - the CALLER allocates every buffer (outputs, gradients, scratch); the library never owns
+ *     tensor memory.  Scratch sizes are queried with the *_scratch_bytes functions;
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (a void*; pass
+ *     torch.cuda.current_stream().cuda_stream) and is hipGraph-capturable;
+ *   - return value: 0 = ok, negative = bad argument (DDX_E_*), positive = hipError_t;
+ *     ddx_last_error() returns a thread-local message for the last failing call;
+ *   - all floating point is fp32, indices int32, tensors dense row-major unless a batch stride
+ *     (in elements, 0 = broadcast one copy over the batch) is given.
+ */
+#ifndef DDX_H
+#define DDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDX_VERSION 100
+
+#define DDX_E_NULL (-1)     /* a required pointer is NULL */
+#define DDX_E_SHAPE (-2)    /* a size is out of range */
+#define DDX_E_SCRATCH (-3)  /* scratch buffer too small */
+#define DDX_E_ALIGN (-4)    /* pointer not 16-byte aligned */
+
+int ddx_version(void);
+const char* ddx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * xfm: batched 4x4 transform of points / vectors.
+ * Replaces torch_bindings.cpp:142-175 (xfm_fwd), :177-203 (xfm_bwd), :242-277 (xfm_bwd_mtx),
+ * :205-239 (xfm_bwd_full) and the kernels of c_src/mesh.cu:22-214.
+ *   points  [Bp,N,3] with batch stride points_bstride (0 => broadcast, Bp==1)
+ *   matrix  [B,4,4]
+ *   out     [B,N,4] (is_points) or [B,N,3] (vectors):  out[b,n,r] = sum_c M[b,r,c] p[n,c] (+ M[b,r,3])
+ *   dout    same shape as out
+ *   dpoints [B,N,3] dense (the reference returns a dense [B,N,3] even for broadcast points)
+ *   dmatrix [B,4,4], fully written by the call (zero rows/cols where the op has no dependence)
+ * variant: 0 = MFMA (v_mfma_f32_4x4x1_16b_f32), 1 = plain VALU fma (for A/B measurements).
+ * ------------------------------------------------------------------------------------------- */
+int ddx_xfm_fwd(const float* points, long long points_bstride, const float* matrix, int B, int N,
+                int is_points, float* out, int variant, void* stream);
+int ddx_xfm_bwd_points(const float* matrix, int B, int N, int is_points, const float* dout,
+                       float* dpoints, int variant, void* stream);
+int ddx_xfm_bwd_mtx(const float* points, long long points_bstride, int B, int N, int is_points,
+                    const float* dout, float* dmatrix, int variant, void* stream);
+int ddx_xfm_bwd_full(const float* points, long long points_bstride, const float* matrix, int B, int N,
+                     int is_points, const float* dout, float* dpoints, float* dmatrix, int variant,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * rasterize: replaces dr.rasterize(glctx, pos, tri, resolution) at diffdope.py:198-200 and its
+ * backward.  Software tile rasteriser: per-hypothesis 16x16-pixel tiles, wavefront-aggregated
+ * triangle binning, LDS depth tile with 64-bit (depth,id) min.
+ *   pos   [B,V,4] clip space;  tri [T,3];  rast [B,H,W,4] = (u, v, z/w, tri_id+1), 0 on background
+ *   status: device int32[4] written by the call: [0]=1 if the bin buffer overflowed (result
+ *           incomplete -> enlarge scratch via `pairs_hint`), [1]=number of (tile,triangle) pairs.
+ * scratch_bytes(B,T,H,W,pairs_hint): pairs_hint = expected (tile,triangle) pairs in total, 0 => default
+ * sizing of 4*B*T + 64*B*tiles.
+ * ------------------------------------------------------------------------------------------- */
+size_t ddx_rasterize_scratch_bytes(int B, int T, int H, int W, long long pairs_hint);
+int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
+                      void* scratch, size_t scratch_bytes, float* rast, int32_t* status, void* stream);
+/* drast [B,H,W,4] (channels 0,1 used) -> dpos [B,V,4], fully written (zeroed then accumulated). */
+int ddx_rasterize_bwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
+                      const float* rast, const float* drast, float* dpos, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * interpolate: replaces dr.interpolate(attr, rast, tri) (diffdope.py:143-153 and :203,:212,:218,:230).
+ * The pixel-derivative outputs (diff_attrs="all") are never consumed by diff-dope and are not produced.
+ *   attr [Ba,Va,A] with batch stride attr_bstride (0 => broadcast); out [B,H,W,A]
+ *   dattr (nullable) same layout as attr, accumulated over pixels (and over b when broadcast),
+ *   fully written; drast [B,H,W,4] fully written (channels 2,3 zero).
+ * ------------------------------------------------------------------------------------------- */
+int ddx_interpolate_fwd(const float* attr, long long attr_bstride, int Va, int A, const float* rast,
+                        const int32_t* tri, int T, int B, int H, int W, float* out, void* stream);
+int ddx_interpolate_bwd(const float* attr, long long attr_bstride, int Va, int A, const float* rast,
+                        const int32_t* tri, int T, int B, int H, int W, const float* dout, float* dattr,
+                        float* drast, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * texture: replaces dr.texture(tex, uv, filter_mode="linear") (boundary wrap), diffdope.py:221-226.
+ *   tex [Bt,Th,Tw,C] with batch stride tex_bstride (0 => one shared texture -- the reference
+ *   replicates it B times, diffdope.py:875-893; this build does not need that);
+ *   uv [B,H,W,2]; out [B,H,W,C]; duv [B,H,W,2] fully written; dtex nullable, same layout as tex,
+ *   fully written.
+ * ------------------------------------------------------------------------------------------- */
+int ddx_texture_linear_fwd(const float* tex, long long tex_bstride, int Th, int Tw, int C, const float* uv,
+                           int B, int H, int W, float* out, void* stream);
+int ddx_texture_linear_bwd(const float* tex, long long tex_bstride, int Th, int Tw, int C, const float* uv,
+                           int B, int H, int W, const float* dout, float* duv, float* dtex, int Bt,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * antialias: replaces dr.antialias(color, rast, pos, tri) at diffdope.py:214.
+ * The edge topology (nvdiffrast rebuilds its hash on every call) is built ONCE per mesh on the host:
+ *   ddx_topology_build(tri_host [T,3], T, opp_host [T,3]): opp[t,k] = vertex opposite to edge k
+ *   (joining vertices (k+1)%3,(k+2)%3) in the lowest-indexed other triangle sharing it, or -1.
+ *   color/out/dcolor [B,H,W,C]; dpos [B,V,4] fully written.
+ * ------------------------------------------------------------------------------------------- */
+int ddx_topology_build(const int32_t* tri_host, int T, int32_t* opp_host);
+int ddx_antialias_fwd(const float* color, int C, const float* rast, const float* pos, const int32_t* tri,
+                      const int32_t* opp, int B, int V, int T, int H, int W, float* out, void* stream);
+int ddx_antialias_bwd(const float* color, int C, const float* rast, const float* pos, const int32_t* tri,
+                      const int32_t* opp, int B, int V, int T, int H, int W, const float* dout,
+                      float* dcolor, float* dpos, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused refinement engine: the body of DiffDope.run_optimization (diffdope.py:1656-1714) for the
+ * built-in losses (l1_rgb_with_mask / l1_depth_with_mask / l1_mask, diffdope.py:547-613):
+ * pose -> matrices -> vertex transform -> tile binning/raster -> shade + loss + analytic backward
+ * -> d loss / d(q,t) -> optimiser step, B hypotheses at a time, no G-buffer ever written to HBM.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ddx_engine_desc {
+    int32_t B;        /* hypotheses on this device */
+    int32_t B_global; /* hypotheses of the whole job (the batch mean of diffdope.py:562 divides by this) */
+    int32_t V, T, H, W;
+    int32_t Th, Tw;   /* texture size; Th == 0 => per-vertex colour path (diffdope.py:230) */
+    int32_t use_rgb, use_depth, use_mask;
+    float w_rgb, w_depth, w_mask;
+    int32_t optimizer; /* 0 = SGD (reference, diffdope.py:1363), 1 = Adam */
+    float adam_beta1, adam_beta2, adam_eps;
+    int32_t max_iters; /* rows available in lr_sched / loss_log / mtx_log */
+    int32_t reserved[8];
+} ddx_engine_desc;
+
+typedef struct ddx_engine_buffers {
+    /* mesh (one copy, shared by all hypotheses) */
+    const float* pos;        /* [V,3] */
+    const int32_t* tri;      /* [T,3] */
+    const int32_t* opp;      /* [T,3] from ddx_topology_build */
+    const float* uv;         /* [V,2] or NULL */
+    const float* tex;        /* [Th,Tw,3] or NULL */
+    const float* vtx_color;  /* [V,3] or NULL */
+    const float* proj;       /* [4,4] */
+    /* observed images (one copy), stored bottom-up like the reference holds them (diffdope.py:1131) */
+    const float* gt_rgb;     /* [H,W,3] or NULL */
+    const float* gt_depth;   /* [H,W]   or NULL */
+    const float* gt_seg;     /* [H,W,3] */
+    const float* lr_mult;    /* [B] per-hypothesis loss multipliers (diffdope.py:1368-1375) */
+    const float* lr_sched;   /* [max_iters] optimiser lr per iteration (diffdope.py:1657-1664) */
+    float* params;           /* [7,B] qx,qy,qz,qw,x,y,z -- read and updated in place */
+    float* loss_log;         /* [max_iters,3,B] weighted, un-LR'd per-hypothesis losses (rgb,depth,mask) */
+    float* mtx_log;          /* [max_iters,B,16] pose matrix used by each iteration's forward */
+    void* scratch;
+    size_t scratch_bytes;
+} ddx_engine_buffers;
+
+typedef struct ddx_engine ddx_engine;
+
+size_t ddx_engine_scratch_bytes(const ddx_engine_desc* desc, long long pairs_hint);
+int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* bufs, ddx_engine** out);
+/* Run iterations [it0, it0+n) (rows of lr_sched / loss_log / mtx_log).  use_graph != 0 replays a
+ * captured hipGraph of one iteration. */
+int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
+/* device int32[8] inside scratch: [0] overflow flag, [1] (tile,tri) pairs of the last iteration,
+ * [2] active tiles of the last iteration */
+const int32_t* ddx_engine_status_ptr(ddx_engine* e);
+/* per-kernel launch durations of the last ddx_engine_profile call are returned in ms (host array
+ * of `n_kernels`), measured with hipEvents on `stream`; returns the number of kernels. */
+int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_out, const char** names_out, int max_k,
+                       void* stream);
+void ddx_engine_destroy(ddx_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDX_H */
