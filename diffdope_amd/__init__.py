@@ -1,0 +1,18 @@
+"""diffdope_amd -- MI355X-native render-and-compare pose refinement with the diff-dope API.
+
+`import diffdope_amd as dd` (or the alias package `diffdope`) offers what `import diffdope as dd`
+does in the reference (diffdope/__init__.py:1-7): xfm_points / xfm_vectors, render_texture_batch,
+the loss functions and the DiffDope / Object3D / Mesh / Scene / Image / Camera classes.
+"""
+from .ops import xfm_points, xfm_vectors  # noqa: F401
+from .render import (  # noqa: F401
+    RasterizeContext,
+    RasterizeGLContext,
+    antialias,
+    interpolate,
+    rasterize,
+    render_texture_batch,
+    texture,
+)
+from .engine import RefineEngine  # noqa: F401
+from .pose import matrix_batch_44_from_position_quat  # noqa: F401

@@ -36,6 +36,8 @@ void ddx_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+int ddx_xfm_fwd_strided(const float* points, const float* matrix0, int mstride, int B, int N, float* out, hipStream_t s);
+
 static inline int ddx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,268 @@
+// raster_math.h -- per-pixel / per-triangle device math shared by the rasteriser, the renderer ops
+// and the fused engine.  Semantics: SURVEY.md section 2.2 (nvdiffrast ops as used at
+// diffdope/diffdope.py:198-231).  Everything that decides a triangle id (snapping, coverage,
+// depth key) is exact integer arithmetic or explicitly ordered fp32 (this library is built with
+// -ffp-contract=off), so visibility is reproducible bit for bit.
+#pragma once
+#include "ddx_common.h"
+
+#define DDX_SUBPIX 256  // 8 sub-pixel bits
+#define DDX_TILE 16     // screen tile edge in pixels (one 256-thread workgroup per tile)
+
+struct float4a { float x, y, z, w; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---- snapped window coordinates ---------------------------------------------------------------
+__device__ __forceinline__ int snap_coord(float ndc, int dim)
+{
+    float f = __fmaf_rn(ndc, (float)(dim * (DDX_SUBPIX / 2)), (float)(dim * (DDX_SUBPIX / 2)));
+    const float lim = 16777216.0f;
+    if (!(f > -lim)) f = -lim;
+    if (f > lim) f = lim;
+    return (int)rintf(f);
+}
+
+struct SnapTri {
+    int X[3], Y[3];
+    long long area;
+    bool ok;
+};
+
+__device__ __forceinline__ void snap_triangle(const float4& p0, const float4& p1, const float4& p2, int H, int W,
+                                              SnapTri& s)
+{
+    s.ok = false;
+    if (!(p0.w > 0.f) || !(p1.w > 0.f) || !(p2.w > 0.f)) return;
+    const float i0 = __fdiv_rn(1.0f, p0.w), i1 = __fdiv_rn(1.0f, p1.w), i2 = __fdiv_rn(1.0f, p2.w);
+    s.X[0] = snap_coord(p0.x * i0, W); s.Y[0] = snap_coord(p0.y * i0, H);
+    s.X[1] = snap_coord(p1.x * i1, W); s.Y[1] = snap_coord(p1.y * i1, H);
+    s.X[2] = snap_coord(p2.x * i2, W); s.Y[2] = snap_coord(p2.y * i2, H);
+    s.area = (long long)(s.X[1] - s.X[0]) * (long long)(s.Y[2] - s.Y[0]) -
+             (long long)(s.X[2] - s.X[0]) * (long long)(s.Y[1] - s.Y[0]);
+    s.ok = s.area != 0;
+}
+
+// pixel-centre range [px0,px1] x [py0,py1] whose centres can lie inside the snapped bbox (unclamped)
+__device__ __forceinline__ void snap_bbox(const SnapTri& s, int& px0, int& py0, int& px1, int& py1)
+{
+    const int xmin = min(s.X[0], min(s.X[1], s.X[2])), xmax = max(s.X[0], max(s.X[1], s.X[2]));
+    const int ymin = min(s.Y[0], min(s.Y[1], s.Y[2])), ymax = max(s.Y[0], max(s.Y[1], s.Y[2]));
+    px0 = (xmin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8;  // arithmetic shift = floor
+    px1 = (xmax - DDX_SUBPIX / 2) >> 8;
+    py0 = (ymin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8;
+    py1 = (ymax - DDX_SUBPIX / 2) >> 8;
+}
+
+__device__ __forceinline__ bool edge_inside(int ax, int ay, int bx, int by, int px, int py, bool flip)
+{
+    int dx = bx - ax, dy = by - ay;
+    long long e = (long long)dx * (long long)(py - ay) - (long long)dy * (long long)(px - ax);
+    if (flip) { e = -e; dx = -dx; dy = -dy; }
+    if (e > 0) return true;
+    if (e < 0) return false;
+    return (dy > 0) || (dy == 0 && dx < 0);
+}
+
+__device__ __forceinline__ bool tri_covers(const SnapTri& s, int px, int py)
+{
+    const int PX = px * DDX_SUBPIX + DDX_SUBPIX / 2, PY = py * DDX_SUBPIX + DDX_SUBPIX / 2;
+    const bool flip = s.area < 0;
+    return edge_inside(s.X[1], s.Y[1], s.X[2], s.Y[2], PX, PY, flip) &&
+           edge_inside(s.X[2], s.Y[2], s.X[0], s.Y[0], PX, PY, flip) &&
+           edge_inside(s.X[0], s.Y[0], s.X[1], s.Y[1], PX, PY, flip);
+}
+
+// ---- perspective-correct barycentrics -----------------------------------------------------------
+struct Bary {
+    float u, v, zw, a0, a1, a2, s;
+    float p0x, p0y, p1x, p1y, p2x, p2y, fx, fy;
+};
+
+__device__ __forceinline__ bool pixel_bary(const float4& p0, const float4& p1, const float4& p2, int px, int py, int H,
+                                           int W, Bary& o)
+{
+    const float xs = __fdiv_rn(2.0f, (float)W), xo = __fdiv_rn(1.0f, (float)W) - 1.0f;
+    const float ys = __fdiv_rn(2.0f, (float)H), yo = __fdiv_rn(1.0f, (float)H) - 1.0f;
+    const float fx = __fmaf_rn((float)px, xs, xo), fy = __fmaf_rn((float)py, ys, yo);
+    o.fx = fx; o.fy = fy;
+    o.p0x = __fmaf_rn(-fx, p0.w, p0.x); o.p0y = __fmaf_rn(-fy, p0.w, p0.y);
+    o.p1x = __fmaf_rn(-fx, p1.w, p1.x); o.p1y = __fmaf_rn(-fy, p1.w, p1.y);
+    o.p2x = __fmaf_rn(-fx, p2.w, p2.x); o.p2y = __fmaf_rn(-fy, p2.w, p2.y);
+    o.a0 = __fmaf_rn(o.p1x, o.p2y, -(o.p1y * o.p2x));
+    o.a1 = __fmaf_rn(o.p2x, o.p0y, -(o.p2y * o.p0x));
+    o.a2 = __fmaf_rn(o.p0x, o.p1y, -(o.p0y * o.p1x));
+    o.s = (o.a0 + o.a1) + o.a2;
+    if (!(fabsf(o.s) > 0.f)) return false;
+    const float is = __fdiv_rn(1.0f, o.s);
+    o.u = o.a0 * is;
+    o.v = o.a1 * is;
+    const float zn = __fmaf_rn(o.a2, p2.z, __fmaf_rn(o.a1, p1.z, o.a0 * p0.z));
+    const float wn = __fmaf_rn(o.a2, p2.w, __fmaf_rn(o.a1, p1.w, o.a0 * p0.w));
+    o.zw = __fdiv_rn(zn, wn) + 0.0f;
+    return true;
+}
+
+__device__ __forceinline__ unsigned int depth_key(float zw)
+{
+    unsigned int bits = __float_as_uint(zw);
+    return bits ^ ((bits >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__device__ __forceinline__ float clamp01(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
+
+// gradient of (u,v) w.r.t. the clip-space (x,y,w) of the three vertices, given upstream (gu,gv).
+// True derivative of the forward: a clamped component passes no gradient.
+__device__ __forceinline__ void bary_backward(const Bary& bc, float gu, float gv, float gx[3], float gy[3], float gw[3])
+{
+    if (bc.u < 0.f || bc.u > 1.f) gu = 0.f;
+    if (bc.v < 0.f || bc.v > 1.f) gv = 0.f;
+    const float is = __fdiv_rn(1.0f, bc.s);
+    const float k = gu * bc.u + gv * bc.v;
+    const float A0 = (gu - k) * is, A1 = (gv - k) * is, A2 = (-k) * is;
+    gx[0] = A1 * (-bc.p2y) + A2 * bc.p1y;  gy[0] = A1 * bc.p2x + A2 * (-bc.p1x);
+    gx[1] = A0 * bc.p2y + A2 * (-bc.p0y);  gy[1] = A0 * (-bc.p2x) + A2 * bc.p0x;
+    gx[2] = A0 * (-bc.p1y) + A1 * bc.p0y;  gy[2] = A0 * bc.p1x + A1 * (-bc.p0x);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gw[i] = -bc.fx * gx[i] - bc.fy * gy[i];
+}
+
+// ---- bilinear texture, wrap boundary --------------------------------------------------------------
+struct TexelSetup { int x0, x1, y0, y1; float fx, fy; };
+
+__device__ __forceinline__ void tex_setup(float u, float v, int Th, int Tw, TexelSetup& s)
+{
+    u = u - floorf(u);
+    v = v - floorf(v);
+    const float x = __fmaf_rn(u, (float)Tw, -0.5f), y = __fmaf_rn(v, (float)Th, -0.5f);
+    const float xf = floorf(x), yf = floorf(y);
+    s.fx = x - xf; s.fy = y - yf;
+    int x0 = (int)xf, y0 = (int)yf;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    if (x0 < 0) x0 += Tw;
+    if (y0 < 0) y0 += Th;
+    if (x0 >= Tw) x0 -= Tw;
+    if (y0 >= Th) y0 -= Th;
+    if (x1 >= Tw) x1 -= Tw;
+    if (y1 >= Th) y1 -= Th;
+    s.x0 = x0; s.x1 = x1; s.y0 = y0; s.y1 = y1;
+}
+
+// ---- antialias pair analysis ------------------------------------------------------------------------
+struct AAPair {
+    bool valid;
+    int tri, va, vb, d;
+    bool chosen1, clamped;
+    float ds, dc, alpha;
+    float xa, ya, xb, yb, fx, fy;
+};
+
+__device__ __forceinline__ bool sign_bit(float x) { return (__float_as_uint(x) >> 31) != 0; }
+
+// Analyse the pixel pair (px,py)-(px+1,py) [d=0] or (px,py)-(px,py+1) [d=1] given the triangle ids
+// (0-based, -1 = background) and z/w of both pixels.  P = clip positions [V,4] of this hypothesis.
+__device__ __forceinline__ void aa_eval_pair(const float* __restrict__ P, const int* __restrict__ tri,
+                                             const int* __restrict__ opp, int H, int W, int px, int py, int d, int t0,
+                                             int t1, float z0, float z1, AAPair& o)
+{
+    o.valid = false;
+    if (t0 == t1) return;
+    bool chosen1;
+    if (t0 >= 0 && t1 >= 0) chosen1 = !(z0 < z1);
+    else chosen1 = t0 < 0;
+    const int t = chosen1 ? t1 : t0;
+    const int cx = chosen1 ? px + (d == 0) : px, cy = chosen1 ? py + (d == 1) : py;
+    const float ds = chosen1 ? -1.0f : 1.0f;
+    const int vi[3] = {tri[t * 3 + 0], tri[t * 3 + 1], tri[t * 3 + 2]};
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    const float fx = (float)cx + 0.5f - hw, fy = (float)cy + 0.5f - hh;
+    float x[3], y[3], ox[3], oy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float4 p = ld4(P + (size_t)vi[i] * 4);
+        if (!(p.w > 0.f)) return;
+        const float iw = __fdiv_rn(1.0f, p.w);
+        x[i] = __fmaf_rn(p.x * iw, hw, -fx);
+        y[i] = __fmaf_rn(p.y * iw, hh, -fy);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ov = opp[t * 3 + k];
+        ox[k] = x[k]; oy[k] = y[k];
+        if (ov >= 0) {
+            const float4 p = ld4(P + (size_t)ov * 4);
+            if (p.w > 0.f) {
+                const float iw = __fdiv_rn(1.0f, p.w);
+                ox[k] = __fmaf_rn(p.x * iw, hw, -fx);
+                oy[k] = __fmaf_rn(p.y * iw, hh, -fy);
+            }
+        }
+    }
+    const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+    float aw[3];
+    aw[0] = (x[1] - ox[0]) * (y[2] - oy[0]) - (x[2] - ox[0]) * (y[1] - oy[0]);
+    aw[1] = (x[2] - ox[1]) * (y[0] - oy[1]) - (x[0] - ox[1]) * (y[2] - oy[1]);
+    aw[2] = (x[0] - ox[2]) * (y[1] - oy[2]) - (x[1] - ox[2]) * (y[0] - oy[2]);
+    bool sil[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sil[k] = sign_bit(aw[k]) == sign_bit(bb);
+    if (!(sil[0] || sil[1] || sil[2])) return;
+    if (d) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float tmp = x[i]; x[i] = y[i]; y[i] = tmp; }
+    }
+    int best = -1;
+    float rbest = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ia = (k + 1) % 3, ib = (k + 2) % 3;
+        if (sign_bit(y[ia]) == sign_bit(y[ib])) continue;
+        const float dx = x[ib] - x[ia], dy = y[ib] - y[ia];
+        const float r = ds * __fdiv_rn(x[ia] * dy - y[ia] * dx, dy);
+        if (best < 0 || r > rbest) { best = k; rbest = r; }
+    }
+    if (best < 0) return;
+    const int ia = (best + 1) % 3, ib = (best + 2) % 3;
+    // select without dynamic register-array indexing
+    const float xa = ia == 0 ? x[0] : (ia == 1 ? x[1] : x[2]), ya = ia == 0 ? y[0] : (ia == 1 ? y[1] : y[2]);
+    const float xb = ib == 0 ? x[0] : (ib == 1 ? x[1] : x[2]), yb = ib == 0 ? y[0] : (ib == 1 ? y[1] : y[2]);
+    const bool silb = best == 0 ? sil[0] : (best == 1 ? sil[1] : sil[2]);
+    const float dx = xb - xa, dy = yb - ya;
+    if (!(silb && fabsf(dy) >= fabsf(dx))) return;
+    const float eps = 0.0625f;
+    if (!(rbest > -eps && rbest < 1.0f + eps)) return;
+    o.valid = true;
+    o.tri = t; o.chosen1 = chosen1; o.d = d;
+    o.va = ia == 0 ? vi[0] : (ia == 1 ? vi[1] : vi[2]);
+    o.vb = ib == 0 ? vi[0] : (ib == 1 ? vi[1] : vi[2]);
+    o.ds = ds; o.dc = rbest;
+    o.clamped = !(rbest > 0.f && rbest < 1.f);
+    const float dcc = rbest < 0.f ? 0.f : (rbest > 1.f ? 1.f : rbest);
+    o.alpha = ds * (0.5f - dcc);
+    o.xa = xa; o.ya = ya; o.xb = xb; o.yb = yb;
+    o.fx = fx; o.fy = fy;
+}
+
+// gradient of alpha w.r.t. the clip (x,y,w) of the pair's two edge vertices, times galpha
+__device__ __forceinline__ void aa_pair_backward(const AAPair& pr, const float* __restrict__ P, int H, int W,
+                                                 float galpha, float g[2][3] /* [vertex a/b][x,y,w] */)
+{
+    const float gr = -galpha;
+    const float D = pr.yb - pr.ya;
+    const float r = __fdiv_rn(pr.xa * pr.yb - pr.ya * pr.xb, D);
+    const float g_xa = gr * pr.yb / D, g_xb = gr * (-pr.ya) / D;
+    const float g_ya = gr * (r - pr.xb) / D, g_yb = gr * (pr.xa - r) / D;
+    const float gX[2] = {pr.d ? g_ya : g_xa, pr.d ? g_yb : g_xb};
+    const float gY[2] = {pr.d ? g_xa : g_ya, pr.d ? g_xb : g_yb};
+    const float ix[2] = {pr.d ? pr.ya : pr.xa, pr.d ? pr.yb : pr.xb};
+    const float iy[2] = {pr.d ? pr.xa : pr.ya, pr.d ? pr.xb : pr.yb};
+    const int vv[2] = {pr.va, pr.vb};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float pw = P[(size_t)vv[i] * 4 + 3];
+        const float iw = __fdiv_rn(1.0f, pw);
+        g[i][0] = gX[i] * 0.5f * (float)W * iw;
+        g[i][1] = gY[i] * 0.5f * (float)H * iw;
+        g[i][2] = -(gX[i] * (ix[i] + pr.fx) + gY[i] * (iy[i] + pr.fy)) * iw;
+    }
+}

@@ -1,0 +1,298 @@
+// renderops.hip -- op-level renderer kernels behind diffdope_amd.render (the nvdiffrast-shaped API
+// render_texture_batch is written against, diffdope/diffdope.py:143-231): rasterize backward,
+// interpolate, texture(linear, wrap), antialias -- forward and backward.  These are the
+// compatibility path (user loss functions that need materialised renders); the timed path is the
+// fused engine (engine.hip), which shares raster_math.h with these kernels.
+// All kernels: one lane per pixel, 256-thread workgroups, grid-stride over B*H*W.
+#include "raster.h"
+
+#define PIX_GRID(n) ((n + 255) / 256 > 16384 ? 16384 : (int)((n + 255) / 256))
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rasterize_bwd_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
+                                                            int V, int T, int B, int H, int W,
+                                                            const float* __restrict__ rast,
+                                                            const float* __restrict__ drast, float* __restrict__ dpos)
+{
+    const long long n = (long long)B * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float4 r = ld4(rast + i * 4);
+        const int t = (int)r.w - 1;
+        if (t < 0 || t >= T) continue;
+        const float4 g = ld4(drast + i * 4);
+        if (g.x == 0.f && g.y == 0.f) continue;
+        const int px = (int)(i % W), py = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
+        const int vi[3] = {tri[t * 3 + 0], tri[t * 3 + 1], tri[t * 3 + 2]};
+        const float* P = pos + (size_t)b * V * 4;
+        const float4 p0 = ld4(P + (size_t)vi[0] * 4), p1 = ld4(P + (size_t)vi[1] * 4), p2 = ld4(P + (size_t)vi[2] * 4);
+        Bary bc;
+        if (!pixel_bary(p0, p1, p2, px, py, H, W, bc)) continue;
+        float gx[3], gy[3], gw[3];
+        bary_backward(bc, g.x, g.y, gx, gy, gw);
+        float* D = dpos + (size_t)b * V * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicAdd(D + (size_t)vi[k] * 4 + 0, gx[k]);
+            atomicAdd(D + (size_t)vi[k] * 4 + 1, gy[k]);
+            atomicAdd(D + (size_t)vi[k] * 4 + 3, gw[k]);
+        }
+    }
+}
+
+extern "C" int ddx_rasterize_bwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
+                                 const float* rast, const float* drast, float* dpos, void* stream)
+{
+    DDX_REQUIRE(pos && tri && rast && drast && dpos, DDX_E_NULL, "rasterize_bwd: NULL pointer");
+    DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "rasterize_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    DDX_HIP(hipMemsetAsync(dpos, 0, (size_t)B * V * 4 * sizeof(float), s));
+    const long long n = (long long)B * H * W;
+    rasterize_bwd_kernel<<<PIX_GRID(n), 256, 0, s>>>(pos, tri, V, T, B, H, W, rast, drast, dpos);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interpolate_fwd_kernel(const float* __restrict__ attr, long long abs_, int Va,
+                                                              int A, const float* __restrict__ rast,
+                                                              const int* __restrict__ tri, int T, long long HW,
+                                                              long long n, float* __restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float4 r = ld4(rast + i * 4);
+        const int t = (int)r.w - 1;
+        float* o = out + i * A;
+        if (t < 0 || t >= T) {
+            for (int c = 0; c < A; ++c) o[c] = 0.f;
+            continue;
+        }
+        const int b = (int)(i / HW);
+        const float* AT = attr + (size_t)b * abs_;
+        const int i0 = tri[t * 3 + 0], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
+        if ((unsigned)i0 >= (unsigned)Va || (unsigned)i1 >= (unsigned)Va || (unsigned)i2 >= (unsigned)Va) {
+            for (int c = 0; c < A; ++c) o[c] = 0.f;
+            continue;
+        }
+        const float u = r.x, v = r.y, w2 = (1.0f - u) - v;
+        const float *a0 = AT + (size_t)i0 * A, *a1 = AT + (size_t)i1 * A, *a2 = AT + (size_t)i2 * A;
+        for (int c = 0; c < A; ++c) o[c] = __fmaf_rn(w2, a2[c], __fmaf_rn(v, a1[c], u * a0[c]));
+    }
+}
+
+__global__ __launch_bounds__(256) void interpolate_bwd_kernel(const float* __restrict__ attr, long long abs_, int Va,
+                                                              int A, const float* __restrict__ rast,
+                                                              const int* __restrict__ tri, int T, long long HW,
+                                                              long long n, const float* __restrict__ dout,
+                                                              float* __restrict__ dattr, float* __restrict__ drast)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float4 r = ld4(rast + i * 4);
+        const int t = (int)r.w - 1;
+        float gu = 0.f, gv = 0.f;
+        if (t >= 0 && t < T) {
+            const int b = (int)(i / HW);
+            const int i0 = tri[t * 3 + 0], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
+            if ((unsigned)i0 < (unsigned)Va && (unsigned)i1 < (unsigned)Va && (unsigned)i2 < (unsigned)Va) {
+                const size_t ab = (size_t)b * abs_;
+                const float u = r.x, v = r.y, w2 = (1.0f - u) - v;
+                for (int c = 0; c < A; ++c) {
+                    const float g = dout[i * A + c];
+                    const float a0 = attr[ab + (size_t)i0 * A + c], a1 = attr[ab + (size_t)i1 * A + c],
+                                a2 = attr[ab + (size_t)i2 * A + c];
+                    gu = __fmaf_rn(g, a0 - a2, gu);
+                    gv = __fmaf_rn(g, a1 - a2, gv);
+                    if (dattr && g != 0.f) {
+                        atomicAdd(dattr + ab + (size_t)i0 * A + c, u * g);
+                        atomicAdd(dattr + ab + (size_t)i1 * A + c, v * g);
+                        atomicAdd(dattr + ab + (size_t)i2 * A + c, w2 * g);
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(drast + i * 4) = make_float4(gu, gv, 0.f, 0.f);
+    }
+}
+
+extern "C" int ddx_interpolate_fwd(const float* attr, long long abs_, int Va, int A, const float* rast,
+                                   const int32_t* tri, int T, int B, int H, int W, float* out, void* stream)
+{
+    DDX_REQUIRE(attr && rast && tri && out, DDX_E_NULL, "interpolate_fwd: NULL pointer");
+    DDX_REQUIRE(Va >= 1 && A >= 1 && A <= 64 && B >= 1 && H >= 1 && W >= 1 && T >= 1, DDX_E_SHAPE, "interpolate_fwd: bad shape");
+    const long long n = (long long)B * H * W;
+    interpolate_fwd_kernel<<<PIX_GRID(n), 256, 0, (hipStream_t)stream>>>(attr, abs_, Va, A, rast, tri, T, (long long)H * W, n, out);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_interpolate_bwd(const float* attr, long long abs_, int Va, int A, const float* rast,
+                                   const int32_t* tri, int T, int B, int H, int W, const float* dout, float* dattr,
+                                   float* drast, void* stream)
+{
+    DDX_REQUIRE(attr && rast && tri && dout && drast, DDX_E_NULL, "interpolate_bwd: NULL pointer");
+    DDX_REQUIRE(Va >= 1 && A >= 1 && A <= 64 && B >= 1 && H >= 1 && W >= 1 && T >= 1, DDX_E_SHAPE, "interpolate_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (dattr) DDX_HIP(hipMemsetAsync(dattr, 0, (size_t)(abs_ == 0 ? 1 : B) * Va * A * sizeof(float), s));
+    const long long n = (long long)B * H * W;
+    interpolate_bwd_kernel<<<PIX_GRID(n), 256, 0, s>>>(attr, abs_, Va, A, rast, tri, T, (long long)H * W, n, dout, dattr, drast);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void texture_fwd_kernel(const float* __restrict__ tex, long long tbs, int Th, int Tw,
+                                                          int C, const float* __restrict__ uv, long long HW, long long n,
+                                                          float* __restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float2 q = *reinterpret_cast<const float2*>(uv + i * 2);
+        TexelSetup s;
+        tex_setup(q.x, q.y, Th, Tw, s);
+        const float* TX = tex + (size_t)(i / HW) * tbs;
+        const float *t00 = TX + ((size_t)s.y0 * Tw + s.x0) * C, *t10 = TX + ((size_t)s.y0 * Tw + s.x1) * C,
+                    *t01 = TX + ((size_t)s.y1 * Tw + s.x0) * C, *t11 = TX + ((size_t)s.y1 * Tw + s.x1) * C;
+        for (int c = 0; c < C; ++c) {
+            const float a = __fmaf_rn(s.fx, t10[c] - t00[c], t00[c]);
+            const float bq = __fmaf_rn(s.fx, t11[c] - t01[c], t01[c]);
+            out[i * C + c] = __fmaf_rn(s.fy, bq - a, a);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void texture_bwd_kernel(const float* __restrict__ tex, long long tbs, int Th, int Tw,
+                                                          int C, const float* __restrict__ uv, long long HW, long long n,
+                                                          const float* __restrict__ dout, float* __restrict__ duv,
+                                                          float* __restrict__ dtex)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float2 q = *reinterpret_cast<const float2*>(uv + i * 2);
+        TexelSetup s;
+        tex_setup(q.x, q.y, Th, Tw, s);
+        const size_t tb = (size_t)(i / HW) * tbs;
+        const size_t o00 = tb + ((size_t)s.y0 * Tw + s.x0) * C, o10 = tb + ((size_t)s.y0 * Tw + s.x1) * C,
+                     o01 = tb + ((size_t)s.y1 * Tw + s.x0) * C, o11 = tb + ((size_t)s.y1 * Tw + s.x1) * C;
+        float gu = 0.f, gv = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float g = dout[i * C + c];
+            if (g == 0.f) continue;
+            const float t00 = tex[o00 + c], t10 = tex[o10 + c], t01 = tex[o01 + c], t11 = tex[o11 + c];
+            gu = __fmaf_rn(g, __fmaf_rn(s.fy, (t11 - t01) - (t10 - t00), t10 - t00), gu);
+            gv = __fmaf_rn(g, __fmaf_rn(s.fx, (t11 - t10) - (t01 - t00), t01 - t00), gv);
+            if (dtex) {
+                atomicAdd(dtex + o00 + c, g * (1.f - s.fx) * (1.f - s.fy));
+                atomicAdd(dtex + o10 + c, g * s.fx * (1.f - s.fy));
+                atomicAdd(dtex + o01 + c, g * (1.f - s.fx) * s.fy);
+                atomicAdd(dtex + o11 + c, g * s.fx * s.fy);
+            }
+        }
+        *reinterpret_cast<float2*>(duv + i * 2) = make_float2(gu * (float)Tw, gv * (float)Th);
+    }
+}
+
+extern "C" int ddx_texture_linear_fwd(const float* tex, long long tbs, int Th, int Tw, int C, const float* uv, int B,
+                                      int H, int W, float* out, void* stream)
+{
+    DDX_REQUIRE(tex && uv && out, DDX_E_NULL, "texture_linear_fwd: NULL pointer");
+    DDX_REQUIRE(Th >= 1 && Tw >= 1 && C >= 1 && C <= 64 && B >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "texture_linear_fwd: bad shape");
+    DDX_REQUIRE(((uintptr_t)uv & 7) == 0, DDX_E_ALIGN, "texture_linear_fwd: uv must be 8-byte aligned");
+    const long long n = (long long)B * H * W;
+    texture_fwd_kernel<<<PIX_GRID(n), 256, 0, (hipStream_t)stream>>>(tex, tbs, Th, Tw, C, uv, (long long)H * W, n, out);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_texture_linear_bwd(const float* tex, long long tbs, int Th, int Tw, int C, const float* uv, int B,
+                                      int H, int W, const float* dout, float* duv, float* dtex, int Bt, void* stream)
+{
+    DDX_REQUIRE(tex && uv && dout && duv, DDX_E_NULL, "texture_linear_bwd: NULL pointer");
+    DDX_REQUIRE(Th >= 1 && Tw >= 1 && C >= 1 && C <= 64 && B >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "texture_linear_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtex) DDX_HIP(hipMemsetAsync(dtex, 0, (size_t)(Bt < 1 ? 1 : Bt) * Th * Tw * C * sizeof(float), s));
+    const long long n = (long long)B * H * W;
+    texture_bwd_kernel<<<PIX_GRID(n), 256, 0, s>>>(tex, tbs, Th, Tw, C, uv, (long long)H * W, n, dout, duv, dtex);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// antialias: one lane per pixel analyses the pairs to its right (d=0) and above (d=1, row+1)
+template <bool BWD>
+__global__ __launch_bounds__(256) void antialias_kernel(const float* __restrict__ color, int C,
+                                                        const float* __restrict__ rast, const float* __restrict__ pos,
+                                                        const int* __restrict__ tri, const int* __restrict__ opp, int B,
+                                                        int V, int T, int H, int W, const float* __restrict__ dout,
+                                                        float* __restrict__ out /* fwd: out ; bwd: dcolor */,
+                                                        float* __restrict__ dpos)
+{
+    const long long n = (long long)B * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int px = (int)(i % W), py = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
+        const float4 r0 = ld4(rast + i * 4);
+        const int t0 = (int)r0.w - 1;
+        const float* P = pos + (size_t)b * V * 4;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int qx = px + (d == 0), qy = py + (d == 1);
+            if (qx >= W || qy >= H) continue;
+            const long long j = i + (d == 0 ? 1 : W);
+            const float4 r1 = ld4(rast + j * 4);
+            const int t1 = (int)r1.w - 1;
+            if (t0 == t1 || t0 >= T || t1 >= T) continue;
+            AAPair pr;
+            aa_eval_pair(P, tri, opp, H, W, px, py, d, t0, t1, r0.z, r1.z, pr);
+            if (!pr.valid) continue;
+            const long long tg = pr.alpha > 0.f ? i : j;
+            if (!BWD) {
+                for (int c = 0; c < C; ++c)
+                    atomicAdd(out + tg * C + c, pr.alpha * (color[j * C + c] - color[i * C + c]));
+            } else {
+                float galpha = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float g = dout[tg * C + c];
+                    galpha = __fmaf_rn(g, color[j * C + c] - color[i * C + c], galpha);
+                    if (g != 0.f) {
+                        atomicAdd(out + j * C + c, pr.alpha * g);
+                        atomicAdd(out + i * C + c, -pr.alpha * g);
+                    }
+                }
+                if (pr.clamped || galpha == 0.f) continue;
+                float g[2][3];
+                aa_pair_backward(pr, P, H, W, galpha, g);
+                float* D = dpos + (size_t)b * V * 4;
+                atomicAdd(D + (size_t)pr.va * 4 + 0, g[0][0]);
+                atomicAdd(D + (size_t)pr.va * 4 + 1, g[0][1]);
+                atomicAdd(D + (size_t)pr.va * 4 + 3, g[0][2]);
+                atomicAdd(D + (size_t)pr.vb * 4 + 0, g[1][0]);
+                atomicAdd(D + (size_t)pr.vb * 4 + 1, g[1][1]);
+                atomicAdd(D + (size_t)pr.vb * 4 + 3, g[1][2]);
+            }
+        }
+    }
+}
+
+extern "C" int ddx_antialias_fwd(const float* color, int C, const float* rast, const float* pos, const int32_t* tri,
+                                 const int32_t* opp, int B, int V, int T, int H, int W, float* out, void* stream)
+{
+    DDX_REQUIRE(color && rast && pos && tri && opp && out, DDX_E_NULL, "antialias_fwd: NULL pointer");
+    DDX_REQUIRE(C >= 1 && C <= 64 && B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "antialias_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)B * H * W;
+    DDX_HIP(hipMemcpyAsync(out, color, (size_t)n * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    antialias_kernel<false><<<PIX_GRID(n), 256, 0, s>>>(color, C, rast, pos, tri, opp, B, V, T, H, W, nullptr, out, nullptr);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_antialias_bwd(const float* color, int C, const float* rast, const float* pos, const int32_t* tri,
+                                 const int32_t* opp, int B, int V, int T, int H, int W, const float* dout,
+                                 float* dcolor, float* dpos, void* stream)
+{
+    DDX_REQUIRE(color && rast && pos && tri && opp && dout && dcolor && dpos, DDX_E_NULL, "antialias_bwd: NULL pointer");
+    DDX_REQUIRE(C >= 1 && C <= 64 && B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "antialias_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)B * H * W;
+    DDX_HIP(hipMemcpyAsync(dcolor, dout, (size_t)n * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DDX_HIP(hipMemsetAsync(dpos, 0, (size_t)B * V * 4 * sizeof(float), s));
+    antialias_kernel<true><<<PIX_GRID(n), 256, 0, s>>>(color, C, rast, pos, tri, opp, B, V, T, H, W, dout, dcolor, dpos);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}

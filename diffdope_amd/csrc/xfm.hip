@@ -24,13 +24,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 template <bool MFMA, bool POINTS>
 __global__ __launch_bounds__(XFM_BLOCK) void xfm_fwd_kernel(const float* __restrict__ points, long long pbs,
-                                                            const float* __restrict__ matrix, int N,
+                                                            const float* __restrict__ matrix, int mbs, int N,
                                                             float* __restrict__ out)
 {
     const int b = blockIdx.y;
     const int n = blockIdx.x * XFM_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const float* M = matrix + (size_t)b * 16;
+    const float* M = matrix + (size_t)b * mbs;
     const bool live = n < N;
     const float* p = points + (size_t)b * pbs + (size_t)(live ? n : 0) * 3;
     const float px = p[0], py = p[1], pz = p[2];
@@ -218,12 +218,21 @@ extern "C" int ddx_xfm_fwd(const float* points, long long pbs, const float* matr
     dim3 grid(ddx_cdiv(N, XFM_BLOCK), B), block(XFM_BLOCK);
     hipStream_t s = (hipStream_t)stream;
     if (variant == 0) {
-        if (is_points) xfm_fwd_kernel<true, true><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
-        else xfm_fwd_kernel<true, false><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
+        if (is_points) xfm_fwd_kernel<true, true><<<grid, block, 0, s>>>(points, pbs, matrix, 16, N, out);
+        else xfm_fwd_kernel<true, false><<<grid, block, 0, s>>>(points, pbs, matrix, 16, N, out);
     } else {
-        if (is_points) xfm_fwd_kernel<false, true><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
-        else xfm_fwd_kernel<false, false><<<grid, block, 0, s>>>(points, pbs, matrix, N, out);
+        if (is_points) xfm_fwd_kernel<false, true><<<grid, block, 0, s>>>(points, pbs, matrix, 16, N, out);
+        else xfm_fwd_kernel<false, false><<<grid, block, 0, s>>>(points, pbs, matrix, 16, N, out);
     }
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+// internal: one shared point set, per-hypothesis matrices `mstride` floats apart (fused engine)
+int ddx_xfm_fwd_strided(const float* points, const float* matrix0, int mstride, int B, int N, float* out, hipStream_t s)
+{
+    dim3 grid(ddx_cdiv(N, XFM_BLOCK), B), block(XFM_BLOCK);
+    xfm_fwd_kernel<true, true><<<grid, block, 0, s>>>(points, 0, matrix0, mstride, N, out);
     DDX_LAUNCH_CHECK();
     return 0;
 }

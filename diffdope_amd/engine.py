@@ -1,0 +1,130 @@
+"""Python face of the fused refinement engine (csrc/engine.hip, include/ddx.h ddx_engine_*).
+
+`RefineEngine` runs the body of DiffDope.run_optimization (diffdope/diffdope.py:1656-1714) for the
+built-in losses entirely on the device.  All buffers are torch tensors owned here; the native side
+only borrows pointers.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .render import build_topology
+
+KERNEL_NAMES_MAX = 16
+
+
+class RefineEngine:
+    """
+    Args (torch tensors on one ROCm device, fp32 / int32):
+        pos [V,3], tri [T,3], proj [4,4]; uv [V,2] + tex [Th,Tw,3]  or  vtx_color [V,3]
+        gt: dict with 'segmentation' [H,W,3] and optionally 'rgb' [H,W,3], 'depth' [H,W]
+            (bottom-up rows, as diffdope.py:1131 holds them)
+        params [7,B]: qx,qy,qz,qw,x,y,z (diffdope.py:1019-1026) -- updated in place
+        lr_mult [B]: per-hypothesis loss multipliers (diffdope.py:1368-1375)
+        lr_sched: list/1-D tensor of optimiser learning rates, one per iteration (diffdope.py:1657-1661)
+        weights: dict(rgb=, depth=, mask=) -- None/absent disables the term (cfg.losses)
+        global_batch: batch size of the whole job when hypotheses are sharded over GPUs
+    """
+
+    def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
+                 vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, pairs_hint=0, log_mtx=True):
+        self.lib = _lib.load()
+        dev = pos.device
+        if dev.type != "cuda":
+            raise RuntimeError("RefineEngine needs ROCm tensors (diffdope_amd has no CPU path)")
+        f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
+        self.pos, self.proj = f32(pos), f32(proj)
+        self.tri = tri.to(device=dev, dtype=torch.int32).contiguous()
+        self.opp = build_topology(self.tri)
+        self.uv, self.tex, self.vtx_color = f32(uv), f32(tex), f32(vtx_color)
+        if self.tex is not None and self.tex.dim() == 4:
+            self.tex = self.tex[0].contiguous()
+        H, W = int(resolution[0]), int(resolution[1])
+        self.H, self.W = H, W
+        self.gt_seg = f32(gt["segmentation"])
+        self.gt_rgb = f32(gt.get("rgb"))
+        self.gt_depth = f32(gt.get("depth"))
+        assert tuple(self.gt_seg.shape) == (H, W, 3), f"segmentation must be [H,W,3], got {tuple(self.gt_seg.shape)}"
+        self.params = params
+        assert params.is_cuda and params.dtype == torch.float32 and params.is_contiguous() and params.shape[0] == 7
+        B = params.shape[1]
+        self.B = B
+        self.lr_mult = f32(lr_mult)
+        self.lr_sched = torch.as_tensor(lr_sched, dtype=torch.float64).to(torch.float32).to(dev).contiguous()
+        n_it = self.lr_sched.numel()
+        self.max_iters = n_it
+        self.loss_log = torch.zeros((n_it, 3, B), dtype=torch.float32, device=dev)
+        self.mtx_log = torch.zeros((n_it, B, 16), dtype=torch.float32, device=dev) if log_mtx else None
+        w = {k: weights.get(k) for k in ("rgb", "depth", "mask")}
+        d = _lib.EngineDesc()
+        d.B, d.B_global = B, int(global_batch or B)
+        d.V, d.T, d.H, d.W = self.pos.shape[0], self.tri.shape[0], H, W
+        d.Th, d.Tw = (self.tex.shape[0], self.tex.shape[1]) if (self.tex is not None and self.vtx_color is None) else (0, 0)
+        d.use_rgb, d.use_depth, d.use_mask = int(w["rgb"] is not None), int(w["depth"] is not None), int(w["mask"] is not None)
+        d.w_rgb, d.w_depth, d.w_mask = float(w["rgb"] or 0), float(w["depth"] or 0), float(w["mask"] or 0)
+        d.optimizer = {"sgd": 0, "adam": 1}[optimizer]
+        d.adam_beta1, d.adam_beta2, d.adam_eps = adam
+        d.max_iters = n_it
+        self.desc = d
+        nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d), pairs_hint)
+        if nbytes == 0:
+            raise RuntimeError("ddx_engine_scratch_bytes: " + self.lib.ddx_last_error().decode())
+        self._scratch_raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        off = (-self._scratch_raw.data_ptr()) % 256
+        self.scratch = self._scratch_raw[off:off + nbytes]
+        b = _lib.EngineBuffers()
+        P = lambda t: None if t is None else t.data_ptr()
+        b.pos, b.tri, b.opp, b.uv, b.tex, b.vtx_color, b.proj = P(self.pos), P(self.tri), P(self.opp), P(self.uv), P(self.tex), P(self.vtx_color), P(self.proj)
+        b.gt_rgb, b.gt_depth, b.gt_seg = P(self.gt_rgb), P(self.gt_depth), P(self.gt_seg)
+        b.lr_mult, b.lr_sched, b.params = P(self.lr_mult), P(self.lr_sched), P(self.params)
+        b.loss_log, b.mtx_log = P(self.loss_log), P(self.mtx_log)
+        b.scratch, b.scratch_bytes = P(self.scratch), nbytes
+        self.bufs = b
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.ddx_engine_create(ctypes.byref(d), ctypes.byref(b), ctypes.byref(h)), "ddx_engine_create")
+        self.handle = h
+        self.it = 0
+
+    def run(self, n=None, use_graph=True):
+        """Run n iterations (default: all remaining) asynchronously on the current stream."""
+        n = self.max_iters - self.it if n is None else n
+        _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
+        self.it += n
+
+    def rewind(self, it=0):
+        self.it = it
+
+    def status(self):
+        """dict(overflow, pairs, active_tiles, it, n_seg) -- synchronises."""
+        p = self.lib.ddx_engine_status_ptr(self.handle)
+        off = p - self.scratch.data_ptr()
+        st = self.scratch[off:off + 32].view(torch.int32).cpu().tolist()
+        return dict(overflow=st[0], pairs=st[1], active_tiles=st[2], it=st[3], n_seg=st[4])
+
+    def check(self):
+        st = self.status()
+        if st["overflow"]:
+            raise RuntimeError(f"triangle bin list overflowed ({st['pairs']} pairs): re-create the engine with pairs_hint >= {2 * st['pairs']}")
+        return st
+
+    def profile(self, it0=0, iters=5):
+        """Per-kernel average launch duration in ms (hipEvents on the current stream).  Mutates params."""
+        ms = (ctypes.c_float * KERNEL_NAMES_MAX)()
+        names = (ctypes.c_char_p * KERNEL_NAMES_MAX)()
+        k = self.lib.ddx_engine_profile(self.handle, it0, iters, ms, names, KERNEL_NAMES_MAX, _lib.stream_ptr())
+        if k <= 0:
+            _lib.check(k if k else -99, "ddx_engine_profile")
+        return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+    def losses(self):
+        """[iters_done, 3, B] weighted un-LR'd per-hypothesis losses (rgb, depth, mask)."""
+        return self.loss_log[: self.it]
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ddx_engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

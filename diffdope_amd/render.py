@@ -1,0 +1,320 @@
+"""Renderer ops with the call shapes diff-dope uses from nvdiffrast (`import nvdiffrast.torch as dr`,
+diffdope/diffdope.py:25,147,198,212,214,218,221,230,1312) backed by libddx.so (csrc/raster.hip,
+csrc/renderops.hip), plus `render_texture_batch` (diffdope.py:156-234) written against them.
+
+    RasterizeGLContext()                      -> RasterizeContext (a scratch/plan holder, no GL)
+    rasterize(ctx, pos, tri, resolution)      -> (rast, rast_db)
+    interpolate(attr, rast, tri, rast_db, diff_attrs) -> (out, out_da)
+    texture(tex, uv, uv_da, filter_mode="linear")     -> out
+    antialias(color, rast, pos, tri)          -> out
+
+Differences that are visible to callers: the pixel-derivative outputs (`rast_db`, `out_da`) are
+zero-stride zero placeholders (diff-dope discards them or feeds them to texture(..., "linear") which
+ignores them); only filter_mode="linear" / boundary wrap is implemented; everything needs ROCm
+tensors (no CPU fallback).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from . import ops as dd_ops
+
+
+def _f32c(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/ROCm tensor (diffdope_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t.contiguous()
+
+
+def _i32c(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/ROCm tensor")
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be int32")
+    if t.dim() != 2 or t.shape[1] != 3:
+        raise RuntimeError(f"{name} must be [num_triangles, 3], got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class RasterizeContext:
+    """Stands in for dr.RasterizeGLContext() (diffdope.py:1312): owns the binning scratch (a torch
+    buffer, so the caching allocator sees it) and grows it if the bin list overflows."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        self.device = device
+        self._scratch = None
+        self._key = None
+        self._pairs_hint = 0
+
+    def scratch(self, B, T, H, W, device):
+        key = (B, T, H, W, self._pairs_hint, str(device))
+        if self._key != key:
+            nbytes = self.lib.ddx_rasterize_scratch_bytes(B, T, H, W, self._pairs_hint)
+            self._scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self._key = key
+        off = (-self._scratch.data_ptr()) % 256
+        return self._scratch[off:], self._scratch.numel() - off
+
+
+RasterizeGLContext = RasterizeContext
+RasterizeCudaContext = RasterizeContext
+
+
+class _rasterize_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, glctx, pos, tri, resolution):
+        pos, tri = _f32c(pos, "pos"), _i32c(tri, "tri")
+        if pos.dim() != 3 or pos.shape[2] != 4:
+            raise RuntimeError(f"pos must be [B,V,4] (instanced mode), got {tuple(pos.shape)}")
+        H, W = int(resolution[0]), int(resolution[1])
+        B, V, T = pos.shape[0], pos.shape[1], tri.shape[0]
+        lib = glctx.lib
+        rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device)
+        status = torch.empty(4, dtype=torch.int32, device=pos.device)
+        for _ in range(3):
+            scratch, nbytes = glctx.scratch(B, T, H, W, pos.device)
+            _lib.check(lib.ddx_rasterize_fwd(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes,
+                                             _lib.ptr(rast), _lib.ptr(status), _lib.stream_ptr()), "ddx_rasterize_fwd")
+            st = status.cpu()
+            if int(st[0]) == 0:
+                break
+            glctx._pairs_hint = int(int(st[1]) * 1.25) + 1024  # bin list overflowed: grow and redo
+        else:
+            raise RuntimeError("rasterize: bin list overflow persists")
+        ctx.save_for_backward(pos, tri, rast)
+        ctx.res = (H, W)
+        rast_db = torch.zeros((1, 1, 1, 4), dtype=torch.float32, device=pos.device).expand(B, H, W, 4)
+        ctx.mark_non_differentiable(rast_db)
+        return rast, rast_db
+
+    @staticmethod
+    def backward(ctx, drast, _ddb):
+        pos, tri, rast = ctx.saved_tensors
+        H, W = ctx.res
+        B, V, T = pos.shape[0], pos.shape[1], tri.shape[0]
+        drast = _f32c(drast, "drast")
+        dpos = torch.empty_like(pos)
+        _lib.check(_lib.load().ddx_rasterize_bwd(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(rast), _lib.ptr(drast),
+                                                 _lib.ptr(dpos), _lib.stream_ptr()), "ddx_rasterize_bwd")
+        return None, dpos, None, None
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
+    """dr.rasterize (diffdope.py:198-200).  Returns (rast [B,H,W,4] = (u,v,z/w,tri_id+1), rast_db placeholder)."""
+    if ranges is not None:
+        raise RuntimeError("range mode is not implemented (diff-dope uses instanced mode only)")
+    return _rasterize_func.apply(glctx, pos, tri, resolution)
+
+
+class _interpolate_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri):
+        if not attr.is_cuda or attr.dtype != torch.float32:
+            raise RuntimeError("attr must be a float32 CUDA/ROCm tensor")
+        rast, tri = _f32c(rast, "rast"), _i32c(tri, "tri")
+        B, H, W = rast.shape[:3]
+        if attr.dim() == 2:
+            attr3 = attr[None]
+        elif attr.shape[0] > 1 and attr.stride(0) == 0:
+            attr3 = attr[:1]  # batch-expanded view (what Mesh.set_batchsize produces here): use the one copy
+        else:
+            attr3 = attr
+        attr3 = attr3.contiguous()
+        Ba, Va, A = attr3.shape
+        if Ba not in (1, B):
+            raise RuntimeError(f"attr batch must be 1 or {B}, got {Ba}")
+        abs_ = 0 if Ba == 1 else Va * A
+        out = torch.empty((B, H, W, A), dtype=torch.float32, device=rast.device)
+        _lib.check(_lib.load().ddx_interpolate_fwd(_lib.ptr(attr3), abs_, Va, A, _lib.ptr(rast), _lib.ptr(tri), tri.shape[0],
+                                                   B, H, W, _lib.ptr(out), _lib.stream_ptr()), "ddx_interpolate_fwd")
+        ctx.save_for_backward(attr3, rast, tri)
+        ctx.attr_shape = tuple(attr.shape)
+        ctx.abs_ = abs_
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        attr3, rast, tri = ctx.saved_tensors
+        B, H, W = rast.shape[:3]
+        Ba, Va, A = attr3.shape
+        dout = _f32c(dout, "dout")
+        need_attr = ctx.needs_input_grad[0]
+        dattr = torch.empty_like(attr3) if need_attr else None
+        drast = torch.empty_like(rast)
+        _lib.check(_lib.load().ddx_interpolate_bwd(_lib.ptr(attr3), ctx.abs_, Va, A, _lib.ptr(rast), _lib.ptr(tri), tri.shape[0],
+                                                   B, H, W, _lib.ptr(dout), _lib.ptr(dattr), _lib.ptr(drast), _lib.stream_ptr()),
+                   "ddx_interpolate_bwd")
+        if dattr is not None:
+            if len(ctx.attr_shape) == 3 and ctx.attr_shape[0] != dattr.shape[0]:
+                # input was a stride-0 batch view: spread the summed gradient so that autograd's own
+                # reduction over the expanded dimension restores it
+                dattr = (dattr / ctx.attr_shape[0]).expand(ctx.attr_shape)
+            else:
+                dattr = dattr.reshape(ctx.attr_shape)
+        return dattr, drast, None
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """dr.interpolate (diffdope.py:147-153).  Returns (out [B,H,W,A], out_da placeholder)."""
+    out = _interpolate_func.apply(attr, rast, tri)
+    if rast_db is not None and diff_attrs is not None:
+        A = out.shape[-1]
+        out_da = torch.zeros((1, 1, 1, 1), dtype=torch.float32, device=out.device).expand(*out.shape[:3], 2 * A)
+    else:
+        out_da = torch.zeros((out.shape[0], out.shape[1], out.shape[2], 0), dtype=torch.float32, device=out.device)
+    return out, out_da
+
+
+class _texture_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv):
+        if not tex.is_cuda or tex.dtype != torch.float32:
+            raise RuntimeError("tex must be a float32 CUDA/ROCm tensor")
+        uv = _f32c(uv, "uv")
+        if tex.dim() != 4 or uv.dim() != 4 or uv.shape[3] != 2:
+            raise RuntimeError(f"tex must be [Bt,Th,Tw,C] and uv [B,H,W,2], got {tuple(tex.shape)} / {tuple(uv.shape)}")
+        B, H, W = uv.shape[:3]
+        Bt, Th, Tw, C = tex.shape
+        if Bt not in (1, B):
+            raise RuntimeError(f"tex batch must be 1 or {B}, got {Bt}")
+        # a batch-expanded (stride 0) texture -- what Mesh.set_batchsize produces here -- is used in place
+        if Bt == B and B > 1 and tex.stride(0) == 0:
+            tex_c, tbs, Bt_eff = tex[:1].contiguous(), 0, 1
+        else:
+            tex_c = tex.contiguous()
+            tbs, Bt_eff = (0, 1) if Bt == 1 else (Th * Tw * C, Bt)
+        out = torch.empty((B, H, W, C), dtype=torch.float32, device=uv.device)
+        _lib.check(_lib.load().ddx_texture_linear_fwd(_lib.ptr(tex_c), tbs, Th, Tw, C, _lib.ptr(uv), B, H, W, _lib.ptr(out),
+                                                      _lib.stream_ptr()), "ddx_texture_linear_fwd")
+        ctx.save_for_backward(tex_c, uv)
+        ctx.meta = (tbs, Bt_eff, tuple(tex.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tex_c, uv = ctx.saved_tensors
+        tbs, Bt_eff, tex_shape = ctx.meta
+        B, H, W = uv.shape[:3]
+        _, Th, Tw, C = tex_c.shape
+        dout = _f32c(dout, "dout")
+        duv = torch.empty_like(uv)
+        dtex = torch.empty_like(tex_c) if ctx.needs_input_grad[0] else None
+        _lib.check(_lib.load().ddx_texture_linear_bwd(_lib.ptr(tex_c), tbs, Th, Tw, C, _lib.ptr(uv), B, H, W, _lib.ptr(dout),
+                                                      _lib.ptr(duv), _lib.ptr(dtex), Bt_eff, _lib.stream_ptr()),
+                   "ddx_texture_linear_bwd")
+        if dtex is not None and tuple(dtex.shape) != tex_shape:
+            dtex = (dtex / tex_shape[0]).expand(tex_shape)  # stride-0 batch view: autograd sums it back
+        return dtex, duv
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="auto", boundary_mode="wrap", max_mip_level=None):
+    """dr.texture (diffdope.py:221-226): bilinear, wrap."""
+    if filter_mode == "auto":
+        filter_mode = "linear"
+    if filter_mode != "linear" or boundary_mode != "wrap":
+        raise RuntimeError("only filter_mode='linear', boundary_mode='wrap' is implemented (what diff-dope uses)")
+    return _texture_func.apply(tex, uv)
+
+
+_topology_cache = {}
+
+
+def build_topology(tri):
+    """opp [T,3] int32 on tri's device (ddx_topology_build on the host, cached per index buffer)."""
+    key = (tri.data_ptr(), tuple(tri.shape), str(tri.device), tri._version)
+    hit = _topology_cache.get(key)
+    if hit is not None:
+        return hit
+    tri_h = np.ascontiguousarray(tri.detach().cpu().numpy().astype(np.int32))
+    opp_h = np.empty_like(tri_h)
+    _lib.check(_lib.load().ddx_topology_build(tri_h.ctypes.data, tri_h.shape[0], opp_h.ctypes.data), "ddx_topology_build")
+    opp = torch.from_numpy(opp_h).to(tri.device)
+    if len(_topology_cache) > 16:
+        _topology_cache.clear()
+    _topology_cache[key] = opp
+    return opp
+
+
+class _antialias_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, opp):
+        color, rast, pos, tri = _f32c(color, "color"), _f32c(rast, "rast"), _f32c(pos, "pos"), _i32c(tri, "tri")
+        B, H, W, C = color.shape
+        V, T = pos.shape[1], tri.shape[0]
+        out = torch.empty_like(color)
+        _lib.check(_lib.load().ddx_antialias_fwd(_lib.ptr(color), C, _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp),
+                                                 B, V, T, H, W, _lib.ptr(out), _lib.stream_ptr()), "ddx_antialias_fwd")
+        ctx.save_for_backward(color, rast, pos, tri, opp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        color, rast, pos, tri, opp = ctx.saved_tensors
+        B, H, W, C = color.shape
+        V, T = pos.shape[1], tri.shape[0]
+        dout = _f32c(dout, "dout")
+        dcolor = torch.empty_like(color)
+        dpos = torch.empty_like(pos)
+        _lib.check(_lib.load().ddx_antialias_bwd(_lib.ptr(color), C, _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp),
+                                                 B, V, T, H, W, _lib.ptr(dout), _lib.ptr(dcolor), _lib.ptr(dpos),
+                                                 _lib.stream_ptr()), "ddx_antialias_bwd")
+        return dcolor, None, dpos, None, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    """dr.antialias (diffdope.py:214)."""
+    opp = topology_hash if topology_hash is not None else build_topology(tri)
+    out = _antialias_func.apply(color, rast, pos, tri, opp)
+    return out
+
+
+def antialias_construct_topology_hash(tri):
+    return build_topology(tri)
+
+
+# ------------------------------------------------------------------------------------------------
+def _interpolate_wrapper(attr, rast, attr_idx, rast_db=None):
+    """diffdope.py:143-153"""
+    return interpolate(attr.contiguous(), rast, attr_idx, rast_db=rast_db, diff_attrs=None if rast_db is None else "all")
+
+
+def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None, uv_idx=None, tex=None, vtx_color=None,
+                         return_rast_out=False):
+    """Same signature, outputs and op order as diffdope.py:156-234 (op-by-op path: materialises every
+    image; the fused engine in diffdope_amd.engine is the fast path for the built-in losses).
+
+    Returns dict(rgb [B,H,W,3], depth [B,H,W], rast_out or None, mask [B,H,W,3]).
+    """
+    if not type(resolution) == list:
+        resolution = [resolution, resolution]
+    dev = pos.device
+    posw = torch.cat([pos, torch.ones([pos.shape[0], pos.shape[1], 1], device=dev)], axis=2)
+    final_mtx_proj = torch.matmul(proj_cam, mtx)
+    pos_clip_ja = dd_ops.xfm_points(pos.contiguous(), final_mtx_proj)
+    tri = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
+    rast_out, rast_out_db = rasterize(glctx, pos_clip_ja, tri, resolution=resolution)
+
+    gb_pos, _ = _interpolate_wrapper(posw, rast_out, tri, rast_db=rast_out_db)
+    shape_keep = gb_pos.shape
+    gb_pos = gb_pos.reshape(shape_keep[0], -1, shape_keep[-1])[..., :3]
+    depth = dd_ops.xfm_points(gb_pos.contiguous(), mtx)
+    depth = depth.reshape(shape_keep)[..., 2] * -1
+
+    ones = torch.ones((1, tri.shape[0], 3), device=dev)  # the reference indexes a [B,T,3] ones tensor per vertex
+    mask, _ = interpolate(ones, rast_out, tri, rast_db=rast_out_db, diff_attrs="all")
+    mask = antialias(mask, rast_out, pos_clip_ja, tri)
+
+    if vtx_color is None:
+        uvi = uv_idx[0] if uv_idx.dim() == 3 else uv_idx
+        texc, texd = interpolate(uv, rast_out, uvi, rast_db=rast_out_db, diff_attrs="all")
+        color = texture(tex, texc, texd, filter_mode="linear")
+        color = color * torch.clamp(rast_out[..., -1:], 0, 1)
+    else:
+        color, _ = interpolate(vtx_color, rast_out, tri)
+        color = color * torch.clamp(rast_out[..., -1:], 0, 1)
+    if not return_rast_out:
+        rast_out = None
+    return {"rgb": color, "depth": depth, "rast_out": rast_out, "mask": mask}

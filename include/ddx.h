@@ -167,8 +167,9 @@ int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* buf
 /* Run iterations [it0, it0+n) (rows of lr_sched / loss_log / mtx_log).  use_graph != 0 replays a
  * captured hipGraph of one iteration. */
 int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
-/* device int32[8] inside scratch: [0] overflow flag, [1] (tile,tri) pairs of the last iteration,
- * [2] active tiles of the last iteration */
+/* device int32[8] inside scratch: [0] sticky bin-overflow flag (results invalid: enlarge scratch),
+ * [1] (tile,triangle) pairs of the last iteration, [2] active tiles of the last iteration,
+ * [3] next iteration index, [4] pixels with seg != 0 */
 const int32_t* ddx_engine_status_ptr(ddx_engine* e);
 /* per-kernel launch durations of the last ddx_engine_profile call are returned in ms (host array
  * of `n_kernels`), measured with hipEvents on `stream`; returns the number of kernels. */
