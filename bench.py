@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- render+backward iterations/sec of the fused refinement engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one full optimiser iteration (pose -> matrices -> vertex transform -> binning/raster ->
+shade + losses + analytic backward -> d loss/d(q,t) -> optimiser step) over the 64 pose hypotheses a GPU
+owns, on BASELINE.json configs[1] ("cfg2": 20 480-triangle textured mesh, 640x480, rgb+mask loss),
+synthetic inputs resident in HBM.  Multi-GPU = hypothesis sharding (weak scaling: 64 hypotheses per
+GPU, global batch 64*N in the batch-mean factor) with ONE all_reduce for the global arg-min pose.
+Rank 0 prints one JSON line; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy rate)
+
+
+def algorithmic_bytes(V, T, HW, B):
+    """SURVEY.md section 8(d), fp32/int32 'visibility-buffer model', bytes per LAUNCH (all B hypotheses)."""
+    return {
+        "pose_kernel": 28.0 * B + 128.0 * B,
+        "xfm_fwd_kernel": (12.0 * V + 16.0 * V) * B,
+        # raster row of 8(d): 16V r + 12T r + 16 HW w -- attributed to the four launches that make it up
+        "raster_stage": (16.0 * V + 12.0 * T + 16.0 * HW) * B,
+        # shade+loss fwd (16 HW r) + bwd (16 HW r + 32 V) + pose-grad contraction (28 V) are ONE kernel here;
+        # the observed images (20 HW, read in fwd and bwd) are shared by all hypotheses
+        "shade_kernel": (32.0 * HW + 60.0 * V) * B + 40.0 * HW,
+        "update_kernel": 28.0 * B * 2,
+        "iteration": (104.0 * V + 12.0 * T + (48.0 + 40.0 / B) * HW) * B,
+    }
+
+
+def cpu_baseline(w, budget_s=12.0):
+    """The oracle (CPU port of the same iteration, op by op like the reference) timed on this host, on a
+    bounded sample: whole iterations of a 2-hypothesis batch until ~budget_s seconds have been spent."""
+    import numpy as np
+
+    from oracle import oracle as orc  # cpu_baseline leg only
+
+    npy = lambda t: None if t is None else t.detach().cpu().numpy()
+    kw = dict(uv=npy(w["uv"]), tex=npy(w["tex"])) if w["tex"] is not None else dict(vtx_color=npy(w["vtx_color"]))
+    wts = {k: w["weights"].get(k) for k in ("rgb", "depth", "mask")}
+    R = orc.RenderOracle(npy(w["pos"]), npy(w["tri"]), npy(w["proj"]), w["H"], w["W"], {k: npy(v) for k, v in w["gt"].items()}, wts,
+                         dtype=np.float32, **kw)
+    params = npy(w["params0"])[:, :2].copy()
+    lrm = npy(w["lr_mult"])[:2].copy()
+    R.loss_and_grad(params, lrm)  # warm caches
+    n, t0 = 0, time.perf_counter()
+    while True:
+        R.loss_and_grad(params, lrm)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    s_per_hyp_iter = el / (n * 2)
+    return {
+        "value": 1.0 / (s_per_hyp_iter * w["B"]), "unit": "iters/s", "cores": 1, "kind": "port",
+        "sample": f"{n} iterations x 2 hypotheses of the same workload ({el:.1f} s), scaled to {w['B']} hypotheses/iter",
+        "s_per_hypothesis_iteration": s_per_hyp_iter,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import diffdope_amd as dd
+    from diffdope_amd import dist as ddist
+    from diffdope_amd import workloads as wl
+
+    Bl = wl.CONFIGS[args.config]["B"]  # hypotheses per GPU (weak scaling)
+    w = wl.build(args.config, dev, B=Bl, global_lo=rank * Bl, global_B=Bl * world)
+    n_it = args.warmup + args.steps
+    base = 0.005 if args.optimizer == "adam" else 1.0
+    lrs = [base * l / 2.0 for l in wl.lr_schedule(max(n_it - 1, 1), 20, 0.1)][:n_it]
+    params = w["params0"].clone()
+    eng = dd.RefineEngine(w["pos"], w["tri"], w["proj"], [w["H"], w["W"]], w["gt"], params, w["lr_mult"], lrs, w["weights"],
+                          uv=w["uv"], tex=w["tex"], vtx_color=w["vtx_color"], optimizer=args.optimizer, global_batch=Bl * world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    used = [i for i, k in enumerate(("rgb", "depth", "mask")) if w["weights"].get(k) is not None]
+
+    def select_best(it):
+        # the one collective of the job: global arg-min hypothesis + its pose (diffdope.py:1488-1513,1618-1632)
+        per_hyp = eng.loss_log[it][used].mean(0)
+        return per_hyp, ddist.global_argmin(per_hyp, eng.mtx_log[it].reshape(Bl, 4, 4), lo=rank * Bl)
+
+    eng.run(args.warmup, use_graph=not args.no_graph)
+    if args.warmup > 0:
+        select_best(args.warmup - 1)  # warm the selection path too (first-use kernel loads, RCCL channel setup)
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(args.steps, use_graph=not args.no_graph)
+    per_hyp, (gidx, gloss, gpose) = select_best(n_it - 1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    st = eng.check()
+
+    if rank == 0:
+        rot, tr = wl.pose_errors(params, w["q_gt"], w["t_gt"])
+        add = wl.add_error(params, w["pos"], w["q_gt"], w["t_gt"])
+        lbest = int(np.argmin(per_hyp.cpu().numpy()))
+        V, T, HW = w["V"], w["T"], w["H"] * w["W"]
+        alg = algorithmic_bytes(V, T, HW, Bl)
+        # per-kernel launch durations, live, HIP events on the launch stream (a second engine: profiling mutates poses)
+        p2 = w["params0"].clone()
+        eng2 = dd.RefineEngine(w["pos"], w["tri"], w["proj"], [w["H"], w["W"]], w["gt"], p2, w["lr_mult"], lrs, w["weights"],
+                               uv=w["uv"], tex=w["tex"], vtx_color=w["vtx_color"], optimizer=args.optimizer, global_batch=Bl * world)
+        eng2.run(min(args.warmup, n_it - 1))
+        torch.cuda.synchronize()
+        kms = eng2.profile(it0=min(args.warmup, n_it - 1), iters=max(1, min(20, n_it - args.warmup)))
+        raster_ms = sum(kms[k] for k in ("bin_kernel<count>", "scan_kernel", "bin_kernel<fill>", "raster_kernel"))
+        groups = {"pose_kernel": kms["pose_kernel"], "xfm_fwd_kernel": kms["xfm_fwd_kernel"], "raster_stage": raster_ms,
+                  "shade_kernel": kms["shade_kernel"], "update_kernel": kms["update_kernel"]}
+        dom = max(("shade_kernel", "raster_kernel"), key=lambda k: kms[k])
+        dom_bytes = alg["shade_kernel"] if dom == "shade_kernel" else alg["raster_stage"]
+        achieved = dom_bytes / (kms[dom] * 1e-3) / 1e9
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "render+backward iters/sec at 640x480, 64 hypotheses per iteration",
+            "value": world * args.steps / elapsed,
+            "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: seeded blob mesh T={T} V={V}, 2048^2 texture, {w['W']}x{w['H']}, "
+                                   f"{Bl} hypotheses/GPU, losses {sorted(w['weights'])}, optimizer {args.optimizer}, "
+                                   f"object covers {100 * w['coverage']:.2f}% of the frame",
+                       "hypotheses_per_gpu": Bl, "global_hypotheses": Bl * world, "parallelism": f"hyp-shard x{world}",
+                       "hipgraph": not args.no_graph},
+            "hypothesis_iters_per_s": world * Bl * args.steps / elapsed,
+            "iteration_model_GBps": alg["iteration"] * args.steps / elapsed / 1e9,
+            "iteration_model_frac_of_hbm_peak": alg["iteration"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kms[dom],
+                         "note": "algorithmic bytes = SURVEY 8(d) visibility-buffer model (full-frame G-buffer streams); this "
+                                 "engine touches active tiles only, so frac can exceed 1 -- see DESIGN.md and profiles/"},
+            "kernel_ms": kms, "stage_ms": groups,
+            "final_pose": {"argmin_global_index": gidx, "argmin_loss": gloss,
+                           "rot_err_rad_best": float(rot[lbest]), "trans_err_m_best": float(tr[lbest]), "add_m_best": float(add[lbest]),
+                           "rot_err_rad_median": float(np.median(rot)), "trans_err_m_median": float(np.median(tr))},
+            "engine_status": st,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

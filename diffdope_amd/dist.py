@@ -1,0 +1,51 @@
+"""Hypothesis sharding over the GPUs of one node.
+
+Hypotheses are independent (per-hypothesis parameters diffdope.py:1019-1026 and losses :534-544), so
+rank r simply owns a contiguous slice of the batch; mesh, texture and observed images are replicated.
+The only exchange is the final arg-min over all hypotheses (get_argmin / get_pose semantics,
+diffdope.py:1488-1513,1618-1632): every rank puts (loss, global index, 4x4 pose) of its local best into
+its row of a zeroed [world,18] buffer, ONE all_reduce(SUM) over RCCL/xGMI (576 B at 8 GPUs: latency
+bound) makes the table identical everywhere, and each rank takes the row-arg-min.
+"""
+import torch
+
+
+def shard_range(total, rank, world):
+    """Contiguous slice [lo,hi) of `total` hypotheses owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def local_best(per_hyp_loss, mtx):
+    """per_hyp_loss [B_local], mtx [B_local,4,4] -> (loss scalar tensor, local index tensor, mtx [16])."""
+    idx = torch.argmin(per_hyp_loss)
+    return per_hyp_loss[idx], idx, mtx[idx].reshape(16)
+
+
+def global_argmin(per_hyp_loss, mtx, lo=0, group=None):
+    """Arg-min over the hypotheses of ALL ranks with a single all_reduce.
+
+    per_hyp_loss [B_local] (mean over loss keys of the last-step losses, diffdope.py:1505-1511),
+    mtx [B_local,4,4]; lo = global index of this rank's first hypothesis.
+    Returns (global_index:int, loss:float, pose [4,4] tensor), identical on every rank.
+    Ties resolve to the lowest global index (what torch.argmin over the concatenated batch gives).
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    loss, idx, m = local_best(per_hyp_loss, mtx)
+    table = torch.zeros((world, 18), dtype=torch.float64 if per_hyp_loss.device.type == "cpu" else torch.float32,
+                        device=per_hyp_loss.device)
+    table[rank, 0] = loss
+    table[rank, 1] = (idx + lo).to(table.dtype)
+    table[rank, 2:] = m.to(table.dtype)
+    if world > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    # row arg-min, ties -> lowest global index
+    losses, gidx = table[:, 0], table[:, 1]
+    best = torch.min(losses)
+    cand = torch.where(losses == best, gidx, torch.full_like(gidx, float("inf")))
+    row = int(torch.argmin(cand))
+    return int(table[row, 1].item()), float(table[row, 0].item()), table[row, 2:].reshape(4, 4).to(mtx.dtype)

@@ -1,0 +1,103 @@
+"""Synthetic BASELINE.json workloads, built on the device with the product's own
+renderer: mesh, texture, camera, the observed images rendered at a known pose, and the batch of
+initial hypotheses."""
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import synthetic as syn
+from .render import RasterizeContext, render_texture_batch
+from .pose import matrix_batch_44_from_position_quat
+
+# name -> (rows, cols) of the blob mesh (T = 2*rows*cols), B, (H,W), textured, loss weights
+CONFIGS = {
+    # BASELINE.json configs[0]: the reference's own example size, CPU-runnable
+    "cfg1": dict(rows=77, cols=90, B=1, H=120, W=160, textured=True, weights=dict(mask=1.0), tex=2048),
+    # configs[1]: the configuration the headline metric is quoted on
+    "cfg2": dict(rows=80, cols=128, B=64, H=480, W=640, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
+    # configs[2] without the edge loss (an extension with no reference counterpart)
+    "cfg3": dict(rows=160, cols=160, B=128, H=480, W=640, textured=True, weights=dict(rgb=0.7, depth=1.0), tex=2048),
+    # configs[3]: per-GPU share of the 512-hypothesis untextured job
+    "cfg4": dict(rows=100, cols=150, B=64, H=480, W=640, textured=False, weights=dict(depth=1.0, mask=1.0), tex=0),
+    "tiny": dict(rows=16, cols=20, B=4, H=60, W=80, textured=True, weights=dict(rgb=0.7, depth=1.0, mask=1.0), tex=64),
+}
+
+
+def projection_matrix(fx, fy, cx, cy, im_width, im_height, znear=0.01, zfar=200.0):
+    """Camera.get_projection_matrix, 'y_down' window convention (diffdope.py:679-742)."""
+    w, h = im_width, im_height
+    depth = float(zfar - znear)
+    q = -(zfar + znear) / depth
+    qn = -2 * (zfar * znear) / depth
+    return np.array([[2 * fx / w, 0, (-2 * cx + w) / w, 0], [0, 2 * fy / h, (2 * cy - h) / h, 0], [0, 0, q, qn], [0, 0, -1, 0]],
+                    dtype=np.float64)
+
+
+def lr_schedule(nb_iterations, base_lr, lr_decay):
+    """diffdope.py:1657-1661: one optimiser lr per iteration, nb_iterations+1 entries."""
+    return [base_lr * lr_decay ** (it / nb_iterations + 1) for it in range(nb_iterations + 1)]
+
+
+def build(name, device, B=None, seed=0, global_lo=0, global_B=None, rot_deg=10.0, trans_frac=0.04, distance=7.5):
+    """Returns a dict of device tensors describing the workload.  Hypothesis b of the GLOBAL batch gets
+    initial pose / multiplier number (global_lo + b), so shards of one job are consistent."""
+    cfg = dict(CONFIGS[name])
+    B = cfg["B"] if B is None else B
+    global_B = B if global_B is None else global_B
+    H, W = cfg["H"], cfg["W"]
+    pos, tri, uv = syn.blob_mesh(cfg["rows"], cfg["cols"], seed=seed)
+    T = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=device)
+    out = dict(name=name, H=H, W=W, B=B, global_B=global_B, weights=cfg["weights"], V=pos.shape[0], T=tri.shape[0])
+    out["pos"], out["tri"] = T(pos), T(tri, torch.int32)
+    if cfg["textured"]:
+        out["uv"], out["tex"], out["vtx_color"] = T(uv), T(syn.texture(cfg["tex"], seed=seed + 1)), None
+    else:
+        out["uv"], out["tex"], out["vtx_color"] = None, None, T(syn.vertex_colors(pos, seed=seed + 5))
+    proj = projection_matrix(**syn.camera_intrinsics(W, H))
+    out["proj"] = T(proj)
+    rng = np.random.RandomState(seed + 2)
+    q_gt, t_gt = syn.random_quat(rng), np.array([0.0, 0.0, -distance])
+    out["q_gt"], out["t_gt"] = q_gt, t_gt
+    # observed images: rendered by the HIP renderer at the GT pose (bottom-up rows, as diffdope.py:1131 holds them)
+    with torch.no_grad():
+        mtx = matrix_batch_44_from_position_quat(q=T(q_gt)[None], p=T(t_gt)[None])
+        kw = dict(uv=out["uv"][None], uv_idx=out["tri"][None], tex=out["tex"][None]) if cfg["textured"] else dict(vtx_color=out["vtx_color"][None])
+        r = render_texture_batch(RasterizeContext(), out["proj"][None], mtx, out["pos"][None], out["tri"][None], [H, W],
+                                 return_rast_out=True, **kw)
+        seg = (r["rast_out"][0, ..., 3:] > 0).float().expand(H, W, 3).contiguous()
+        out["gt"] = dict(rgb=r["rgb"][0].contiguous(), depth=r["depth"][0].contiguous(), segmentation=seg)
+        out["coverage"] = float(seg[..., 0].mean())
+    # hypotheses: GT perturbed per hypothesis (north_star mode), seeded per GLOBAL index
+    params = np.zeros((7, B), np.float32)
+    lr_mult = np.zeros(B, np.float32)
+    for b in range(B):
+        g = global_lo + b
+        r_b = np.random.RandomState(seed * 100003 + 17 + g)
+        q, t = syn.perturb_pose(q_gt, t_gt, rot_deg * r_b.uniform(0.2, 1.0), trans_frac * r_b.uniform(0.2, 1.0), r_b)
+        params[:4, b], params[4:, b] = q, t
+        lr_mult[b] = math.exp(random.Random(3 + g).uniform(math.log(0.5), math.log(2.0)))
+    out["params0"], out["lr_mult"] = T(params), T(lr_mult)
+    return out
+
+
+def pose_errors(params, q_gt, t_gt, unit_m=0.1):
+    """Rotation geodesic (rad) and translation error (m; 1 scene unit = 0.1 m, configs/diffdope.yaml:16) per hypothesis."""
+    p = params.detach().cpu().numpy().astype(np.float64)
+    rot = np.array([syn.rotation_geodesic(p[:4, b], q_gt) for b in range(p.shape[1])])
+    tr = np.linalg.norm(p[4:].T - np.asarray(t_gt)[None], axis=1) * unit_m
+    return rot, tr
+
+
+def add_error(params, pos, q_gt, t_gt, unit_m=0.1):
+    """ADD = mean_v |(R x + t) - (R* x + t*)| per hypothesis, metres (defined by this build)."""
+    dev = pos.device
+    q = params[:4].T / torch.norm(params[:4].T, dim=1, keepdim=True)
+    M = matrix_batch_44_from_position_quat(q=q, p=params[4:].T)
+    Mg = matrix_batch_44_from_position_quat(q=torch.tensor(q_gt, dtype=torch.float32, device=dev)[None],
+                                            p=torch.tensor(t_gt, dtype=torch.float32, device=dev)[None])
+    ph = torch.cat([pos, torch.ones_like(pos[:, :1])], 1)
+    a = torch.matmul(ph[None], M.transpose(1, 2))[..., :3]
+    g = torch.matmul(ph[None], Mg.transpose(1, 2))[..., :3]
+    return (torch.norm(a - g, dim=2).mean(1) * unit_m).cpu().numpy()
