@@ -1,0 +1,70 @@
+"""world_size-2 gloo test (CPU) of the only exchange step of the path: the global arg-min over the
+hypothesis shards (diffdope_amd/dist.py)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, losses, mtx, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffdope_amd.dist import global_argmin, shard_range
+
+    res = []
+    for case in range(losses.shape[0]):
+        lo, hi = shard_range(losses.shape[1], rank, world)
+        gi, gl, gm = global_argmin(torch.tensor(losses[case, lo:hi]), torch.tensor(mtx[case, lo:hi]), lo=lo)
+        res.append((gi, gl, gm.numpy().copy()))
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_argmin_two_ranks_gloo():
+    rng = np.random.RandomState(0)
+    B, cases = 10, 4
+    losses = rng.uniform(size=(cases, B)).astype(np.float32)
+    losses[1, 7] = losses[1, 2] = losses[1].min() - 0.1  # a tie across the two shards -> lowest global index
+    losses[2, 9] = -1.0  # winner on the last rank
+    losses[3, 0] = -1.0  # winner on rank 0
+    mtx = rng.normal(size=(cases, B, 4, 4)).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, losses, mtx, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for case in range(cases):
+        expect = int(np.argmin(losses[case]))
+        for rank in (0, 1):
+            gi, gl, gm = got[rank][case]
+            assert gi == expect
+            assert abs(gl - float(losses[case, expect])) < 1e-6
+            np.testing.assert_allclose(gm, mtx[case, expect], rtol=1e-6)
+
+
+def test_global_argmin_single_process_matches_reference_get_argmin(golden_dir):
+    """World size 1 (no process group): same selection as DiffDope.get_argmin on the golden losses."""
+    from diffdope_amd.dist import global_argmin
+
+    g = np.load(os.path.join(golden_dir, "g6_argmin.npz"))
+    stacked = np.stack([g[f"v_{k}"][-1] for k in ("rgb", "depth", "mask_selection")]).mean(0)
+    gi, gl, _ = global_argmin(torch.tensor(stacked), torch.zeros(stacked.shape[0], 4, 4))
+    assert gi == int(g["argmin"])
