@@ -43,7 +43,7 @@ _SIGNATURES = {
     "ddx_xfm_bwd_points": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_xfm_bwd_mtx": (_I, [_P, _LL, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_xfm_bwd_full": (_I, [_P, _LL, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
-    "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _LL]),
+    "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I, _LL]),
     "ddx_rasterize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _P]),
     "ddx_rasterize_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_interpolate_fwd": (_I, [_P, _LL, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -4,10 +4,11 @@
 // (diffdope/diffdope.py:1656-1714) for B pose hypotheses with the built-in losses
 // (diffdope.py:547-613), entirely on the device:
 //
-//   pose_kernel    q/|q|, [R|t] (diffdope.py:46-89,1085-1098), final = proj . mtx (:195), mtx log
-//   xfm            clip = final . [pos;1]  (MFMA 4x4x1, xfm.hip)                    (:196)
-//   bin/scan/bin   wave-aggregated tile binning (raster.hip)
-//   raster         LDS depth tiles over ACTIVE tiles only -> vis (4 B/pixel)          (:198)
+//   pose_xfm_kernel  q/|q|, [R|t] (diffdope.py:46-89,1085-1098), final = proj . mtx (:195), mtx log,
+//                  clip = final . [pos;1] on the matrix core (MFMA 4x4x1, as xfm.hip) (:196), and the
+//                  1/256-pixel window-coordinate snap of every vertex
+//   scatter/scan/fill/raster_big   per-triangle scatter rasteriser with a binned path for large
+//                  triangles (raster.hip) -> zbuf (depth key, id), active-tile list    (:198)
 //   shade_kernel   per pixel of the active tiles, in registers: barycentrics, uv/colour/position
 //                  interpolation (:203,:218,:230), bilinear texture (:221), depth (:204-209),
 //                  antialiased coverage (:212-214), the three L1 terms against the observed images,
@@ -39,7 +40,8 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int last_active;
     int it;
     int n_seg;       // entries in the compact seg list
-    int pad[3];
+    int ticket;      // update_kernel arrival counter (the last workgroup closes the iteration)
+    int pad[2];
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
 };
@@ -81,7 +83,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base, 
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
     const size_t o_part = carve((size_t)d.B * ntx * nty * NPART * sizeof(float));
     const size_t o_rast = carve(0);
-    const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.T, d.H, d.W, pairs_hint);
+    const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W, pairs_hint);
     off += rast_bytes;
     E.st = (EngineState*)(p + o_state);
     E.mats = (float*)(p + o_mats);
@@ -155,28 +157,27 @@ __device__ __forceinline__ void quat_to_matrix(const float q[4], const float t[3
     M[12] = 0.f; M[13] = 0.f; M[14] = 0.f; M[15] = 1.f;
 }
 
-__global__ __launch_bounds__(64) void pose_kernel(EngineDev E)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// pose -> matrices -> clip-space vertices -> snapped window coordinates, one launch.
+// Every lane rebuilds its hypothesis' matrices from the 7 parameters (uniform scalar loads, ~150 flops:
+// cheaper than a separate launch + a dependent load), then transforms one vertex on the matrix core:
+// four v_mfma_f32_4x4x1_16b_f32 with A = row (lane%4) of final = proj . mtx and B = p[k]
+// (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain).
+__global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= E.d.B) return;
-    const int B = E.d.B;
-    float q[4], t[3], M[16];
+    const int b = blockIdx.y, B = E.d.B, V = E.d.V;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float q[4], t[3], M[16], F[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = E.b.params[(size_t)i * B + b];
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = E.b.params[(size_t)(4 + i) * B + b];
-    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], n);
+    for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
     quat_to_matrix(q, t, M);
-    float* dst = E.mats + (size_t)b * 32;
-    const int it = E.st->it;
-    float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        dst[i] = M[i];
-        if (logm) logm[i] = M[i];
-    }
     // final = proj . mtx  (torch.matmul at diffdope.py:195; k-ordered fma)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -185,8 +186,34 @@ __global__ __launch_bounds__(64) void pose_kernel(EngineDev E)
             float a = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) a = __fmaf_rn(E.b.proj[r * 4 + k], M[k * 4 + c], a);
-            dst[16 + r * 4 + c] = a;
+            F[r * 4 + c] = a;
         }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float* dst = E.mats + (size_t)b * 32;
+        float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)E.st->it * B + b) * 16 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dst[i] = M[i];
+            dst[16 + i] = F[i];
+            if (logm) logm[i] = M[i];
+        }
+    }
+    const int r = lane & 3;
+    const float a0 = r == 0 ? F[0] : (r == 1 ? F[4] : (r == 2 ? F[8] : F[12]));
+    const float a1 = r == 0 ? F[1] : (r == 1 ? F[5] : (r == 2 ? F[9] : F[13]));
+    const float a2 = r == 0 ? F[2] : (r == 1 ? F[6] : (r == 2 ? F[10] : F[14]));
+    const float a3 = r == 0 ? F[3] : (r == 1 ? F[7] : (r == 2 ? F[11] : F[15]));
+    const bool live = n < V;
+    const float* p = E.b.pos + (size_t)(live ? n : 0) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, px, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, py, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, pz, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, 1.0f, acc, 0, 0, 0);
+    if (!live) return;
+    *reinterpret_cast<f32x4*>(E.clip + ((size_t)b * V + n) * 4) = acc;
+    E.L.snap[(size_t)b * V + n] = snap_vertex(make_float4(acc.x, acc.y, acc.z, acc.w), E.d.H, E.d.W);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,15 +257,19 @@ __global__ __launch_bounds__(256) void shade_kernel(EngineDev E)
         const int tcx = tile % L.ntx, tcy = tile / L.ntx;
         const int ox = tcx * DDX_TILE, oy = tcy * DDX_TILE;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
-        const unsigned* __restrict__ vis = L.vis + (size_t)b * H * W;
-        const int* __restrict__ tcount = L.tile_count + (size_t)b * L.NT;
+        const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
+        const int* __restrict__ tflag = L.tile_flag + (size_t)b * L.NT;
         // ---- stage the 18x18 id halo in LDS
         for (int i = tid; i < HALO * HALO; i += 256) {
             const int gx = ox - 1 + i % HALO, gy = oy - 1 + i / HALO;
             int v = -1;
             if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
                 const int nt = (gy / DDX_TILE) * L.ntx + gx / DDX_TILE;
-                v = tcount[nt] > 0 ? (int)vis[(size_t)gy * W + gx] : 0;
+                v = 0;
+                if (tflag[nt] != 0) {
+                    const unsigned long long key = zb[(size_t)gy * W + gx];
+                    v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
+                }
             }
             ids[i] = v;
         }
@@ -434,6 +465,21 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
     __shared__ float red[4][NPART];
     __shared__ float sums[NPART];
     const int base = E.L.b_active[b * 2 + 0], n = E.L.b_active[b * 2 + 1];
+    // re-arm what this iteration dirtied, so that the next one needs no memset: the depth/visibility
+    // buffer of this hypothesis' active tiles, its tile flags and its bin counters
+    {
+        const int H = d.H, W = d.W;
+        const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
+        for (int s = 0; s < n; ++s) {
+            const int tile = E.L.active[base + s] - b * E.L.NT;
+            const int px = (tile % E.L.ntx) * DDX_TILE + lx, py = (tile / E.L.ntx) * DDX_TILE + ly;
+            if (px < W && py < H) E.L.zbuf[((size_t)b * H + py) * W + px] = ~0ull;
+        }
+        for (int i = tid; i < E.L.NT; i += 256) {
+            E.L.tile_count[(size_t)b * E.L.NT + i] = 0;
+            E.L.tile_flag[(size_t)b * E.L.NT + i] = 0;
+        }
+    }
     // fixed-order reduction of this hypothesis' tile partials: thread (slot % 8, j) layout
     {
         const int j = tid % 32, lanegrp = tid / 32;  // 8 groups of 32 threads; thread j < 19 sums value j
@@ -527,36 +573,36 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
             E.b.params[(size_t)i * B + b] -= lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
         }
     }
-    if (b == 0) {
+    // the last workgroup to arrive closes the iteration: every other one has already read `it`
+    __threadfence();
+    if (atomicAdd(&E.st->ticket, 1) == B - 1) {
         E.st->overflow |= E.L.counters[0];
         E.st->last_pairs = E.L.counters[1];
         E.st->last_active = E.L.counters[2];
+        E.L.counters[0] = 0; E.L.counters[1] = 0; E.L.counters[2] = 0; E.L.counters[3] = 0;
+        E.st->ticket = 0;
+        E.st->it = it + 1;
     }
 }
 
-__global__ void advance_kernel(EngineState* st) { st->it += 1; }
 __global__ void set_it_kernel(EngineState* st, int it) { st->it = it; }
 
 // ---------------------------------------------------------------------------------------------
-enum { K_POSE, K_XFM, K_BIN_COUNT, K_SCAN, K_BIN_FILL, K_RASTER, K_SHADE, K_UPDATE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"pose_kernel",     "xfm_fwd_kernel", "bin_kernel<count>", "scan_kernel",
-                                                  "bin_kernel<fill>", "raster_kernel",  "shade_kernel",      "update_kernel"};
+enum { K_XFM, K_BIN_COUNT, K_SCAN, K_BIN_FILL, K_RASTER, K_SHADE, K_UPDATE, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"pose_xfm_kernel",   "scatter_kernel", "scan_kernel",  "bin_fill_kernel",
+                                                  "raster_big_kernel", "shade_kernel",   "update_kernel"};
 
 static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
 {
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
-    if (ev) DDX_HIP(hipEventRecord(ev[0], s));
-    pose_kernel<<<ddx_cdiv(d.B, 64), 64, 0, s>>>(E);
-    if (ev) DDX_HIP(hipEventRecord(ev[1], s));
-    // shared mesh (batch stride 0), per-hypothesis `final` = second half of each 32-float mats row
-    if (int err = ddx_xfm_fwd_strided(E.b.pos, E.mats + 16, 32, d.B, d.V, E.clip, s)) return err;
-    if (int err = raster_run(E.clip, E.b.tri, d.B, d.V, d.T, d.H, d.W, E.L, s, ev ? ev + K_BIN_COUNT : nullptr)) return err;
+    if (ev) DDX_HIP(hipEventRecord(ev[K_XFM], s));
+    pose_xfm_kernel<<<dim3(ddx_cdiv(d.V, 256), d.B), 256, 0, s>>>(E);
+    if (int err = raster_run(E.clip, E.b.tri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_BIN_COUNT : nullptr)) return err;
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
     shade_kernel<<<RASTER_GRID, 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
     update_kernel<<<d.B, 256, 0, s>>>(E);
-    advance_kernel<<<1, 1, 0, s>>>(E.st);
     if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
     DDX_LAUNCH_CHECK();
     return 0;
@@ -566,7 +612,7 @@ static int check_desc(const ddx_engine_desc* d)
 {
     DDX_REQUIRE(d, DDX_E_NULL, "engine: NULL desc");
     DDX_REQUIRE(d->B >= 1 && d->B <= 65535 && d->B_global >= d->B && d->V >= 3 && d->T >= 1 && d->H >= 1 && d->W >= 1 &&
-                    d->H <= 16384 && d->W <= 16384 && d->max_iters >= 1,
+                    d->H <= 4096 && d->W <= 4096 && d->max_iters >= 1,
                 DDX_E_SHAPE, "engine: bad shape B=%d Bg=%d V=%d T=%d H=%d W=%d iters=%d", d->B, d->B_global, d->V, d->T, d->H, d->W, d->max_iters);
     DDX_REQUIRE((d->Th > 0) == (d->Tw > 0), DDX_E_SHAPE, "engine: Th/Tw must both be zero or positive");
     return 0;
@@ -613,6 +659,8 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     EngineDev& E = e->dev;
     DDX_HIP(hipMemsetAsync(E.st, 0, sizeof(EngineState), s));
     DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)14 * E.d.B * sizeof(float), s));
+    DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // kept zero by update_kernel afterwards
+    DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
     e->setup_done = true;

@@ -4,6 +4,8 @@
 // depth key) is exact integer arithmetic or explicitly ordered fp32 (this library is built with
 // -ffp-contract=off), so visibility is reproducible bit for bit.
 #pragma once
+#include <limits.h>
+
 #include "ddx_common.h"
 
 #define DDX_SUBPIX 256  // 8 sub-pixel bits
@@ -38,6 +40,24 @@ __device__ __forceinline__ void snap_triangle(const float4& p0, const float4& p1
     s.X[0] = snap_coord(p0.x * i0, W); s.Y[0] = snap_coord(p0.y * i0, H);
     s.X[1] = snap_coord(p1.x * i1, W); s.Y[1] = snap_coord(p1.y * i1, H);
     s.X[2] = snap_coord(p2.x * i2, W); s.Y[2] = snap_coord(p2.y * i2, H);
+    s.area = (long long)(s.X[1] - s.X[0]) * (long long)(s.Y[2] - s.Y[0]) -
+             (long long)(s.X[2] - s.X[0]) * (long long)(s.Y[1] - s.Y[0]);
+    s.ok = s.area != 0;
+}
+
+// per-vertex snap (x = INT_MIN marks a vertex with w <= 0) and triangle setup from snapped vertices
+__device__ __forceinline__ int2 snap_vertex(const float4& p, int H, int W)
+{
+    if (!(p.w > 0.f)) return make_int2(INT_MIN, 0);
+    const float iw = __fdiv_rn(1.0f, p.w);
+    return make_int2(snap_coord(p.x * iw, W), snap_coord(p.y * iw, H));
+}
+
+__device__ __forceinline__ void snap_from_vertices(const int2& a, const int2& b, const int2& c, SnapTri& s)
+{
+    s.ok = false;
+    if (a.x == INT_MIN || b.x == INT_MIN || c.x == INT_MIN) return;
+    s.X[0] = a.x; s.Y[0] = a.y; s.X[1] = b.x; s.Y[1] = b.y; s.X[2] = c.x; s.Y[2] = c.y;
     s.area = (long long)(s.X[1] - s.X[0]) * (long long)(s.Y[2] - s.Y[0]) -
              (long long)(s.X[2] - s.X[0]) * (long long)(s.Y[1] - s.Y[0]);
     s.ok = s.area != 0;

@@ -49,10 +49,12 @@ class RasterizeContext:
         self._key = None
         self._pairs_hint = 0
 
-    def scratch(self, B, T, H, W, device):
-        key = (B, T, H, W, self._pairs_hint, str(device))
+    def scratch(self, B, V, T, H, W, device):
+        key = (B, V, T, H, W, self._pairs_hint, str(device))
         if self._key != key:
-            nbytes = self.lib.ddx_rasterize_scratch_bytes(B, T, H, W, self._pairs_hint)
+            nbytes = self.lib.ddx_rasterize_scratch_bytes(B, V, T, H, W, self._pairs_hint)
+            if nbytes == 0:
+                raise RuntimeError(f"rasterize: unsupported shape B={B} V={V} T={T} H={H} W={W} (H,W <= 4096)")
             self._scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
             self._key = key
         off = (-self._scratch.data_ptr()) % 256
@@ -75,7 +77,7 @@ class _rasterize_func(torch.autograd.Function):
         rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device)
         status = torch.empty(4, dtype=torch.int32, device=pos.device)
         for _ in range(3):
-            scratch, nbytes = glctx.scratch(B, T, H, W, pos.device)
+            scratch, nbytes = glctx.scratch(B, V, T, H, W, pos.device)
             _lib.check(lib.ddx_rasterize_fwd(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes,
                                              _lib.ptr(rast), _lib.ptr(status), _lib.stream_ptr()), "ddx_rasterize_fwd")
             st = status.cpu()

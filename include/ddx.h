@@ -69,10 +69,10 @@ int ddx_xfm_bwd_full(const float* points, long long points_bstride, const float*
  *   pos   [B,V,4] clip space;  tri [T,3];  rast [B,H,W,4] = (u, v, z/w, tri_id+1), 0 on background
  *   status: device int32[4] written by the call: [0]=1 if the bin buffer overflowed (result
  *           incomplete -> enlarge scratch via `pairs_hint`), [1]=number of (tile,triangle) pairs.
- * scratch_bytes(B,T,H,W,pairs_hint): pairs_hint = expected (tile,triangle) pairs in total, 0 => default
+ * H, W <= 4096.  scratch_bytes(B,V,T,H,W,pairs_hint): pairs_hint = expected (tile,triangle) pairs in total, 0 => default
  * sizing of 4*B*T + 64*B*tiles.
  * ------------------------------------------------------------------------------------------- */
-size_t ddx_rasterize_scratch_bytes(int B, int T, int H, int W, long long pairs_hint);
+size_t ddx_rasterize_scratch_bytes(int B, int V, int T, int H, int W, long long pairs_hint);
 int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
                       void* scratch, size_t scratch_bytes, float* rast, int32_t* status, void* stream);
 /* drast [B,H,W,4] (channels 0,1 used) -> dpos [B,V,4], fully written (zeroed then accumulated). */
