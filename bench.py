@@ -149,7 +149,7 @@ def main():
         eng2.run(min(args.warmup, n_it - 1))
         torch.cuda.synchronize()
         kms = eng2.profile(it0=min(args.warmup, n_it - 1), iters=max(1, min(20, n_it - args.warmup)))
-        raster_ms = sum(kms[k] for k in ("scatter_kernel", "scan_kernel", "bin_fill_kernel", "raster_big_kernel"))
+        raster_ms = sum(kms[k] for k in ("scatter_kernel", "compact_big_kernel"))
         groups = {"pose_xfm_kernel": kms["pose_xfm_kernel"], "raster_stage": raster_ms,
                   "shade_kernel": kms["shade_kernel"], "update_kernel": kms["update_kernel"]}
         dom = max(("shade_kernel", "scatter_kernel"), key=lambda k: kms[k])

@@ -43,8 +43,8 @@ _SIGNATURES = {
     "ddx_xfm_bwd_points": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_xfm_bwd_mtx": (_I, [_P, _LL, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_xfm_bwd_full": (_I, [_P, _LL, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
-    "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I, _LL]),
-    "ddx_rasterize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _P]),
+    "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "ddx_rasterize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
     "ddx_rasterize_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_interpolate_fwd": (_I, [_P, _LL, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "ddx_interpolate_bwd": (_I, [_P, _LL, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -53,7 +53,7 @@ _SIGNATURES = {
     "ddx_topology_build": (_I, [_P, _I, _P]),
     "ddx_antialias_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ddx_antialias_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "ddx_engine_scratch_bytes": (_SZ, [ctypes.POINTER(EngineDesc), _LL]),
+    "ddx_engine_scratch_bytes": (_SZ, [ctypes.POINTER(EngineDesc)]),
     "ddx_engine_create": (_I, [ctypes.POINTER(EngineDesc), ctypes.POINTER(EngineBuffers), ctypes.POINTER(_P)]),
     "ddx_engine_run": (_I, [_P, _I, _I, _I, _P]),
     "ddx_engine_status_ptr": (_P, [_P]),

@@ -41,7 +41,8 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int it;
     int n_seg;       // entries in the compact seg list
     int ticket;      // update_kernel arrival counter (the last workgroup closes the iteration)
-    int pad[2];
+    int active_acc;  // active tiles summed over the hypotheses of the running iteration
+    int pad[1];
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
 };
@@ -52,7 +53,7 @@ struct EngineDev {
     RasterScratch L;
     float* clip;      // [B,V,4]
     float* mats;      // [B,2,16]: mtx | final
-    float* partials;  // [B*NT, NPART]
+    float* partials;  // [B*NT*4, NPART]: one per 8x8 quadrant, indexed by (b*NT + tile)*4 + quadrant
     float* adam;      // [2,7,B]
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
     EngineState* st;
@@ -66,7 +67,7 @@ struct ddx_engine {
 };
 
 // ---------------------------------------------------------------------------------------------
-static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base, long long pairs_hint)
+static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
 {
     size_t off = 0;
     auto carve = [&](size_t bytes) {
@@ -81,9 +82,9 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base, 
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
-    const size_t o_part = carve((size_t)d.B * ntx * nty * NPART * sizeof(float));
+    const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * NPART * sizeof(float));  // one partial per 8x8 quadrant
     const size_t o_rast = carve(0);
-    const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W, pairs_hint);
+    const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W);
     off += rast_bytes;
     E.st = (EngineState*)(p + o_state);
     E.mats = (float*)(p + o_mats);
@@ -233,226 +234,284 @@ __device__ __forceinline__ void acc_vertex(PixAcc& A, const float* __restrict__ 
     A.dF[8] = __fmaf_rn(gw, x, A.dF[8]); A.dF[9] = __fmaf_rn(gw, y, A.dF[9]); A.dF[10] = __fmaf_rn(gw, z, A.dF[10]); A.dF[11] += gw;
 }
 
-#define HALO (DDX_TILE + 2)
+#define QUAD 8             // one wave shades one 8x8 quadrant of a 16x16 tile
+#define QH (QUAD + 2)      // quadrant + 1-pixel halo
+#define PAIR_CAP 160       // >= 2*64 + 8 + 8 candidate antialias pairs per quadrant
+#define WAVES_PER_TILE 4
 
-__global__ __launch_bounds__(256) void shade_kernel(EngineDev E)
+__device__ __forceinline__ void wave_lds_sync()
 {
-    __shared__ int ids[HALO * HALO];  // vis id (0 = background) ; -1 = outside the image
-    __shared__ float red[4][NPART];
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// decode candidate pair `desc` = pixel lane | kind << 6 of the quadrant at (qx,qy):
+// kind 0: (p, right)  1: (p, up)  2: (left, p)  3: (down, p).  h0/h1 = halo indices of pixel0 / pixel1.
+__device__ __forceinline__ void pair_decode(int desc, int& h0, int& h1, int& d)
+{
+    const int pl = desc & 63, kind = desc >> 6;
+    const int hx = (pl % QUAD) + 1, hy = (pl / QUAD) + 1;
+    d = kind & 1;
+    const int x0 = kind == 2 ? hx - 1 : hx, y0 = kind == 3 ? hy - 1 : hy;
+    h0 = y0 * QH + x0;
+    h1 = d ? h0 + QH : h0 + 1;
+}
+
+__global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
+{
+    __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
+    __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
+    __shared__ float s_gm[WAVES_PER_TILE][64];          // d loss / d mask of each pixel
+    __shared__ unsigned short s_pairs[WAVES_PER_TILE][PAIR_CAP];
     const ddx_engine_desc& d = E.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W, V = d.V;
     const RasterScratch& L = E.L;
-    const int n_active = L.counters[2];
+    extern __shared__ __attribute__((aligned(16))) int s_prefix[];  // [B+1] exclusive scan of the per-hypothesis counts
+    __shared__ int s_wsum[4];
     const float* __restrict__ pos = E.b.pos;
     const int* __restrict__ tri = E.b.tri;
-    // contiguous eighth of the (hypothesis-major) active list per XCD: blocks i, i+8, ... share an L2
-    const int xcd = blockIdx.x & 7, jblk = blockIdx.x >> 3, nblk = gridDim.x >> 3;
-    const int per = (n_active + 7) / 8;
-    for (int w = jblk; w < per; w += nblk) {
-        const int work = xcd * per + w;
-        if (work >= n_active) break;
-        const int flat = L.active[work];
-        const int b = flat / L.NT, tile = flat - b * L.NT;
-        const int tcx = tile % L.ntx, tcy = tile / L.ntx;
-        const int ox = tcx * DDX_TILE, oy = tcy * DDX_TILE;
+    int* ids = s_ids[wave];
+    const int n_active = work_prefix(L.b_count, d.B, s_prefix, s_wsum);
+    for (int work = blockIdx.x; work < n_active; work += gridDim.x) {
+        const int b = work_lookup(s_prefix, d.B, work);
+        const int tile = L.active[(size_t)b * L.NT + (work - s_prefix[b])];
+        const int flat = b * L.NT + tile;
+        const int qx = (tile % L.ntx) * DDX_TILE + (wave & 1) * QUAD, qy = (tile / L.ntx) * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
         const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
-        const int* __restrict__ tflag = L.tile_flag + (size_t)b * L.NT;
-        // ---- stage the 18x18 id halo in LDS
-        for (int i = tid; i < HALO * HALO; i += 256) {
-            const int gx = ox - 1 + i % HALO, gy = oy - 1 + i / HALO;
+        float* part = E.partials + ((size_t)flat * WAVES_PER_TILE + wave) * NPART;
+        // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
+        bool anycov = false;
+#pragma unroll
+        for (int e = lane; e < QH * QH; e += 64) {
+            const int gx = qx - 1 + e % QH, gy = qy - 1 + e / QH;
             int v = -1;
             if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
-                const int nt = (gy / DDX_TILE) * L.ntx + gx / DDX_TILE;
-                v = 0;
-                if (tflag[nt] != 0) {
-                    const unsigned long long key = zb[(size_t)gy * W + gx];
-                    v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
-                }
+                const unsigned long long key = zb[(size_t)gy * W + gx];
+                v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
             }
-            ids[i] = v;
+            ids[e] = v;
+            anycov |= v > 0;
         }
-        __syncthreads();
-        const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
-        const int px = ox + lx, py = oy + ly;
-        const int id = ids[(ly + 1) * HALO + lx + 1];
+        s_m[wave][lane] = 0.f;
+        if (__ballot(anycov) == 0ull) {  // nothing drawn in or next to this quadrant: only background terms
+            if (lane < NPART) part[lane] = 0.f;
+            continue;
+        }
+        wave_lds_sync();
+        const int lx = lane % QUAD, ly = lane / QUAD;
+        const int px = qx + lx, py = qy + ly;
+        const int hidx = (ly + 1) * QH + lx + 1;
+        const int id = ids[hidx];
         PixAcc A;
 #pragma unroll
         for (int i = 0; i < 12; ++i) A.dF[i] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) A.dM2[i] = 0.f;
         A.L[0] = A.L[1] = A.L[2] = 0.f;
-        bool any = false;
-        if (id >= 0) {  // inside the image
-            const size_t pix = (size_t)py * W + px;
-            const float s0 = E.b.gt_seg[pix * 3 + 0], s1 = E.b.gt_seg[pix * 3 + 1], s2 = E.b.gt_seg[pix * 3 + 2];
-            const float lrb = E.b.lr_mult[b];
-            const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
-            if (id > 0) {
-                any = true;
-                const int t = id - 1;
-                const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
-                const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
-                Bary bc;
-                pixel_bary(p0, p1, p2, px, py, H, W, bc);
-                const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
-                float gu = 0.f, gv = 0.f;
-                if (d.use_rgb) {
-                    const float k = d.w_rgb * lrb * inv_b / (3.0f * (float)H * (float)W);
-                    const float g0 = E.b.gt_rgb[pix * 3 + 0], g1 = E.b.gt_rgb[pix * 3 + 1], g2 = E.b.gt_rgb[pix * 3 + 2];
-                    const float gt[3] = {g0, g1, g2}, sg[3] = {s0, s1, s2};
-                    if (d.Th > 0) {
-                        const float* uv = E.b.uv;
-                        const float a0x = uv[(size_t)v0 * 2], a0y = uv[(size_t)v0 * 2 + 1];
-                        const float a1x = uv[(size_t)v1 * 2], a1y = uv[(size_t)v1 * 2 + 1];
-                        const float a2x = uv[(size_t)v2 * 2], a2y = uv[(size_t)v2 * 2 + 1];
-                        const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x));
-                        const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
-                        TexelSetup ts;
-                        tex_setup(tu, tv, d.Th, d.Tw, ts);
-                        const float* TX = E.b.tex;
-                        const float *t00 = TX + ((size_t)ts.y0 * d.Tw + ts.x0) * 3, *t10 = TX + ((size_t)ts.y0 * d.Tw + ts.x1) * 3,
-                                    *t01 = TX + ((size_t)ts.y1 * d.Tw + ts.x0) * 3, *t11 = TX + ((size_t)ts.y1 * d.Tw + ts.x1) * 3;
-                        float gU = 0.f, gV = 0.f;
+        const float lrb = E.b.lr_mult[b];
+        const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        const size_t pix = (size_t)py * W + px;
+        if (id >= 0) { s0 = E.b.gt_seg[pix * 3 + 0]; s1 = E.b.gt_seg[pix * 3 + 1]; s2 = E.b.gt_seg[pix * 3 + 2]; }
+        if (id > 0) {
+            const int t = id - 1;
+            const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
+            const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
+            Bary bc;
+            pixel_bary(p0, p1, p2, px, py, H, W, bc);
+            const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
+            float gu = 0.f, gv = 0.f;
+            if (d.use_rgb) {
+                const float k = d.w_rgb * lrb * inv_b / (3.0f * (float)H * (float)W);
+                const float g0 = E.b.gt_rgb[pix * 3 + 0], g1 = E.b.gt_rgb[pix * 3 + 1], g2 = E.b.gt_rgb[pix * 3 + 2];
+                const float gt[3] = {g0, g1, g2}, sg[3] = {s0, s1, s2};
+                if (d.Th > 0) {
+                    const float* uv = E.b.uv;
+                    const float a0x = uv[(size_t)v0 * 2], a0y = uv[(size_t)v0 * 2 + 1];
+                    const float a1x = uv[(size_t)v1 * 2], a1y = uv[(size_t)v1 * 2 + 1];
+                    const float a2x = uv[(size_t)v2 * 2], a2y = uv[(size_t)v2 * 2 + 1];
+                    const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x));
+                    const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
+                    TexelSetup ts;
+                    tex_setup(tu, tv, d.Th, d.Tw, ts);
+                    const float* TX = E.b.tex;
+                    const float *t00 = TX + ((size_t)ts.y0 * d.Tw + ts.x0) * 3, *t10 = TX + ((size_t)ts.y0 * d.Tw + ts.x1) * 3,
+                                *t01 = TX + ((size_t)ts.y1 * d.Tw + ts.x0) * 3, *t11 = TX + ((size_t)ts.y1 * d.Tw + ts.x1) * 3;
+                    float gU = 0.f, gV = 0.f;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
-                            const float a = __fmaf_rn(ts.fx, c10 - c00, c00);
-                            const float bq = __fmaf_rn(ts.fx, c11 - c01, c01);
-                            const float col = __fmaf_rn(ts.fy, bq - a, a);
-                            const float diff = (col - gt[c]) * sg[c];
-                            A.L[0] += fabsf(diff) - fabsf(gt[c] * sg[c]);
-                            const float g = k * sgnf(diff) * sg[c];
-                            gU = __fmaf_rn(g, __fmaf_rn(ts.fy, (c11 - c01) - (c10 - c00), c10 - c00), gU);
-                            gV = __fmaf_rn(g, __fmaf_rn(ts.fx, (c11 - c10) - (c01 - c00), c01 - c00), gV);
-                        }
-                        gU *= (float)d.Tw;
-                        gV *= (float)d.Th;
-                        gu += gU * (a0x - a2x) + gV * (a0y - a2y);
-                        gv += gU * (a1x - a2x) + gV * (a1y - a2y);
-                    } else {
-                        const float* vc = E.b.vtx_color;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float c0 = vc[(size_t)v0 * 3 + c], c1 = vc[(size_t)v1 * 3 + c], c2 = vc[(size_t)v2 * 3 + c];
-                            const float col = __fmaf_rn(w2, c2, __fmaf_rn(v, c1, u * c0));
-                            const float diff = (col - gt[c]) * sg[c];
-                            A.L[0] += fabsf(diff) - fabsf(gt[c] * sg[c]);
-                            const float g = k * sgnf(diff) * sg[c];
-                            gu = __fmaf_rn(g, c0 - c2, gu);
-                            gv = __fmaf_rn(g, c1 - c2, gv);
-                        }
+                    for (int c = 0; c < 3; ++c) {
+                        const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
+                        const float a = __fmaf_rn(ts.fx, c10 - c00, c00);
+                        const float bq = __fmaf_rn(ts.fx, c11 - c01, c01);
+                        const float col = __fmaf_rn(ts.fy, bq - a, a);
+                        const float diff = (col - gt[c]) * sg[c];
+                        A.L[0] += fabsf(diff) - fabsf(gt[c] * sg[c]);
+                        const float g = k * sgnf(diff) * sg[c];
+                        gU = __fmaf_rn(g, __fmaf_rn(ts.fy, (c11 - c01) - (c10 - c00), c10 - c00), gU);
+                        gV = __fmaf_rn(g, __fmaf_rn(ts.fx, (c11 - c10) - (c01 - c00), c01 - c00), gV);
                     }
-                }
-                if (d.use_depth) {
-                    const float k = d.w_depth * lrb * inv_b / ((float)H * (float)W);
-                    const float* M = E.mats + (size_t)b * 32;
-                    const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
-                    const float x0 = pos[(size_t)v0 * 3], y0 = pos[(size_t)v0 * 3 + 1], z0 = pos[(size_t)v0 * 3 + 2];
-                    const float x1 = pos[(size_t)v1 * 3], y1 = pos[(size_t)v1 * 3 + 1], z1 = pos[(size_t)v1 * 3 + 2];
-                    const float x2 = pos[(size_t)v2 * 3], y2 = pos[(size_t)v2 * 3 + 1], z2 = pos[(size_t)v2 * 3 + 2];
-                    const float gbx = __fmaf_rn(w2, x2, __fmaf_rn(v, x1, u * x0));
-                    const float gby = __fmaf_rn(w2, y2, __fmaf_rn(v, y1, u * y0));
-                    const float gbz = __fmaf_rn(w2, z2, __fmaf_rn(v, z1, u * z0));
-                    float zc = __fmaf_rn(m20, gbx, 0.f);
-                    zc = __fmaf_rn(m21, gby, zc);
-                    zc = __fmaf_rn(m22, gbz, zc);
-                    zc = __fmaf_rn(m23, 1.0f, zc);
-                    const float depth = -zc, dbg = -m23;
-                    const float gtd = E.b.gt_depth[pix];
-                    const float diff = (depth - gtd) * s0, dbase = (dbg - gtd) * s0;
-                    A.L[1] += fabsf(diff) - fabsf(dbase);
-                    const float g = k * sgnf(diff) * s0;  // d loss / d depth
-                    A.dM2[0] += -g * gbx; A.dM2[1] += -g * gby; A.dM2[2] += -g * gbz;
-                    A.dM2[3] += -g + k * sgnf(dbase) * s0;  // actual term and the subtracted background term
-                    gu += -g * (m20 * (x0 - x2) + m21 * (y0 - y2) + m22 * (z0 - z2));
-                    gv += -g * (m20 * (x1 - x2) + m21 * (y1 - y2) + m22 * (z1 - z2));
-                }
-                if (gu != 0.f || gv != 0.f) {
-                    float gx[3], gy[3], gw[3];
-                    bary_backward(bc, gu, gv, gx, gy, gw);
-                    acc_vertex(A, pos, v0, gx[0], gy[0], gw[0]);
-                    acc_vertex(A, pos, v1, gx[1], gy[1], gw[1]);
-                    acc_vertex(A, pos, v2, gx[2], gy[2], gw[2]);
+                    gU *= (float)d.Tw;
+                    gV *= (float)d.Th;
+                    gu += gU * (a0x - a2x) + gV * (a0y - a2y);
+                    gv += gU * (a1x - a2x) + gV * (a1y - a2y);
+                } else {
+                    const float* vc = E.b.vtx_color;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float c0 = vc[(size_t)v0 * 3 + c], c1 = vc[(size_t)v1 * 3 + c], c2 = vc[(size_t)v2 * 3 + c];
+                        const float col = __fmaf_rn(w2, c2, __fmaf_rn(v, c1, u * c0));
+                        const float diff = (col - gt[c]) * sg[c];
+                        A.L[0] += fabsf(diff) - fabsf(gt[c] * sg[c]);
+                        const float g = k * sgnf(diff) * sg[c];
+                        gu = __fmaf_rn(g, c0 - c2, gu);
+                        gv = __fmaf_rn(g, c1 - c2, gv);
+                    }
                 }
             }
-            if (d.use_mask) {
-                // gather form of antialias: which of the 4 pairs this pixel belongs to deposit into it?
-                const float k = d.w_mask * lrb * inv_b / (3.0f * (float)H * (float)W);
-                const int cov = id > 0;
-                float m = (float)cov;
-                unsigned valid = 0;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    // n: 0 right, 1 left, 2 up (row+1), 3 down
-                    const int dx = n == 0 ? 1 : (n == 1 ? -1 : 0), dy = n == 2 ? 1 : (n == 3 ? -1 : 0);
-                    const int idq = ids[(ly + 1 + dy) * HALO + lx + 1 + dx];
-                    if (idq < 0 || (idq > 0) == (id > 0)) continue;
-                    const bool me0 = (n == 0 || n == 2);  // am I pixel0 of the pair?
-                    const int dd = n >= 2;
-                    const int px0 = me0 ? px : px + dx, py0 = me0 ? py : py + dy;
-                    const int t0 = (me0 ? id : idq) - 1, t1 = (me0 ? idq : id) - 1;
-                    AAPair pr;
-                    aa_eval_pair(P, tri, E.b.opp, H, W, px0, py0, dd, t0, t1, 0.f, 0.f, pr);
-                    if (!pr.valid) continue;
-                    const bool target0 = pr.alpha > 0.f;
-                    if (target0 != me0) continue;
-                    const float c1mc0 = (float)((t1 >= 0) - (t0 >= 0));
-                    m = __fmaf_rn(pr.alpha, c1mc0, m);
-                    valid |= 1u << n;
-                }
-                const float e0 = m - s0, e1 = m - s1, e2 = m - s2;
-                A.L[2] += (fabsf(e0) - fabsf(s0)) + (fabsf(e1) - fabsf(s1)) + (fabsf(e2) - fabsf(s2));
-                if (valid) {
-                    any = true;
-                    const float gm = k * (sgnf(e0) + sgnf(e1) + sgnf(e2));
-                    if (gm != 0.f) {
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            if (!(valid & (1u << n))) continue;
-                            const int dx = n == 0 ? 1 : (n == 1 ? -1 : 0), dy = n == 2 ? 1 : (n == 3 ? -1 : 0);
-                            const int idq = ids[(ly + 1 + dy) * HALO + lx + 1 + dx];
-                            const bool me0 = (n == 0 || n == 2);
-                            const int dd = n >= 2;
-                            const int px0 = me0 ? px : px + dx, py0 = me0 ? py : py + dy;
-                            const int t0 = (me0 ? id : idq) - 1, t1 = (me0 ? idq : id) - 1;
-                            AAPair pr;
-                            aa_eval_pair(P, tri, E.b.opp, H, W, px0, py0, dd, t0, t1, 0.f, 0.f, pr);
-                            if (!pr.valid || pr.clamped) continue;
-                            const float c1mc0 = (float)((t1 >= 0) - (t0 >= 0));
-                            float g[2][3];
-                            aa_pair_backward(pr, P, H, W, gm * c1mc0, g);
-                            acc_vertex(A, pos, pr.va, g[0][0], g[0][1], g[0][2]);
-                            acc_vertex(A, pos, pr.vb, g[1][0], g[1][1], g[1][2]);
-                        }
-                    }
-                } else if (m != 0.f || s0 != 0.f || s1 != 0.f || s2 != 0.f) {
-                    any = true;
-                }
+            if (d.use_depth) {
+                const float k = d.w_depth * lrb * inv_b / ((float)H * (float)W);
+                const float* M = E.mats + (size_t)b * 32;
+                const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
+                const float x0 = pos[(size_t)v0 * 3], y0 = pos[(size_t)v0 * 3 + 1], z0 = pos[(size_t)v0 * 3 + 2];
+                const float x1 = pos[(size_t)v1 * 3], y1 = pos[(size_t)v1 * 3 + 1], z1 = pos[(size_t)v1 * 3 + 2];
+                const float x2 = pos[(size_t)v2 * 3], y2 = pos[(size_t)v2 * 3 + 1], z2 = pos[(size_t)v2 * 3 + 2];
+                const float gbx = __fmaf_rn(w2, x2, __fmaf_rn(v, x1, u * x0));
+                const float gby = __fmaf_rn(w2, y2, __fmaf_rn(v, y1, u * y0));
+                const float gbz = __fmaf_rn(w2, z2, __fmaf_rn(v, z1, u * z0));
+                float zc = __fmaf_rn(m20, gbx, 0.f);
+                zc = __fmaf_rn(m21, gby, zc);
+                zc = __fmaf_rn(m22, gbz, zc);
+                zc = __fmaf_rn(m23, 1.0f, zc);
+                const float depth = -zc, dbg = -m23;
+                const float gtd = E.b.gt_depth[pix];
+                const float diff = (depth - gtd) * s0, dbase = (dbg - gtd) * s0;
+                A.L[1] += fabsf(diff) - fabsf(dbase);
+                const float g = k * sgnf(diff) * s0;  // d loss / d depth
+                A.dM2[0] += -g * gbx; A.dM2[1] += -g * gby; A.dM2[2] += -g * gbz;
+                A.dM2[3] += -g + k * sgnf(dbase) * s0;  // actual term and the subtracted background term
+                gu += -g * (m20 * (x0 - x2) + m21 * (y0 - y2) + m22 * (z0 - z2));
+                gv += -g * (m20 * (x1 - x2) + m21 * (y1 - y2) + m22 * (z1 - z2));
+            }
+            if (gu != 0.f || gv != 0.f) {
+                float gx[3], gy[3], gw[3];
+                bary_backward(bc, gu, gv, gx, gy, gw);
+                acc_vertex(A, pos, v0, gx[0], gy[0], gw[0]);
+                acc_vertex(A, pos, v1, gx[1], gy[1], gw[1]);
+                acc_vertex(A, pos, v2, gx[2], gy[2], gw[2]);
             }
         }
-        // ---- workgroup reduction -> one partial per tile (fixed order: bit-reproducible)
-        const bool wave_any = __ballot(any) != 0ull;
+        if (d.use_mask) {
+            // ---- antialias, pair-parallel: compact the candidate pairs (exactly one side covered, at least
+            // one side in this quadrant) with ballots, then ONE lane per pair instead of 4 divergent
+            // neighbour probes per pixel.  A pair deposits alpha*(c1-c0) into its target pixel (LDS add);
+            // pairs whose target lies in another quadrant are evaluated there as well and dropped here.
+            const float k = d.w_mask * lrb * inv_b / (3.0f * (float)H * (float)W);
+            const bool inimg = id >= 0;
+            const int idr = ids[hidx + 1], idu = ids[hidx + QH], idl = ids[hidx - 1], idd = ids[hidx - QH];
+            const bool c0 = inimg && idr >= 0 && ((idr > 0) != (id > 0));
+            const bool c1 = inimg && idu >= 0 && ((idu > 0) != (id > 0));
+            const bool c2 = inimg && lx == 0 && idl >= 0 && ((idl > 0) != (id > 0));
+            const bool c3 = inimg && ly == 0 && idd >= 0 && ((idd > 0) != (id > 0));
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3);
+            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            const int np = n0 + n1 + n2 + n3;
+            if (c0) s_pairs[wave][__popcll(m0 & lt)] = (unsigned short)(lane | (0 << 6));
+            if (c1) s_pairs[wave][n0 + __popcll(m1 & lt)] = (unsigned short)(lane | (1 << 6));
+            if (c2) s_pairs[wave][n0 + n1 + __popcll(m2 & lt)] = (unsigned short)(lane | (2 << 6));
+            if (c3) s_pairs[wave][n0 + n1 + n2 + __popcll(m3 & lt)] = (unsigned short)(lane | (3 << 6));
+            wave_lds_sync();
+            // forward: each lane owns pair `lane` (+64, ... in the rare quadrant with more than 64 pairs)
+            AAPair pr0;
+            pr0.valid = false;
+            int tl0 = -1;
+            float cd0 = 0.f;
+            for (int j0 = 0; j0 < np; j0 += 64) {
+                const int j = j0 + lane;
+                AAPair pr;
+                pr.valid = false;
+                int tl = -1;
+                float cd = 0.f;
+                if (j < np) {
+                    int h0, h1, dd;
+                    pair_decode(s_pairs[wave][j], h0, h1, dd);
+                    const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
+                    aa_eval_pair(P, tri, E.b.opp, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, 0.f, 0.f, pr);
+                    if (pr.valid) {
+                        const int ht = pr.alpha > 0.f ? h0 : h1;
+                        const int tx = ht % QH - 1, ty = ht / QH - 1;
+                        cd = (float)((t1 >= 0) - (t0 >= 0));
+                        if (tx >= 0 && tx < QUAD && ty >= 0 && ty < QUAD) {
+                            tl = ty * QUAD + tx;
+                            atomicAdd(&s_m[wave][tl], pr.alpha * cd);
+                        }
+                    }
+                }
+                if (j0 == 0) { pr0 = pr; tl0 = tl; cd0 = cd; }
+            }
+            wave_lds_sync();
+            // pixel: mask value, loss term, d loss / d mask
+            float gm = 0.f;
+            if (inimg) {
+                const float m = (float)(id > 0) + s_m[wave][lane];
+                const float e0 = m - s0, e1 = m - s1, e2 = m - s2;
+                A.L[2] += (fabsf(e0) - fabsf(s0)) + (fabsf(e1) - fabsf(s1)) + (fabsf(e2) - fabsf(s2));
+                gm = k * (sgnf(e0) + sgnf(e1) + sgnf(e2));
+            }
+            s_gm[wave][lane] = gm;
+            s_m[wave][lane] = 0.f;  // re-arm for the next tile
+            wave_lds_sync();
+            // backward: pairs whose target pixel is ours send d alpha to their two edge vertices
+            for (int j0 = 0; j0 < np; j0 += 64) {
+                AAPair pr = pr0;
+                int tl = tl0;
+                float cd = cd0;
+                if (j0 > 0) {  // rare: re-evaluate the overflow pairs
+                    const int j = j0 + lane;
+                    pr.valid = false;
+                    tl = -1;
+                    if (j < np) {
+                        int h0, h1, dd;
+                        pair_decode(s_pairs[wave][j], h0, h1, dd);
+                        const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
+                        aa_eval_pair(P, tri, E.b.opp, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, 0.f, 0.f, pr);
+                        if (pr.valid) {
+                            const int ht = pr.alpha > 0.f ? h0 : h1;
+                            const int tx = ht % QH - 1, ty = ht / QH - 1;
+                            cd = (float)((t1 >= 0) - (t0 >= 0));
+                            if (tx >= 0 && tx < QUAD && ty >= 0 && ty < QUAD) tl = ty * QUAD + tx;
+                        }
+                    }
+                }
+                if (pr.valid && tl >= 0 && !pr.clamped) {
+                    const float ga = s_gm[wave][tl] * cd;
+                    if (ga != 0.f) {
+                        float g[2][3];
+                        aa_pair_backward(pr, P, H, W, ga, g);
+                        acc_vertex(A, pos, pr.va, g[0][0], g[0][1], g[0][2]);
+                        acc_vertex(A, pos, pr.vb, g[1][0], g[1][1], g[1][2]);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+        // ---- wave reduction -> one partial per quadrant (fixed order: bit-reproducible)
         float vals[19];
 #pragma unroll
         for (int i = 0; i < 12; ++i) vals[i] = A.dF[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) vals[12 + i] = A.dM2[i];
         vals[16] = A.L[0]; vals[17] = A.L[1]; vals[18] = A.L[2];
-        if (wave_any) {
+        float mine = 0.f;
 #pragma unroll
-            for (int i = 0; i < 19; ++i) {
-                const float s = wave_sum(vals[i]);
-                if (lane == 0) red[wave][i] = s;
-            }
-        } else if (lane < 19) {
-            red[wave][lane] = 0.f;
+        for (int i = 0; i < 19; ++i) {
+            const float s = wave_sum(vals[i]);
+            if (lane == i) mine = s;
         }
-        __syncthreads();
-        if (tid < NPART)
-            E.partials[(size_t)work * NPART + tid] = tid < 19 ? (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]) : 0.f;
-        __syncthreads();
+        if (lane < NPART) part[lane] = mine;
     }
 }
 
@@ -464,38 +523,52 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float red[4][NPART];
     __shared__ float sums[NPART];
-    const int base = E.L.b_active[b * 2 + 0], n = E.L.b_active[b * 2 + 1];
-    // re-arm what this iteration dirtied, so that the next one needs no memset: the depth/visibility
-    // buffer of this hypothesis' active tiles, its tile flags and its bin counters
-    {
-        const int H = d.H, W = d.W;
-        const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
-        for (int s = 0; s < n; ++s) {
-            const int tile = E.L.active[base + s] - b * E.L.NT;
-            const int px = (tile % E.L.ntx) * DDX_TILE + lx, py = (tile / E.L.ntx) * DDX_TILE + ly;
-            if (px < W && py < H) E.L.zbuf[((size_t)b * H + py) * W + px] = ~0ull;
+    __shared__ float sc[64];      // scalars the tail needs, fetched in parallel
+    __shared__ int s_tiles[256];
+    const int it = E.st->it;
+    const int NT = E.L.NT;
+    // ---- parallel prefetch: params 0..6, lr_mult 7, lr 8, m23 9, proj 16..31, adam 32..45
+    if (tid < 7) sc[tid] = E.b.params[(size_t)tid * B + b];
+    else if (tid == 7) sc[7] = E.b.lr_mult[b];
+    else if (tid == 8) sc[8] = E.b.lr_sched[it];
+    else if (tid == 9) sc[9] = E.mats[(size_t)b * 32 + 11];
+    else if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
+    else if (tid >= 32 && tid < 46) sc[tid] = E.adam[(size_t)(tid - 32) * B + b];
+    // ---- this hypothesis' active tiles come ordered by tile index (compact_big_kernel): sum their quadrant
+    // partials in that fixed order (bit-reproducible) and re-arm what the iteration dirtied (zbuf of the
+    // active tiles, their flags) so that the next iteration needs no memset.
+    const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < 19 of group g sums value j
+    float acc = 0.f;
+    const int n_act = E.L.b_count[b];
+    const int* tiles = E.L.active + (size_t)b * NT;
+    for (int start = 0; start < n_act; start += 256) {
+        __syncthreads();
+        if (start + tid < n_act) {
+            const int tile = tiles[start + tid];
+            s_tiles[tid] = tile;
+            E.L.tile_flag[(size_t)b * NT + tile] = 0;
+            E.L.tile_big[(size_t)b * NT + tile] = 0;
         }
-        for (int i = tid; i < E.L.NT; i += 256) {
-            E.L.tile_count[(size_t)b * E.L.NT + i] = 0;
-            E.L.tile_flag[(size_t)b * E.L.NT + i] = 0;
-        }
-    }
-    // fixed-order reduction of this hypothesis' tile partials: thread (slot % 8, j) layout
-    {
-        const int j = tid % 32, lanegrp = tid / 32;  // 8 groups of 32 threads; thread j < 19 sums value j
-        float acc = 0.f;
+        __syncthreads();
+        const int na = min(256, n_act - start);
         if (j < 19)
-            for (int s = lanegrp; s < n; s += 8) acc += E.partials[(size_t)(base + s) * NPART + j];
-        // combine the 8 groups: groups 0,1 live in wave 0, etc.
-        acc += __shfl_xor(acc, 32, 64);
-        if (lane < NPART) red[wave][lane] = acc;
-        __syncthreads();
-        if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        __syncthreads();
+            for (int s = grp; s < na * 4; s += 8)
+                acc += E.partials[((size_t)(b * NT + s_tiles[s >> 2]) * 4 + (s & 3)) * NPART + j];
+        const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
+        for (int s = 0; s < na; ++s) {
+            const int tile = s_tiles[s];
+            const int px = (tile % E.L.ntx) * DDX_TILE + lx, py = (tile / E.L.ntx) * DDX_TILE + ly;
+            if (px < d.W && py < d.H) E.L.zbuf[((size_t)b * d.H + py) * d.W + px] = ~0ull;
+        }
     }
-    // whole-frame background depth term over the compact seg list
-    const float* M = E.mats + (size_t)b * 32;
-    const float dbg = -M[11];
+    acc += __shfl_xor(acc, 32, 64);  // groups 2w and 2w+1 live in wave w
+    __syncthreads();
+    if (lane < NPART) red[wave][lane] = acc;
+    __syncthreads();
+    if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+    // ---- whole-frame background depth term over the compact seg list
+    const float dbg = -sc[9];
     float bgsum = 0.f, bgder = 0.f;
     if (d.use_depth) {
         const int ns = E.st->n_seg;
@@ -514,9 +587,8 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
         bgder = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
     if (tid != 0) return;
-    const int it = E.st->it;
     const float npx = (float)d.H * (float)d.W;
-    const float lrb = E.b.lr_mult[b];
+    const float lrb = sc[7];
     // ---- loss log: weighted, not LR-scaled (diffdope.py:558-560,576-578,604-608)
     if (E.b.loss_log) {
         float* lg = E.b.loss_log + (size_t)it * 3 * B;
@@ -535,7 +607,7 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
         for (int j = 0; j < 4; ++j) {
             float a = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a = __fmaf_rn(E.b.proj[i * 4 + k], dFin[i * 4 + j], a);
+            for (int i = 0; i < 4; ++i) a = __fmaf_rn(sc[16 + i * 4 + k], dFin[i * 4 + j], a);
             G[k * 4 + j] = a;
         }
     if (d.use_depth) {
@@ -547,7 +619,7 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
     // ---- quaternion chain (the reverse of diffdope.py:57-80 and :1091)
     float qr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qr[i] = E.b.params[(size_t)i * B + b];
+    for (int i = 0; i < 4; ++i) qr[i] = sc[i];
     const float nq = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
     const float x = qr[0] / nq, y = qr[1] / nq, z = qr[2] / nq, w = qr[3] / nq;
     const float gx = G[1] * 2 * y + G[2] * 2 * z + G[4] * 2 * y + G[5] * (-4 * x) + G[6] * (-2 * w) + G[8] * 2 * z + G[9] * 2 * w + G[10] * (-4 * x);
@@ -557,29 +629,29 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
     const float dot = gx * x + gy * y + gz * z + gw * w;
     float grad[7] = {(gx - x * dot) / nq, (gy - y * dot) / nq, (gz - z * dot) / nq, (gw - w * dot) / nq, G[3], G[7], G[11]};
     // ---- optimiser step
-    const float lr = E.b.lr_sched[it];
+    const float lr = sc[8];
     if (d.optimizer == 0) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) E.b.params[(size_t)i * B + b] -= lr * grad[i];
+        for (int i = 0; i < 7; ++i) E.b.params[(size_t)i * B + b] = sc[i] - lr * grad[i];
     } else {
         const float b1 = d.adam_beta1, b2 = d.adam_beta2;
         const float c1 = 1.f - powf(b1, (float)(it + 1)), c2 = 1.f - powf(b2, (float)(it + 1));
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            float& m1 = E.adam[(size_t)i * B + b];
-            float& m2 = E.adam[(size_t)(7 + i) * B + b];
-            m1 = b1 * m1 + (1.f - b1) * grad[i];
-            m2 = b2 * m2 + (1.f - b2) * grad[i] * grad[i];
-            E.b.params[(size_t)i * B + b] -= lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
+            const float m1 = b1 * sc[32 + i] + (1.f - b1) * grad[i];
+            const float m2 = b2 * sc[39 + i] + (1.f - b2) * grad[i] * grad[i];
+            E.adam[(size_t)i * B + b] = m1;
+            E.adam[(size_t)(7 + i) * B + b] = m2;
+            E.b.params[(size_t)i * B + b] = sc[i] - lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
         }
     }
     // the last workgroup to arrive closes the iteration: every other one has already read `it`
+    atomicAdd(&E.st->active_acc, n_act);
     __threadfence();
     if (atomicAdd(&E.st->ticket, 1) == B - 1) {
-        E.st->overflow |= E.L.counters[0];
-        E.st->last_pairs = E.L.counters[1];
-        E.st->last_active = E.L.counters[2];
-        E.L.counters[0] = 0; E.L.counters[1] = 0; E.L.counters[2] = 0; E.L.counters[3] = 0;
+        E.st->last_pairs = E.L.counters[3];  // large triangles of this iteration
+        E.st->last_active = atomicExch(&E.st->active_acc, 0);
+        E.L.counters[3] = 0;
         E.st->ticket = 0;
         E.st->it = it + 1;
     }
@@ -588,9 +660,8 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
 __global__ void set_it_kernel(EngineState* st, int it) { st->it = it; }
 
 // ---------------------------------------------------------------------------------------------
-enum { K_XFM, K_BIN_COUNT, K_SCAN, K_BIN_FILL, K_RASTER, K_SHADE, K_UPDATE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"pose_xfm_kernel",   "scatter_kernel", "scan_kernel",  "bin_fill_kernel",
-                                                  "raster_big_kernel", "shade_kernel",   "update_kernel"};
+enum { K_XFM, K_SCATTER, K_RASTER_BIG, K_SHADE, K_UPDATE, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"pose_xfm_kernel", "scatter_kernel", "compact_big_kernel", "shade_kernel", "update_kernel"};
 
 static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
 {
@@ -598,9 +669,9 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
     const ddx_engine_desc& d = E.d;
     if (ev) DDX_HIP(hipEventRecord(ev[K_XFM], s));
     pose_xfm_kernel<<<dim3(ddx_cdiv(d.V, 256), d.B), 256, 0, s>>>(E);
-    if (int err = raster_run(E.clip, E.b.tri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_BIN_COUNT : nullptr)) return err;
+    if (int err = raster_run(E.clip, E.b.tri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_SCATTER : nullptr)) return err;
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
-    shade_kernel<<<RASTER_GRID, 256, 0, s>>>(E);
+    shade_kernel<<<RASTER_GRID, 256, (size_t)(d.B + 1) * sizeof(int), s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
     update_kernel<<<d.B, 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
@@ -611,18 +682,18 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
 static int check_desc(const ddx_engine_desc* d)
 {
     DDX_REQUIRE(d, DDX_E_NULL, "engine: NULL desc");
-    DDX_REQUIRE(d->B >= 1 && d->B <= 65535 && d->B_global >= d->B && d->V >= 3 && d->T >= 1 && d->H >= 1 && d->W >= 1 &&
+    DDX_REQUIRE(d->B >= 1 && d->B <= WORK_MAX_B && d->B_global >= d->B && d->V >= 3 && d->T >= 1 && d->H >= 1 && d->W >= 1 &&
                     d->H <= 4096 && d->W <= 4096 && d->max_iters >= 1,
                 DDX_E_SHAPE, "engine: bad shape B=%d Bg=%d V=%d T=%d H=%d W=%d iters=%d", d->B, d->B_global, d->V, d->T, d->H, d->W, d->max_iters);
     DDX_REQUIRE((d->Th > 0) == (d->Tw > 0), DDX_E_SHAPE, "engine: Th/Tw must both be zero or positive");
     return 0;
 }
 
-extern "C" size_t ddx_engine_scratch_bytes(const ddx_engine_desc* desc, long long pairs_hint)
+extern "C" size_t ddx_engine_scratch_bytes(const ddx_engine_desc* desc)
 {
     if (check_desc(desc)) return 0;
     EngineDev E;
-    return engine_layout(E, *desc, nullptr, pairs_hint);
+    return engine_layout(E, *desc, nullptr);
 }
 
 extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* bufs, ddx_engine** out)
@@ -640,16 +711,11 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     DDX_REQUIRE(e, DDX_E_NULL, "engine_create: out of host memory");
     e->dev.d = *desc;
     e->dev.b = *bufs;
-    // capacity follows from the scratch actually provided
-    EngineDev probe;
-    const size_t fixed = engine_layout(probe, *desc, b.scratch, 1);
-    if (b.scratch_bytes < fixed) {
+    const size_t need = engine_layout(e->dev, *desc, b.scratch);
+    if (b.scratch_bytes < need) {
         delete e;
-        DDX_REQUIRE(false, DDX_E_SCRATCH, "engine_create: scratch %zu < minimum %zu bytes", b.scratch_bytes, fixed);
+        DDX_REQUIRE(false, DDX_E_SCRATCH, "engine_create: scratch %zu < required %zu bytes", b.scratch_bytes, need);
     }
-    long long cap = (long long)((b.scratch_bytes - fixed) / sizeof(int)) + 1;
-    while (cap > 1 && engine_layout(probe, *desc, b.scratch, cap) > b.scratch_bytes) cap -= 64;
-    engine_layout(e->dev, *desc, b.scratch, cap < 1 ? 1 : cap);
     *out = e;
     return 0;
 }

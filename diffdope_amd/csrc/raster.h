@@ -1,35 +1,77 @@
-// raster.h -- scratch layout and entry points of the tile rasteriser (raster.hip), shared with the
-// renderer ops and the fused engine.
+// raster.h -- scratch layout and entry points of the rasteriser (raster.hip), shared with the renderer
+// ops and the fused engine.
 #pragma once
 #include "raster_math.h"
 
-#define RASTER_GRID 2048  // persistent workgroups striding over the active tiles (256 CUs x 8)
-#define SNAP_INVALID INT_MIN  // snapped X of a vertex with clip w <= 0
+#define RASTER_GRID 2048      // persistent workgroups striding over the active tiles
 #define RASTER_SMALL_PX 16    // triangles whose bbox holds at most this many pixel centres are resolved in scatter_kernel
+#define RASTER_BIG_GRID 256   // workgroups of the large-triangle pass
 
 struct RasterScratch {
-    int* counters;        // [16]: 0 overflow flag, 1 binned (tile,triangle) pairs, 2 active tiles, 3 binned triangles
-    int* tile_count;      // [B,NT] binned (large) triangles per tile
-    int* tile_flag;       // [B,NT] != 0: tile is active (holds or borders a possibly covered pixel)
-    int* tile_cursor;     // [B,NT] (zeroed by scan_kernel)
-    int* tile_offset;     // [B,NT] start of each tile's list in items
-    int* active;          // [B*NT] compacted flat ids (b*NT + tile) of non-empty tiles, hypothesis-major
-    int* b_active;        // [B,2] (first slot, count) of each hypothesis' active tiles
-    int2* snap;           // [B,V] window coordinates in 1/256 px (x = SNAP_INVALID if w <= 0)
-    unsigned* trirange;   // [B,T] packed tile range tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24, ~0u = culled
-    int* items;           // [capacity] triangle ids
-    unsigned long long* zbuf;  // [B,H,W] (depth key << 32 | triangle id), all ones = background
+    int* counters;            // [16]: 3 = large triangles of this pass
+    int* tile_flag;           // [B,NT] != 0: tile holds or borders a possibly covered pixel (plain stores of 1)
+    int* tile_big;            // [B,NT] != 0: a large triangle overlaps the tile
+    int* active;              // [B,NT] per-hypothesis ordered list of active tile ids (first b_count[b] entries)
+    int* b_count;             // [B] active tiles of each hypothesis
+    int2* snap;               // [B,V] window coordinates in 1/256 px (x = INT_MIN if w <= 0)
+    unsigned* trirange;       // [B,T] packed tile range of a LARGE triangle: tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24; ~0u otherwise
+    unsigned long long* zbuf; // [B,H,W] (depth key << 32 | triangle id), all ones = background
     size_t zbuf_bytes;
-    size_t zero_bytes;    // bytes from `counters` that must be zero before a pass (counters + tile_count + tile_flag)
-    int capacity;
+    size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big)
     int ntx, nty, NT;
 };
 
-size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, int W, long long pairs_hint);
+size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, int W);
 // window-coordinate snap of clip positions (the fused engine does this inside its transform kernel)
 int raster_snap(const float* pos, int B, int V, int H, int W, const RasterScratch& L, hipStream_t s);
-// scatter + scan + bin fill + big-triangle raster (no emit); asynchronous on s.  Needs L.snap filled.
-// clear: memset counters/tile_count/tile_flag and re-arm zbuf first (the engine maintains both itself).
-// ev (nullable): 4 events recorded before the count / scan / fill / raster launches (profiling)
+// scatter + (compaction | large-triangle raster) (no emit); asynchronous on s.  Needs L.snap filled.
+// clear: memset counters/tile_flag and re-arm zbuf first (the engine maintains both itself).
+// ev (nullable): 2 events recorded before the scatter / compact_big launches (profiling)
 int raster_run(const float* pos, const int* tri, int B, int V, int T, int H, int W, const RasterScratch& L, hipStream_t s,
                bool clear, hipEvent_t* ev);
+
+// Active-tile bookkeeping without atomics on hot words (device-scope atomics on one address serialise
+// across the 8 XCDs: a per-tile counter cost 27 us per pass here): scatter_kernel flags tiles with plain
+// stores; compact_kernel (one workgroup per hypothesis) ballot-compacts each hypothesis' flags into its own
+// ordered segment active[b*NT ...] and writes the count b_count[b]; consumers rebuild the global
+// enumeration from the B counts with a block scan in LDS (work_prefix) and map work item -> (b, tile)
+// with a binary search (work_lookup).
+#define WORK_MAX_B 4096
+
+// prefix[0..B] (exclusive scan of b_count) into LDS; returns the total.  All 256 threads must call.
+__device__ __forceinline__ int work_prefix(const int* __restrict__ b_count, int B, int* prefix, int* wsum)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;
+    for (int start = 0; start < B; start += 256) {
+        const int i = start + tid;
+        const int c = i < B ? b_count[i] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (i < B) prefix[i] = carry + woff + incl - c;
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (tid == 0) prefix[B] = carry;
+    __syncthreads();
+    return carry;
+}
+
+// largest b with prefix[b] <= w  (w < prefix[B])
+__device__ __forceinline__ int work_lookup(const int* prefix, int B, int w)
+{
+    int lo = 0, hi = B;  // invariant: prefix[lo] <= w < prefix[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= w) lo = mid; else hi = mid;
+    }
+    return lo;
+}

@@ -6,19 +6,20 @@
 //
 //   scatter_kernel   one lane per (hypothesis, triangle).  Three 8-byte gathers of the per-vertex snapped
 //                    window coordinates (1/256 px, produced once per vertex by the transform kernel), exact
-//                    int64 setup, pixel-centre bbox.  No centre inside -> dead.  Up to RASTER_SMALL_PX
-//                    centres -> resolved right here: exact coverage test, fp32 z/w, one non-returning 64-bit
-//                    atomicMin of (depth key, id) per fragment into the depth/visibility buffer
-//                    zbuf[b,y,x].  Larger -> binned: packed tile range stored, per-tile counts bumped with
-//                    WAVE-AGGREGATED atomics (the ballot/popcount grouping is ALU-only, then every group
-//                    leader issues its atomic in the same instruction: one L2 round trip per wave, not
-//                    one per distinct tile).  Either way the 16x16 tiles under bbox + 1 px (antialias
-//                    apron) are flagged active.
-//   scan_kernel      one workgroup per hypothesis: scan of the binned counts (item ranges), ordered
-//                    compaction of the flagged tiles into the active-tile list the shading stage walks.
-//   bin_fill_kernel  binned triangles only: same wave-aggregated grouping, writes ids into the tile lists.
-//   raster_big_kernel  tiles with a non-empty list: the 256 lanes are the 256 pixels, triangle setup is
-//                    wave-uniform, results merge into zbuf with the same atomicMin.
+//                    integer setup, pixel-centre bbox.  No centre inside -> dead.  Up to RASTER_SMALL_PX
+//                    centres -> resolved right here: edge functions evaluated incrementally in 32-bit
+//                    integers relative to the bbox corner (exact: a small triangle spans < 2^13 sub-pixels),
+//                    fp32 z/w for the covered centres, one non-returning 64-bit atomicMin of
+//                    (depth key, id) per fragment into the depth/visibility buffer zbuf[b,y,x].
+//                    Larger -> its packed tile range is stored for raster_big_kernel.
+//                    Either way the 16x16 tiles under bbox + 1 px (antialias apron) are flagged active
+//                    with plain stores (no atomic on a hot word).
+//   compact_big_kernel  workgroups [0,B): ordered per-hypothesis compaction of the flags (active lists);
+//                    the other workgroups: tiles flagged in tile_big only (none in the micro-polygon regime:
+//                    they exit on one scalar load).  Such a workgroup sweeps the hypothesis' packed
+//                    ranges, ballot-compacts the triangles overlapping its tile into LDS, then the 256
+//                    lanes are the 256 pixels (exact int64 coverage), merging into zbuf with atomicMin.
+//                    No per-tile lists in memory, so nothing can overflow.
 //   emit_kernel      (op-level API only) expands zbuf into nvdiffrast's rast tensor (u, v, z/w, id+1).
 //
 // zbuf invariant: all ones between passes.  The op-level entry memsets it; the fused engine re-arms only
@@ -28,12 +29,10 @@
 
 // ---------------------------------------------------------------------------------------------
 // scratch carving
-size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, int W, long long pairs_hint)
+size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, int W)
 {
     const int ntx = ddx_cdiv(W, DDX_TILE), nty = ddx_cdiv(H, DDX_TILE);
     const long long NT = (long long)ntx * nty;
-    long long cap = pairs_hint > 0 ? pairs_hint : (2LL * B * T + 64LL * B * NT);
-    if (cap > 0x7fffffffLL) cap = 0x7fffffffLL;
     size_t off = 0;
     auto carve = [&](size_t bytes) {
         size_t o = off;
@@ -42,30 +41,23 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     };
     char* p = (char*)base;
     const size_t o_counters = carve(16 * sizeof(int));
-    const size_t o_count = carve((size_t)B * NT * sizeof(int));
     const size_t o_flag = carve((size_t)B * NT * sizeof(int));
-    L.zero_bytes = off;  // [counters | tile_count | tile_flag] must be zero when a pass starts
-    const size_t o_cursor = carve((size_t)B * NT * sizeof(int));
-    const size_t o_offset = carve((size_t)B * NT * sizeof(int));
+    const size_t o_big = carve((size_t)B * NT * sizeof(int));
+    L.zero_bytes = off;  // [counters | tile_flag | tile_big] must be zero when a pass starts
     const size_t o_active = carve((size_t)B * NT * sizeof(int));
-    const size_t o_bbase = carve((size_t)B * 2 * sizeof(int));
+    const size_t o_bcount = carve((size_t)B * sizeof(int));
     const size_t o_snap = carve((size_t)B * V * sizeof(int2));
     const size_t o_range = carve((size_t)B * T * sizeof(unsigned));
-    const size_t o_items = carve((size_t)cap * sizeof(int));
     const size_t o_zbuf = carve((size_t)B * H * W * sizeof(unsigned long long));
     L.counters = (int*)(p + o_counters);
-    L.tile_count = (int*)(p + o_count);
     L.tile_flag = (int*)(p + o_flag);
-    L.tile_cursor = (int*)(p + o_cursor);
-    L.tile_offset = (int*)(p + o_offset);
+    L.tile_big = (int*)(p + o_big);
     L.active = (int*)(p + o_active);
-    L.b_active = (int*)(p + o_bbase);
+    L.b_count = (int*)(p + o_bcount);
     L.snap = (int2*)(p + o_snap);
     L.trirange = (unsigned*)(p + o_range);
-    L.items = (int*)(p + o_items);
     L.zbuf = (unsigned long long*)(p + o_zbuf);
     L.zbuf_bytes = (size_t)B * H * W * sizeof(unsigned long long);
-    L.capacity = (int)cap;
     L.ntx = ntx; L.nty = nty; L.NT = (int)NT;
     return off;
 }
@@ -99,33 +91,21 @@ __device__ __forceinline__ unsigned long long frag_key(const float4& p0, const f
     return ((unsigned long long)depth_key(bc.zw) << 32) | (unsigned)t;
 }
 
-// Wave-aggregated per-tile counter bump.  Each lane brings (valid, key).  The grouping loop is pure
-// ballot/shuffle ALU; afterwards every group leader issues ONE atomicAdd in the same instruction and the
-// members read their base back with a shuffle.  Returns this lane's slot within its tile (base + rank).
-template <bool NEED_SLOT>
-__device__ __forceinline__ int wave_grouped_add(int* __restrict__ counter, bool valid, int key, int lane)
+// 32-bit edge function of a SMALL triangle relative to the bbox corner pixel centre (X0,Y0):
+// e(i,j) = e00 + i*sx + j*sy for the pixel (px0+i, py0+j); `own` = ownership of the e == 0 line.
+struct Edge32 { int e00, sx, sy; bool own; };
+
+__device__ __forceinline__ Edge32 make_edge(int ax, int ay, int bx, int by, int X0, int Y0, bool flip)
 {
-    int leader_of = lane, rank = 0, cnt = 0;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int key_l = __shfl(key, leader, 64);
-        const unsigned long long same = __ballot(valid && key == key_l);
-        if (valid && key == key_l) {
-            leader_of = leader;
-            rank = __popcll(same & ((1ull << lane) - 1ull));
-            cnt = __popcll(same);
-        }
-        todo &= ~same;
-    }
-    int base = 0;
-    if (valid && leader_of == lane) {
-        if (NEED_SLOT) base = atomicAdd(counter + key, cnt);
-        else atomicAdd(counter + key, cnt);  // non-returning
-    }
-    if (!NEED_SLOT) return 0;
-    base = __shfl(base, leader_of, 64);
-    return base + rank;
+    int dx = bx - ax, dy = by - ay;
+    if (flip) { dx = -dx; dy = -dy; }
+    Edge32 e;
+    // e = dx*(PY-ay) - dy*(PX-ax); all factors < 2^14 for a small triangle near its own bbox
+    e.e00 = dx * (Y0 - ay) - dy * (X0 - ax);
+    e.sx = -dy * DDX_SUBPIX;
+    e.sy = dx * DDX_SUBPIX;
+    e.own = (dy > 0) || (dy == 0 && dx < 0);
+    return e;
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
@@ -133,182 +113,164 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
 {
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    unsigned range = ~0u;  // packed tile range of a BINNED triangle
-    if (t < T) {
-        const int i0 = tri[t * 3 + 0], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
-        if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
-            const int2* S = L.snap + (size_t)b * V;
-            SnapTri s;
-            snap_from_vertices(S[i0], S[i1], S[i2], s);
-            if (s.ok) {
-                int px0, py0, px1, py1;
-                snap_bbox(s, px0, py0, px1, py1);
-                px0 = max(px0, 0); py0 = max(py0, 0);
-                px1 = min(px1, W - 1); py1 = min(py1, H - 1);
-                if (px0 <= px1 && py0 <= py1) {
-                    // tiles under bbox + 1 px: every pixel adjacent to a covered pixel lies in an active tile
-                    const int tx0 = max(px0 - 1, 0) / DDX_TILE, tx1 = min(px1 + 1, W - 1) / DDX_TILE;
-                    const int ty0 = max(py0 - 1, 0) / DDX_TILE, ty1 = min(py1 + 1, H - 1) / DDX_TILE;
-                    int* flag = L.tile_flag + (size_t)b * L.NT;
-                    const int npx = (px1 - px0 + 1) * (py1 - py0 + 1);
-                    if (npx <= RASTER_SMALL_PX) {
+    if (t >= T) return;
+    unsigned range = ~0u;  // packed tile range of a LARGE triangle
+    const int i0 = tri[t * 3 + 0], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
+    if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+        const int2* S = L.snap + (size_t)b * V;
+        const int2 a = S[i0], bq = S[i1], c = S[i2];
+        if (a.x != INT_MIN && bq.x != INT_MIN && c.x != INT_MIN) {
+            const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
+            const int ymin = min(a.y, min(bq.y, c.y)), ymax = max(a.y, max(bq.y, c.y));
+            int px0 = (xmin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, px1 = (xmax - DDX_SUBPIX / 2) >> 8;
+            int py0 = (ymin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, py1 = (ymax - DDX_SUBPIX / 2) >> 8;
+            px0 = max(px0, 0); py0 = max(py0, 0);
+            px1 = min(px1, W - 1); py1 = min(py1, H - 1);
+            if (px0 <= px1 && py0 <= py1) {
+                const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
+                const bool small = nxp * nyp <= RASTER_SMALL_PX && (xmax - xmin) < 8192 && (ymax - ymin) < 8192;
+                bool alive = false;
+                if (small) {
+                    // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
+                    const int area = (bq.x - a.x) * (c.y - a.y) - (c.x - a.x) * (bq.y - a.y);
+                    if (area != 0) {
+                        alive = true;
+                        const bool flip = area < 0;
+                        const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
+                        const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
+                        const Edge32 e1 = make_edge(c.x, c.y, a.x, a.y, X0, Y0, flip);
+                        const Edge32 e2 = make_edge(a.x, a.y, bq.x, bq.y, X0, Y0, flip);
                         bool loaded = false;
                         float4 p0, p1, p2;
                         unsigned long long* Z = L.zbuf + (size_t)b * H * W;
-                        for (int py = py0; py <= py1; ++py)
-                            for (int px = px0; px <= px1; ++px) {
-                                if (!tri_covers(s, px, py)) continue;
+                        for (int j = 0; j < nyp; ++j) {
+                            int v0 = e0.e00 + j * e0.sy, v1 = e1.e00 + j * e1.sy, v2 = e2.e00 + j * e2.sy;
+                            for (int i = 0; i < nxp; ++i, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx) {
+                                const bool in = (v0 > 0 || (v0 == 0 && e0.own)) && (v1 > 0 || (v1 == 0 && e1.own)) &&
+                                                (v2 > 0 || (v2 == 0 && e2.own));
+                                if (!in) continue;
                                 if (!loaded) {  // clip-space vertices only for triangles that own a pixel centre
                                     const float* P = pos + (size_t)b * V * 4;
                                     p0 = ld4(P + (size_t)i0 * 4); p1 = ld4(P + (size_t)i1 * 4); p2 = ld4(P + (size_t)i2 * 4);
                                     loaded = true;
                                 }
-                                const unsigned long long key = frag_key(p0, p1, p2, px, py, H, W, t);
-                                if (key != ~0ull) atomicMin(Z + (size_t)py * W + px, key);
+                                const unsigned long long key = frag_key(p0, p1, p2, px0 + i, py0 + j, H, W, t);
+                                if (key != ~0ull) atomicMin(Z + (size_t)(py0 + j) * W + px0 + i, key);
                             }
-                        // (a triangle whose bbox holds a centre it does not cover still flags its tiles:
-                        //  conservative, keeps the flag independent of the coverage loop)
+                        }
+                    }
+                } else {
+                    const long long area = (long long)(bq.x - a.x) * (long long)(c.y - a.y) - (long long)(c.x - a.x) * (long long)(bq.y - a.y);
+                    alive = area != 0;
+                }
+                if (alive) {
+                    // tiles under bbox + 1 px: every pixel adjacent to a covered pixel lies in an active tile
+                    // (conservative: a centre inside the bbox need not be covered)
+                    const int tx0 = max(px0 - 1, 0) / DDX_TILE, tx1 = min(px1 + 1, W - 1) / DDX_TILE;
+                    const int ty0 = max(py0 - 1, 0) / DDX_TILE, ty1 = min(py1 + 1, H - 1) / DDX_TILE;
+                    int* flag = L.tile_flag + (size_t)b * L.NT;
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) flag[ty * L.ntx + tx] = 1;  // plain store, no atomics
+                    if (!small) {
+                        int* big = L.tile_big + (size_t)b * L.NT;
                         for (int ty = ty0; ty <= ty1; ++ty)
-                            for (int tx = tx0; tx <= tx1; ++tx) flag[ty * L.ntx + tx] = 1;
-                    } else {
+                            for (int tx = tx0; tx <= tx1; ++tx) big[ty * L.ntx + tx] = 1;
                         range = (unsigned)tx0 | ((unsigned)ty0 << 8) | ((unsigned)(tx1 - tx0) << 16) | ((unsigned)(ty1 - ty0) << 24);
+                        atomicAdd(&L.counters[3], 1);
                     }
                 }
             }
         }
-        L.trirange[(size_t)b * T + t] = range;
     }
-    // binned triangles (rare in the micro-polygon regime): count per tile, flag tiles
-    const unsigned long long anybig = __ballot(range != ~0u);
-    if (anybig == 0ull) return;
-    if (lane == __ffsll((long long)anybig) - 1) atomicAdd(&L.counters[3], __popcll(anybig));
-    const int tx0 = range & 255, ty0 = (range >> 8) & 255;
-    const int nx = range == ~0u ? 0 : (int)((range >> 16) & 255) + 1, ny = range == ~0u ? 0 : (int)(range >> 24) + 1;
-    const int ntiles = nx * ny;
-    int maxn = ntiles;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxn = max(maxn, __shfl_xor(maxn, o, 64));
-    int* const counter = L.tile_count + (size_t)b * L.NT;
-    for (int k = 0; k < maxn; ++k) {
-        const bool valid = k < ntiles;
-        const int key = valid ? (ty0 + k / nx) * L.ntx + (tx0 + k % nx) : -1;
-        wave_grouped_add<false>(counter, valid, key, lane);
-        if (valid) L.tile_flag[(size_t)b * L.NT + key] = 1;
-    }
+    L.trirange[(size_t)b * T + t] = range;
 }
 
-__global__ __launch_bounds__(256) void bin_fill_kernel(int T, RasterScratch L)
-{
-    if (L.counters[3] == 0) return;  // no binned triangle in the whole batch
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const unsigned range = t < T ? L.trirange[(size_t)b * T + t] : ~0u;
-    if (__ballot(range != ~0u) == 0ull) return;
-    const int tx0 = range & 255, ty0 = (range >> 8) & 255;
-    const int nx = range == ~0u ? 0 : (int)((range >> 16) & 255) + 1, ny = range == ~0u ? 0 : (int)(range >> 24) + 1;
-    const int ntiles = nx * ny;
-    int maxn = ntiles;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxn = max(maxn, __shfl_xor(maxn, o, 64));
-    int* const counter = L.tile_cursor + (size_t)b * L.NT;
-    for (int k = 0; k < maxn; ++k) {
-        const bool valid = k < ntiles;
-        const int key = valid ? (ty0 + k / nx) * L.ntx + (tx0 + k % nx) : -1;
-        const int slot_in_tile = wave_grouped_add<true>(counter, valid, key, lane);
-        if (valid) {
-            const long long slot = (long long)L.tile_offset[(size_t)b * L.NT + key] + slot_in_tile;
-            if (slot < L.capacity) L.items[slot] = t;
-        }
-    }
-}
+// One launch, two roles.
+//   workgroups [0, B): compaction -- workgroup b turns hypothesis b's tile flags into its ordered active-tile
+//     segment + count (ballot ranks, no atomics).
+//   workgroups [B, B + RASTER_BIG_GRID): large triangles -- exit on one scalar load when the batch has none;
+//     otherwise stride over all (b, tile) with tile_big set: sweep the hypothesis' packed ranges,
+//     ballot-compact the triangles overlapping the tile into LDS, then lane = pixel (exact int64 coverage),
+//     merging into zbuf with atomicMin.
+#define BIG_LIST 512
 
-// one workgroup per hypothesis: scan the binned counts, reserve the item range, compact flagged tiles
-__global__ __launch_bounds__(256) void scan_kernel(RasterScratch L)
+__global__ __launch_bounds__(256) void compact_big_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int B,
+                                                          int V, int T, int H, int W, RasterScratch L)
 {
-    const int b = blockIdx.x;
+    __shared__ int list[BIG_LIST];
+    __shared__ int wcnt[4];
+    __shared__ int n_list;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ int wsum[4], wact[4];
-    __shared__ int s_base, s_abase, s_carry, s_acarry;
-    if (tid == 0) { s_carry = 0; s_acarry = 0; }
-    __syncthreads();
-    const int* cnt = L.tile_count + (size_t)b * L.NT;
-    const int* flg = L.tile_flag + (size_t)b * L.NT;
-    // pass 1: totals
-    int tot = 0, act = 0;
-    for (int i = tid; i < L.NT; i += 256) { tot += cnt[i]; act += flg[i] != 0; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, 64); act += __shfl_xor(act, o, 64); }
-    if (lane == 0) { wsum[wave] = tot; wact[wave] = act; }
-    __syncthreads();
-    if (tid == 0) {
-        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        const int nact = wact[0] + wact[1] + wact[2] + wact[3];
-        s_base = total ? atomicAdd(&L.counters[1], total) : 0;
-        s_abase = atomicAdd(&L.counters[2], nact);
-        if ((long long)s_base + total > L.capacity) L.counters[0] = 1;
-        L.b_active[b * 2 + 0] = s_abase;
-        L.b_active[b * 2 + 1] = nact;
-    }
-    __syncthreads();
-    // pass 2: exclusive scans in tile order (deterministic), 256 tiles per step
-    for (int start = 0; start < L.NT; start += 256) {
-        const int i = start + tid;
-        const int c = i < L.NT ? cnt[i] : 0;
-        const int a = i < L.NT ? (flg[i] != 0) : 0;
-        int incl = c, aincl = a;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int n = __shfl_up(incl, o, 64), na = __shfl_up(aincl, o, 64);
-            if (lane >= o) { incl += n; aincl += na; }
+    if ((int)blockIdx.x < B) {
+        const int b = blockIdx.x;
+        const int* flg = L.tile_flag + (size_t)b * L.NT;
+        int* out = L.active + (size_t)b * L.NT;
+        int carry = 0;
+        for (int start = 0; start < L.NT; start += 256) {
+            const int i = start + tid;
+            const bool act = i < L.NT && flg[i] != 0;
+            const unsigned long long m = __ballot(act);
+            __syncthreads();
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = carry;
+            for (int w = 0; w < wave; ++w) off += wcnt[w];
+            if (act) out[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            carry += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         }
-        if (lane == 63) { wsum[wave] = incl; wact[wave] = aincl; }
-        __syncthreads();
-        int woff = 0, waoff = 0;
-        for (int w = 0; w < wave; ++w) { woff += wsum[w]; waoff += wact[w]; }
-        const int excl = s_carry + woff + incl - c;
-        const int aexcl = s_acarry + waoff + aincl - a;
-        if (i < L.NT) {
-            L.tile_offset[(size_t)b * L.NT + i] = s_base + excl;
-            L.tile_cursor[(size_t)b * L.NT + i] = 0;
-            if (a) L.active[s_abase + aexcl] = b * L.NT + i;
-        }
-        __syncthreads();
-        if (tid == 255) { s_carry = excl + c; s_acarry = aexcl + a; }
-        __syncthreads();
+        if (tid == 0) L.b_count[b] = carry;
+        return;
     }
-}
-
-// tiles with binned triangles: lane = pixel, wave-uniform triangle walk
-__global__ __launch_bounds__(256) void raster_big_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
-                                                         int H, int W, RasterScratch L)
-{
-    if (L.counters[3] == 0) return;
-    const int tid = threadIdx.x;
-    const int n_active = L.counters[2];
-    for (int work = blockIdx.x; work < n_active; work += gridDim.x) {
-        const int flat = L.active[work];
-        const int cnt = L.tile_count[flat];
-        if (cnt == 0) continue;
+    if (L.counters[3] == 0) return;  // no large triangle in the whole batch
+    const int total = B * L.NT;
+    for (int flat = blockIdx.x - B; flat < total; flat += gridDim.x - B) {
+        if (L.tile_big[flat] == 0) continue;
         const int b = flat / L.NT, tile = flat - b * L.NT;
-        const int ox = (tile % L.ntx) * DDX_TILE, oy = (tile / L.ntx) * DDX_TILE;
+        const int tcx = tile % L.ntx, tcy = tile / L.ntx;
         const float* P = pos + (size_t)b * V * 4;
         const int2* S = L.snap + (size_t)b * V;
-        const int off = L.tile_offset[flat];
-        const int avail = max(0, min(cnt, L.capacity - off));
-        const int px = ox + tid % DDX_TILE, py = oy + tid / DDX_TILE;
-        if (px >= W || py >= H) continue;
+        const unsigned* R = L.trirange + (size_t)b * T;
+        const int px = tcx * DDX_TILE + tid % DDX_TILE, py = tcy * DDX_TILE + tid / DDX_TILE;
+        const bool inimg = px < W && py < H;
         unsigned long long best = ~0ull;
-        for (int j = 0; j < avail; ++j) {
-            const int t = L.items[off + j];
-            const int i0 = tri[t * 3 + 0], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
-            SnapTri s;
-            snap_from_vertices(S[i0], S[i1], S[i2], s);
-            if (!tri_covers(s, px, py)) continue;
-            const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
-            const unsigned long long key = frag_key(p0, p1, p2, px, py, H, W, t);
-            best = key < best ? key : best;
+        for (int t0 = 0; t0 < T; t0 += BIG_LIST) {
+            // ---- compact the triangles of [t0, t0+BIG_LIST) whose tile range contains this tile (ordered)
+            __syncthreads();
+            if (tid == 0) n_list = 0;
+            __syncthreads();
+            for (int sub = 0; sub < BIG_LIST; sub += 256) {
+                const int t = t0 + sub + tid;
+                bool hit = false;
+                if (t < T) {
+                    const unsigned r = R[t];
+                    if (r != ~0u) {
+                        const int x0 = r & 255, y0 = (r >> 8) & 255, nx = (r >> 16) & 255, ny = r >> 24;
+                        hit = tcx >= x0 && tcx <= x0 + nx && tcy >= y0 && tcy <= y0 + ny;
+                    }
+                }
+                const unsigned long long m = __ballot(hit);
+                if (lane == 0) wcnt[wave] = __popcll(m);
+                __syncthreads();
+                int off = n_list;
+                for (int w = 0; w < wave; ++w) off += wcnt[w];
+                if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
+                __syncthreads();
+                if (tid == 0) n_list += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                __syncthreads();
+            }
+            // ---- lane = pixel over the compacted triangles (wave-uniform walk)
+            const int nl = n_list;
+            if (inimg)
+                for (int j = 0; j < nl; ++j) {
+                    const int t = list[j];
+                    const int i0 = tri[t * 3 + 0], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
+                    SnapTri s;
+                    snap_from_vertices(S[i0], S[i1], S[i2], s);
+                    if (!tri_covers(s, px, py)) continue;
+                    const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
+                    const unsigned long long key = frag_key(p0, p1, p2, px, py, H, W, t);
+                    best = key < best ? key : best;
+                }
         }
         if (best != ~0ull) atomicMin(L.zbuf + ((size_t)b * H + py) * W + px, best);
     }
@@ -348,47 +310,36 @@ int raster_run(const float* pos, const int* tri, int B, int V, int T, int H, int
         DDX_HIP(hipMemsetAsync(L.counters, 0, L.zero_bytes, s));
         DDX_HIP(hipMemsetAsync(L.zbuf, 0xFF, L.zbuf_bytes, s));
     }
-    dim3 gbin(ddx_cdiv(T, 256), B);
-    scatter_kernel<<<gbin, 256, 0, s>>>(pos, tri, V, T, H, W, L);
+    scatter_kernel<<<dim3(ddx_cdiv(T, 256), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
     if (ev) DDX_HIP(hipEventRecord(ev[1], s));
-    scan_kernel<<<B, 256, 0, s>>>(L);
-    if (ev) DDX_HIP(hipEventRecord(ev[2], s));
-    bin_fill_kernel<<<gbin, 256, 0, s>>>(T, L);
-    if (ev) DDX_HIP(hipEventRecord(ev[3], s));
-    raster_big_kernel<<<RASTER_GRID, 256, 0, s>>>(pos, tri, V, H, W, L);
+    compact_big_kernel<<<B + RASTER_BIG_GRID, 256, 0, s>>>(pos, tri, B, V, T, H, W, L);
     DDX_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" size_t ddx_rasterize_scratch_bytes(int B, int V, int T, int H, int W, long long pairs_hint)
+extern "C" size_t ddx_rasterize_scratch_bytes(int B, int V, int T, int H, int W)
 {
     if (B < 1 || V < 1 || T < 1 || H < 1 || W < 1 || H > 4096 || W > 4096) return 0;
     RasterScratch L;
-    return raster_layout(L, nullptr, B, V, T, H, W, pairs_hint);
+    return raster_layout(L, nullptr, B, V, T, H, W);
 }
 
 extern "C" int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W, void* scratch,
-                                 size_t scratch_bytes, float* rast, int32_t* status, void* stream)
+                                 size_t scratch_bytes, float* rast, void* stream)
 {
-    DDX_REQUIRE(pos && tri && scratch && rast && status, DDX_E_NULL, "rasterize_fwd: NULL pointer");
+    DDX_REQUIRE(pos && tri && scratch && rast, DDX_E_NULL, "rasterize_fwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && B <= 65535 && V >= 1 && T >= 1 && H >= 1 && W >= 1 && H <= 4096 && W <= 4096, DDX_E_SHAPE,
                 "rasterize_fwd: bad shape B=%d V=%d T=%d H=%d W=%d", B, V, T, H, W);
     DDX_REQUIRE(((uintptr_t)pos & 15) == 0 && ((uintptr_t)rast & 15) == 0 && ((uintptr_t)scratch & 255) == 0, DDX_E_ALIGN,
                 "rasterize_fwd: pos/rast must be 16-byte and scratch 256-byte aligned");
     RasterScratch L;
-    // infer the pairs capacity from the scratch size: everything but the item list is fixed
-    const size_t fixed = raster_layout(L, scratch, B, V, T, H, W, 1);
-    DDX_REQUIRE(scratch_bytes >= fixed, DDX_E_SCRATCH, "rasterize_fwd: scratch %zu < minimum %zu bytes", scratch_bytes, fixed);
-    long long cap = (long long)((scratch_bytes - fixed) / sizeof(int)) + 1;
-    // round down until the layout fits (256-byte rounding of the item section)
-    while (cap > 1 && raster_layout(L, scratch, B, V, T, H, W, cap) > scratch_bytes) cap -= 64;
-    raster_layout(L, scratch, B, V, T, H, W, cap < 1 ? 1 : cap);
+    const size_t need = raster_layout(L, scratch, B, V, T, H, W);
+    DDX_REQUIRE(scratch_bytes >= need, DDX_E_SCRATCH, "rasterize_fwd: scratch %zu < required %zu bytes", scratch_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     if (int e = raster_snap(pos, B, V, H, W, L, s)) return e;
     if (int e = raster_run(pos, tri, B, V, T, H, W, L, s, true, nullptr)) return e;
     const long long n = (long long)B * H * W;
     emit_kernel<<<(n + 255) / 256 > 8192 ? 8192 : (int)((n + 255) / 256), 256, 0, s>>>(pos, tri, V, B, H, W, L, rast);
     DDX_LAUNCH_CHECK();
-    DDX_HIP(hipMemcpyAsync(status, L.counters, 4 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return 0;
 }

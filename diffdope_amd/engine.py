@@ -28,7 +28,7 @@ class RefineEngine:
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
-                 vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, pairs_hint=0, log_mtx=True):
+                 vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":
@@ -67,7 +67,7 @@ class RefineEngine:
         d.adam_beta1, d.adam_beta2, d.adam_eps = adam
         d.max_iters = n_it
         self.desc = d
-        nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d), pairs_hint)
+        nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))
         if nbytes == 0:
             raise RuntimeError("ddx_engine_scratch_bytes: " + self.lib.ddx_last_error().decode())
         self._scratch_raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
@@ -96,16 +96,16 @@ class RefineEngine:
         self.it = it
 
     def status(self):
-        """dict(overflow, pairs, active_tiles, it, n_seg) -- synchronises."""
+        """dict(overflow (always 0), big_triangles, active_tiles, it, n_seg) -- synchronises."""
         p = self.lib.ddx_engine_status_ptr(self.handle)
         off = p - self.scratch.data_ptr()
         st = self.scratch[off:off + 32].view(torch.int32).cpu().tolist()
-        return dict(overflow=st[0], pairs=st[1], active_tiles=st[2], it=st[3], n_seg=st[4])
+        return dict(overflow=st[0], big_triangles=st[1], active_tiles=st[2], it=st[3], n_seg=st[4])
 
     def check(self):
         st = self.status()
         if st["overflow"]:
-            raise RuntimeError(f"triangle bin list overflowed ({st['pairs']} pairs): re-create the engine with pairs_hint >= {2 * st['pairs']}")
+            raise RuntimeError("engine reported an internal overflow")
         return st
 
     def profile(self, it0=0, iters=5):

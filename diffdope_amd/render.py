@@ -39,20 +39,19 @@ def _i32c(t, name):
 
 
 class RasterizeContext:
-    """Stands in for dr.RasterizeGLContext() (diffdope.py:1312): owns the binning scratch (a torch
-    buffer, so the caching allocator sees it) and grows it if the bin list overflows."""
+    """Stands in for dr.RasterizeGLContext() (diffdope.py:1312): owns the rasteriser scratch (a torch
+    buffer, so the caching allocator sees it)."""
 
     def __init__(self, device=None):
         self.lib = _lib.load()
         self.device = device
         self._scratch = None
         self._key = None
-        self._pairs_hint = 0
 
     def scratch(self, B, V, T, H, W, device):
-        key = (B, V, T, H, W, self._pairs_hint, str(device))
+        key = (B, V, T, H, W, str(device))
         if self._key != key:
-            nbytes = self.lib.ddx_rasterize_scratch_bytes(B, V, T, H, W, self._pairs_hint)
+            nbytes = self.lib.ddx_rasterize_scratch_bytes(B, V, T, H, W)
             if nbytes == 0:
                 raise RuntimeError(f"rasterize: unsupported shape B={B} V={V} T={T} H={H} W={W} (H,W <= 4096)")
             self._scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
@@ -75,17 +74,9 @@ class _rasterize_func(torch.autograd.Function):
         B, V, T = pos.shape[0], pos.shape[1], tri.shape[0]
         lib = glctx.lib
         rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device)
-        status = torch.empty(4, dtype=torch.int32, device=pos.device)
-        for _ in range(3):
-            scratch, nbytes = glctx.scratch(B, V, T, H, W, pos.device)
-            _lib.check(lib.ddx_rasterize_fwd(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes,
-                                             _lib.ptr(rast), _lib.ptr(status), _lib.stream_ptr()), "ddx_rasterize_fwd")
-            st = status.cpu()
-            if int(st[0]) == 0:
-                break
-            glctx._pairs_hint = int(int(st[1]) * 1.25) + 1024  # bin list overflowed: grow and redo
-        else:
-            raise RuntimeError("rasterize: bin list overflow persists")
+        scratch, nbytes = glctx.scratch(B, V, T, H, W, pos.device)
+        _lib.check(lib.ddx_rasterize_fwd(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes,
+                                         _lib.ptr(rast), _lib.stream_ptr()), "ddx_rasterize_fwd")
         ctx.save_for_backward(pos, tri, rast)
         ctx.res = (H, W)
         rast_db = torch.zeros((1, 1, 1, 4), dtype=torch.float32, device=pos.device).expand(B, H, W, 4)

@@ -64,17 +64,14 @@ int ddx_xfm_bwd_full(const float* points, long long points_bstride, const float*
 
 /* ---------------------------------------------------------------------------------------------
  * rasterize: replaces dr.rasterize(glctx, pos, tri, resolution) at diffdope.py:198-200 and its
- * backward.  Software tile rasteriser: per-hypothesis 16x16-pixel tiles, wavefront-aggregated
- * triangle binning, LDS depth tile with 64-bit (depth,id) min.
+ * backward.  Software rasteriser: per-vertex 1/256-pixel snap, per-triangle scatter with a 64-bit
+ * (depth key, id) atomicMin for triangles of a few pixels, a tile pass for large ones (raster.hip).
  *   pos   [B,V,4] clip space;  tri [T,3];  rast [B,H,W,4] = (u, v, z/w, tri_id+1), 0 on background
- *   status: device int32[4] written by the call: [0]=1 if the bin buffer overflowed (result
- *           incomplete -> enlarge scratch via `pairs_hint`), [1]=number of (tile,triangle) pairs.
- * H, W <= 4096.  scratch_bytes(B,V,T,H,W,pairs_hint): pairs_hint = expected (tile,triangle) pairs in total, 0 => default
- * sizing of 4*B*T + 64*B*tiles.
+ * H, W <= 4096.  Scratch holds no lists, so it cannot overflow: size = ddx_rasterize_scratch_bytes.
  * ------------------------------------------------------------------------------------------- */
-size_t ddx_rasterize_scratch_bytes(int B, int V, int T, int H, int W, long long pairs_hint);
+size_t ddx_rasterize_scratch_bytes(int B, int V, int T, int H, int W);
 int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
-                      void* scratch, size_t scratch_bytes, float* rast, int32_t* status, void* stream);
+                      void* scratch, size_t scratch_bytes, float* rast, void* stream);
 /* drast [B,H,W,4] (channels 0,1 used) -> dpos [B,V,4], fully written (zeroed then accumulated). */
 int ddx_rasterize_bwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
                       const float* rast, const float* drast, float* dpos, void* stream);
@@ -162,14 +159,13 @@ typedef struct ddx_engine_buffers {
 
 typedef struct ddx_engine ddx_engine;
 
-size_t ddx_engine_scratch_bytes(const ddx_engine_desc* desc, long long pairs_hint);
+size_t ddx_engine_scratch_bytes(const ddx_engine_desc* desc);
 int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* bufs, ddx_engine** out);
 /* Run iterations [it0, it0+n) (rows of lr_sched / loss_log / mtx_log).  use_graph != 0 replays a
  * captured hipGraph of one iteration. */
 int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
-/* device int32[8] inside scratch: [0] sticky bin-overflow flag (results invalid: enlarge scratch),
- * [1] (tile,triangle) pairs of the last iteration, [2] active tiles of the last iteration,
- * [3] next iteration index, [4] pixels with seg != 0 */
+/* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
+ * iteration, [2] active tiles of the last iteration, [3] next iteration index, [4] pixels with seg != 0 */
 const int32_t* ddx_engine_status_ptr(ddx_engine* e);
 /* per-kernel launch durations of the last ddx_engine_profile call are returned in ms (host array
  * of `n_kernels`), measured with hipEvents on `stream`; returns the number of kernels. */

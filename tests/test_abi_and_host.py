@@ -28,10 +28,10 @@ def test_library_exports_every_declared_symbol():
     # argument validation works without a device: NULL pointers / bad shapes are rejected with a message
     assert lib.ddx_xfm_fwd(None, 0, None, 1, 1, 1, None, 0, None) == -1
     assert b"NULL" in lib.ddx_last_error()
-    assert lib.ddx_rasterize_scratch_bytes(0, 1, 1, 1, 1, 0) == 0
-    assert lib.ddx_rasterize_scratch_bytes(2, 60, 100, 48, 64, 0) > 2 * 48 * 64 * 4
+    assert lib.ddx_rasterize_scratch_bytes(0, 1, 1, 1, 1) == 0
+    assert lib.ddx_rasterize_scratch_bytes(2, 60, 100, 48, 64) > 2 * 48 * 64 * 8
     d = _lib.EngineDesc()
-    assert lib.ddx_engine_scratch_bytes(ctypes.byref(d), 0) == 0  # all-zero desc is invalid
+    assert lib.ddx_engine_scratch_bytes(ctypes.byref(d)) == 0  # all-zero desc is invalid
     assert ctypes.sizeof(_lib.EngineDesc) == 27 * 4 and ctypes.sizeof(_lib.EngineBuffers) == 17 * 8
 
 
