@@ -26,13 +26,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable c
 def algorithmic_bytes(V, T, HW, B):
     """SURVEY.md section 8(d), fp32/int32 'visibility-buffer model', bytes per LAUNCH (all B hypotheses)."""
     return {
-        "pose_xfm_kernel": (12.0 * V + 16.0 * V) * B + 156.0 * B,
+        "update_xfm_kernel": (12.0 * V + 16.0 * V) * B + 212.0 * B,  # xfm fwd row of 8(d) + the per-hypothesis update
         # raster row of 8(d): 16V r + 12T r + 16 HW w -- attributed to the four launches that make it up
         "raster_stage": (16.0 * V + 12.0 * T + 16.0 * HW) * B,
         # shade+loss fwd (16 HW r) + bwd (16 HW r + 32 V) + pose-grad contraction (28 V) are ONE kernel here;
         # the observed images (20 HW, read in fwd and bwd) are shared by all hypotheses
         "shade_kernel": (32.0 * HW + 60.0 * V) * B + 40.0 * HW,
-        "update_kernel": 28.0 * B * 2,
         "iteration": (104.0 * V + 12.0 * T + (48.0 + 40.0 / B) * HW) * B,
     }
 
@@ -150,8 +149,7 @@ def main():
         torch.cuda.synchronize()
         kms = eng2.profile(it0=min(args.warmup, n_it - 1), iters=max(1, min(20, n_it - args.warmup)))
         raster_ms = sum(kms[k] for k in ("scatter_kernel", "compact_big_kernel"))
-        groups = {"pose_xfm_kernel": kms["pose_xfm_kernel"], "raster_stage": raster_ms,
-                  "shade_kernel": kms["shade_kernel"], "update_kernel": kms["update_kernel"]}
+        groups = {"raster_stage": raster_ms, "shade_kernel": kms["shade_kernel"], "update_xfm_kernel": kms["update_xfm_kernel"]}
         dom = max(("shade_kernel", "scatter_kernel"), key=lambda k: kms[k])
         dom_bytes = alg["shade_kernel"] if dom == "shade_kernel" else alg["raster_stage"]
         achieved = dom_bytes / (kms[dom] * 1e-3) / 1e9

@@ -19,9 +19,11 @@
 //                  contracted with [pos;1] in registers (the xfm_bwd_mtx product, mesh.cu:165-214),
 //                  reduced per workgroup and written as one 24-float partial per tile: no atomics,
 //                  bit-reproducible.
-//   update_kernel  per hypothesis: fixed-order sum of its tile partials, whole-frame constants for the
+//   update_xfm_kernel  per hypothesis: fixed-order sum of its quadrant partials, whole-frame constants for the
 //                  pixels outside the active tiles, proj^T chain, quaternion chain, SGD/Adam step,
-//                  loss log (diffdope.py:558,576,604), iteration counter.
+//                  loss log (diffdope.py:558,576,604) -- and, with the new pose, the NEXT iteration's
+//                  matrices, clip-space vertices (MFMA) and window-coordinate snap, so an iteration is
+//                  4 launches: scatter, compact_big, shade, update_xfm.
 //
 // Whole-frame semantics without whole-frame work: a pixel outside every active tile renders
 // rgb = 0, mask = 0, depth = -mtx[2][3], so its loss terms are
@@ -38,11 +40,10 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int overflow;
     int last_pairs;
     int last_active;
-    int it;
+    int it;          // iteration index of the running iteration
     int n_seg;       // entries in the compact seg list
-    int ticket;      // update_kernel arrival counter (the last workgroup closes the iteration)
-    int active_acc;  // active tiles summed over the hypotheses of the running iteration
-    int pad[1];
+    int it_next;     // written by update_xfm_kernel (one lane), copied into `it` by the next shade_kernel (one lane)
+    int pad[2];
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
 };
@@ -160,51 +161,36 @@ __device__ __forceinline__ void quat_to_matrix(const float q[4], const float t[3
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// pose -> matrices -> clip-space vertices -> snapped window coordinates, one launch.
-// Every lane rebuilds its hypothesis' matrices from the 7 parameters (uniform scalar loads, ~150 flops:
-// cheaper than a separate launch + a dependent load), then transforms one vertex on the matrix core:
-// four v_mfma_f32_4x4x1_16b_f32 with A = row (lane%4) of final = proj . mtx and B = p[k]
-// (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain).
-__global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
+// q/|q| (diffdope.py:1091), [R|t] (diffdope.py:46-89) and final = proj . mtx (torch.matmul at :195, k-ordered fma)
+__device__ __forceinline__ void pose_matrices(float q[4], const float t[3], const float* proj, float M[16], float F[16])
 {
-    const int b = blockIdx.y, B = E.d.B, V = E.d.V;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    float q[4], t[3], M[16], F[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = E.b.params[(size_t)i * B + b];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = E.b.params[(size_t)(4 + i) * B + b];
     const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
     quat_to_matrix(q, t, M);
-    // final = proj . mtx  (torch.matmul at diffdope.py:195; k-ordered fma)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a = __fmaf_rn(E.b.proj[r * 4 + k], M[k * 4 + c], a);
+            for (int k = 0; k < 4; ++k) a = __fmaf_rn(proj[r * 4 + k], M[k * 4 + c], a);
             F[r * 4 + c] = a;
         }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float* dst = E.mats + (size_t)b * 32;
-        float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)E.st->it * B + b) * 16 : nullptr;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dst[i] = M[i];
-            dst[16 + i] = F[i];
-            if (logm) logm[i] = M[i];
-        }
-    }
+}
+
+// one vertex per lane on the matrix core: four v_mfma_f32_4x4x1_16b_f32 with A = row (lane%4) of final and
+// B = p[k] (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain), then the
+// 1/256-pixel window-coordinate snap.  Must be called by all 64 lanes of a wave.
+__device__ __forceinline__ void xfm_vertex(const EngineDev& E, const float F[16], int b, int n, int n_end, int lane)
+{
+    const int V = E.d.V;
     const int r = lane & 3;
     const float a0 = r == 0 ? F[0] : (r == 1 ? F[4] : (r == 2 ? F[8] : F[12]));
     const float a1 = r == 0 ? F[1] : (r == 1 ? F[5] : (r == 2 ? F[9] : F[13]));
     const float a2 = r == 0 ? F[2] : (r == 1 ? F[6] : (r == 2 ? F[10] : F[14]));
     const float a3 = r == 0 ? F[3] : (r == 1 ? F[7] : (r == 2 ? F[11] : F[15]));
-    const bool live = n < V;
+    const bool live = n < n_end;
     const float* p = E.b.pos + (size_t)(live ? n : 0) * 3;
     const float px = p[0], py = p[1], pz = p[2];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -215,6 +201,35 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
     if (!live) return;
     *reinterpret_cast<f32x4*>(E.clip + ((size_t)b * V + n) * 4) = acc;
     E.L.snap[(size_t)b * V + n] = snap_vertex(make_float4(acc.x, acc.y, acc.z, acc.w), E.d.H, E.d.W);
+}
+
+// pose -> matrices -> clip-space vertices -> snapped window coordinates for the FIRST iteration of a run
+// (later iterations get theirs from update_xfm_kernel).  Every lane rebuilds its hypothesis' matrices from
+// the 7 parameters (uniform scalar loads, ~150 flops: cheaper than a separate launch + a dependent load).
+__global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
+{
+    const int b = blockIdx.y, B = E.d.B, V = E.d.V;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float q[4], t[3], M[16], F[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = E.b.params[(size_t)i * B + b];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = E.b.params[(size_t)(4 + i) * B + b];
+    pose_matrices(q, t, E.b.proj, M, F);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int it = E.st->it;
+        if (b == 0) E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
+        float* dst = E.mats + (size_t)b * 32;
+        float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dst[i] = M[i];
+            dst[16 + i] = F[i];
+            if (logm) logm[i] = M[i];
+        }
+    }
+    xfm_vertex(E, F, b, n, V, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -268,17 +283,19 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W, V = d.V;
     const RasterScratch& L = E.L;
-    extern __shared__ __attribute__((aligned(16))) int s_prefix[];  // [B+1] exclusive scan of the per-hypothesis counts
-    __shared__ int s_wsum[4];
     const float* __restrict__ pos = E.b.pos;
     const int* __restrict__ tri = E.b.tri;
     int* ids = s_ids[wave];
-    const int n_active = work_prefix(L.b_count, d.B, s_prefix, s_wsum);
-    for (int work = blockIdx.x; work < n_active; work += gridDim.x) {
-        const int b = work_lookup(s_prefix, d.B, work);
-        const int tile = L.active[(size_t)b * L.NT + (work - s_prefix[b])];
-        const int flat = b * L.NT + tile;
-        const int qx = (tile % L.ntx) * DDX_TILE + (wave & 1) * QUAD, qy = (tile / L.ntx) * DDX_TILE + (wave >> 1) * QUAD;
+    // grid (S, B): workgroup (s, b) takes tiles s, s+S, ... of hypothesis b's ordered active list -- no
+    // prefix over hypotheses, no global list, workgroups beyond the count leave after one scalar load
+    const int b = blockIdx.y;
+    if (blockIdx.x == 0 && b == 0 && tid == 0) E.st->it = E.st->it_next;  // see update_xfm_kernel
+    const int n_tiles = L.b_count[b];
+    for (int k = blockIdx.x; k < n_tiles; k += gridDim.x) {
+        const int txy = L.active[(size_t)b * L.NT + k];
+        const int tcx = txy & 0xffff, tcy = txy >> 16;
+        const int flat = b * L.NT + tcy * L.ntx + tcx;
+        const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
         const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
         float* part = E.partials + ((size_t)flat * WAVES_PER_TILE + wave) * NPART;
@@ -516,15 +533,26 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void update_kernel(EngineDev E)
+// update + next iteration's transform, one launch: grid (UPD_SLICES, B).
+// Every workgroup of hypothesis b redundantly reduces b's quadrant partials (a few KB from L2, fixed order),
+// runs the proj^T / quaternion chain and the optimiser step in LDS, and then transforms ITS slice of the
+// vertices with the NEW pose on the matrix core (as pose_xfm_kernel), so the next iteration starts at the
+// rasteriser.  Slice 0 also writes parameters, optimiser state and logs; the zbuf / tile-flag re-arm is split
+// over the slices.
+#define UPD_SLICES 4
+
+__global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 {
     const ddx_engine_desc& d = E.d;
-    const int b = blockIdx.x, B = d.B;
+    const int b = blockIdx.y, B = d.B, slice = blockIdx.x, V = d.V;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float red[4][NPART];
     __shared__ float sums[NPART];
     __shared__ float sc[64];      // scalars the tail needs, fetched in parallel
-    __shared__ int s_tiles[256];
+    __shared__ float snew[8];     // updated parameters
+    __shared__ float sG[16];
+    __shared__ float sgrad[8];
+    __shared__ int s_tiles[256], s_tidx[256];
     const int it = E.st->it;
     const int NT = E.L.NT;
     // ---- parallel prefetch: params 0..6, lr_mult 7, lr 8, m23 9, proj 16..31, adam 32..45
@@ -535,8 +563,8 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
     else if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
     else if (tid >= 32 && tid < 46) sc[tid] = E.adam[(size_t)(tid - 32) * B + b];
     // ---- this hypothesis' active tiles come ordered by tile index (compact_big_kernel): sum their quadrant
-    // partials in that fixed order (bit-reproducible) and re-arm what the iteration dirtied (zbuf of the
-    // active tiles, their flags) so that the next iteration needs no memset.
+    // partials in that fixed order (bit-reproducible); re-arm what the iteration dirtied (zbuf of the active
+    // tiles, their flags) so that the next iteration needs no memset -- tile k is re-armed by slice k % UPD_SLICES.
     const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < 19 of group g sums value j
     float acc = 0.f;
     const int n_act = E.L.b_count[b];
@@ -544,20 +572,24 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
     for (int start = 0; start < n_act; start += 256) {
         __syncthreads();
         if (start + tid < n_act) {
-            const int tile = tiles[start + tid];
-            s_tiles[tid] = tile;
-            E.L.tile_flag[(size_t)b * NT + tile] = 0;
-            E.L.tile_big[(size_t)b * NT + tile] = 0;
+            const int txy = tiles[start + tid];
+            const int tile = (txy >> 16) * E.L.ntx + (txy & 0xffff);
+            s_tiles[tid] = txy;
+            s_tidx[tid] = tile;
+            if (((start + tid) % UPD_SLICES) == slice) {
+                E.L.tile_flag[(size_t)b * NT + tile] = 0;
+                E.L.tile_big[(size_t)b * NT + tile] = 0;
+            }
         }
         __syncthreads();
         const int na = min(256, n_act - start);
         if (j < 19)
             for (int s = grp; s < na * 4; s += 8)
-                acc += E.partials[((size_t)(b * NT + s_tiles[s >> 2]) * 4 + (s & 3)) * NPART + j];
+                acc += E.partials[((size_t)(b * NT + s_tidx[s >> 2]) * 4 + (s & 3)) * NPART + j];
         const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
-        for (int s = 0; s < na; ++s) {
-            const int tile = s_tiles[s];
-            const int px = (tile % E.L.ntx) * DDX_TILE + lx, py = (tile / E.L.ntx) * DDX_TILE + ly;
+        for (int s = slice; s < na; s += UPD_SLICES) {  // (start is a multiple of 256, hence of UPD_SLICES)
+            const int txy = s_tiles[s];
+            const int px = (txy & 0xffff) * DDX_TILE + lx, py = (txy >> 16) * DDX_TILE + ly;
             if (px < d.W && py < d.H) E.L.zbuf[((size_t)b * d.H + py) * d.W + px] = ~0ull;
         }
     }
@@ -586,94 +618,139 @@ __global__ __launch_bounds__(256) void update_kernel(EngineDev E)
         bgsum = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         bgder = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
-    if (tid != 0) return;
-    const float npx = (float)d.H * (float)d.W;
-    const float lrb = sc[7];
-    // ---- loss log: weighted, not LR-scaled (diffdope.py:558-560,576-578,604-608)
-    if (E.b.loss_log) {
-        float* lg = E.b.loss_log + (size_t)it * 3 * B;
-        lg[0 * B + b] = d.use_rgb ? d.w_rgb * (float)((E.st->c_rgb + (double)sums[16]) / (3.0 * (double)npx)) : 0.f;
-        lg[1 * B + b] = d.use_depth ? d.w_depth * (float)(((double)bgsum + (double)sums[17]) / (double)npx) : 0.f;
-        lg[2 * B + b] = d.use_mask ? d.w_mask * (float)((E.st->c_mask + (double)sums[18]) / (3.0 * (double)npx)) : 0.f;
-    }
-    // ---- d loss / d mtx = proj^T . dFinal (+ direct depth row)
-    float dFin[16];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { dFin[0 + c] = sums[c]; dFin[4 + c] = sums[4 + c]; dFin[8 + c] = 0.f; dFin[12 + c] = sums[8 + c]; }
-    float G[16];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+    // ---- tail on wave 0, one lane per output where the work allows
+    const bool writer = slice == 0;
+    if (wave == 0) {
+        const float npx = (float)d.H * (float)d.W;
+        const float lrb = sc[7];
+        // loss log: weighted, not LR-scaled (diffdope.py:558-560,576-578,604-608)
+        if (writer && lane < 3 && E.b.loss_log) {
+            float v = 0.f;
+            if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
+            if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
+            if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
+            E.b.loss_log[((size_t)it * 3 + lane) * B + b] = v;
+        }
+        // d loss / d mtx = proj^T . dFinal (+ direct depth row): lane = k*4 + j
+        if (lane < 16) {
+            const int k = lane >> 2, jj = lane & 3;
             float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a = __fmaf_rn(sc[16 + i * 4 + k], dFin[i * 4 + j], a);
-            G[k * 4 + j] = a;
+            a = __fmaf_rn(sc[16 + 0 * 4 + k], sums[0 + jj], a);   // dFinal row x
+            a = __fmaf_rn(sc[16 + 1 * 4 + k], sums[4 + jj], a);   // row y
+            a = __fmaf_rn(sc[16 + 3 * 4 + k], sums[8 + jj], a);   // row w (row z carries no gradient)
+            if (d.use_depth && k == 2) {
+                a += sums[12 + jj];
+                if (jj == 3) a += -(d.w_depth * lrb / ((float)d.B_global * npx)) * bgder;  // whole-frame background term (depth_bg = -m23)
+            }
+            sG[lane] = a;
         }
-    if (d.use_depth) {
-        const float kd = d.w_depth * lrb / ((float)d.B_global * npx);
+        wave_lds_sync();
+        if (lane == 0) {
+            // quaternion chain (the reverse of diffdope.py:57-80 and :1091)
+            const float* G = sG;
+            const float nq = sqrtf(sc[0] * sc[0] + sc[1] * sc[1] + sc[2] * sc[2] + sc[3] * sc[3]);
+            const float x = sc[0] / nq, y = sc[1] / nq, z = sc[2] / nq, w = sc[3] / nq;
+            const float gx = G[1] * 2 * y + G[2] * 2 * z + G[4] * 2 * y + G[5] * (-4 * x) + G[6] * (-2 * w) + G[8] * 2 * z + G[9] * 2 * w + G[10] * (-4 * x);
+            const float gy = G[0] * (-4 * y) + G[1] * 2 * x + G[2] * 2 * w + G[4] * 2 * x + G[6] * 2 * z + G[8] * (-2 * w) + G[9] * 2 * z + G[10] * (-4 * y);
+            const float gz = G[0] * (-4 * z) + G[1] * (-2 * w) + G[2] * 2 * x + G[4] * 2 * w + G[5] * (-4 * z) + G[6] * 2 * y + G[8] * 2 * x + G[9] * 2 * y;
+            const float gw = G[1] * (-2 * z) + G[2] * 2 * y + G[4] * 2 * z + G[6] * (-2 * x) + G[8] * (-2 * y) + G[9] * 2 * x;
+            const float dot = gx * x + gy * y + gz * z + gw * w;
+            sgrad[0] = (gx - x * dot) / nq; sgrad[1] = (gy - y * dot) / nq; sgrad[2] = (gz - z * dot) / nq; sgrad[3] = (gw - w * dot) / nq;
+            sgrad[4] = G[3]; sgrad[5] = G[7]; sgrad[6] = G[11];
+        }
+        wave_lds_sync();
+        // optimiser step: lane = parameter
+        if (lane < 7) {
+            const float g = sgrad[lane], lr = sc[8];
+            float pnew;
+            if (d.optimizer == 0) {
+                pnew = sc[lane] - lr * g;
+            } else {
+                const float b1 = d.adam_beta1, b2 = d.adam_beta2;
+                const float c1 = 1.f - exp2f((float)(it + 1) * log2f(b1)), c2 = 1.f - exp2f((float)(it + 1) * log2f(b2));
+                const float m1 = b1 * sc[32 + lane] + (1.f - b1) * g;
+                const float m2 = b2 * sc[39 + lane] + (1.f - b2) * g * g;
+                if (writer) {
+                    E.adam[(size_t)lane * B + b] = m1;
+                    E.adam[(size_t)(7 + lane) * B + b] = m2;
+                }
+                pnew = sc[lane] - lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
+            }
+            snew[lane] = pnew;
+            if (writer) E.b.params[(size_t)lane * B + b] = pnew;
+        }
+        if (writer && b == 0) {
+            // iteration bookkeeping without atomics (kernel boundaries order these single-lane updates):
+            // shade_kernel of the next iteration copies it_next into `it`, which this kernel reads.
+            int tot = 0;
+            for (int i = lane; i < B; i += 64) tot += E.L.b_count[i];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) G[8 + c] += sums[12 + c];
-        G[11] += -kd * bgder;  // d/d m23 of the whole-frame background term (depth_bg = -m23)
-    }
-    // ---- quaternion chain (the reverse of diffdope.py:57-80 and :1091)
-    float qr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) qr[i] = sc[i];
-    const float nq = sqrtf(qr[0] * qr[0] + qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3]);
-    const float x = qr[0] / nq, y = qr[1] / nq, z = qr[2] / nq, w = qr[3] / nq;
-    const float gx = G[1] * 2 * y + G[2] * 2 * z + G[4] * 2 * y + G[5] * (-4 * x) + G[6] * (-2 * w) + G[8] * 2 * z + G[9] * 2 * w + G[10] * (-4 * x);
-    const float gy = G[0] * (-4 * y) + G[1] * 2 * x + G[2] * 2 * w + G[4] * 2 * x + G[6] * 2 * z + G[8] * (-2 * w) + G[9] * 2 * z + G[10] * (-4 * y);
-    const float gz = G[0] * (-4 * z) + G[1] * (-2 * w) + G[2] * 2 * x + G[4] * 2 * w + G[5] * (-4 * z) + G[6] * 2 * y + G[8] * 2 * x + G[9] * 2 * y;
-    const float gw = G[1] * (-2 * z) + G[2] * 2 * y + G[4] * 2 * z + G[6] * (-2 * x) + G[8] * (-2 * y) + G[9] * 2 * x;
-    const float dot = gx * x + gy * y + gz * z + gw * w;
-    float grad[7] = {(gx - x * dot) / nq, (gy - y * dot) / nq, (gz - z * dot) / nq, (gw - w * dot) / nq, G[3], G[7], G[11]};
-    // ---- optimiser step
-    const float lr = sc[8];
-    if (d.optimizer == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) E.b.params[(size_t)i * B + b] = sc[i] - lr * grad[i];
-    } else {
-        const float b1 = d.adam_beta1, b2 = d.adam_beta2;
-        const float c1 = 1.f - powf(b1, (float)(it + 1)), c2 = 1.f - powf(b2, (float)(it + 1));
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const float m1 = b1 * sc[32 + i] + (1.f - b1) * grad[i];
-            const float m2 = b2 * sc[39 + i] + (1.f - b2) * grad[i] * grad[i];
-            E.adam[(size_t)i * B + b] = m1;
-            E.adam[(size_t)(7 + i) * B + b] = m2;
-            E.b.params[(size_t)i * B + b] = sc[i] - lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            if (lane == 0) {
+                E.st->last_active = tot;
+                E.st->last_pairs = E.L.counters[3];
+                E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
+                E.st->it_next = it + 1;
+            }
         }
     }
-    // the last workgroup to arrive closes the iteration: every other one has already read `it`
-    atomicAdd(&E.st->active_acc, n_act);
-    __threadfence();
-    if (atomicAdd(&E.st->ticket, 1) == B - 1) {
-        E.st->last_pairs = E.L.counters[3];  // large triangles of this iteration
-        E.st->last_active = atomicExch(&E.st->active_acc, 0);
-        E.L.counters[3] = 0;
-        E.st->ticket = 0;
-        E.st->it = it + 1;
+    __syncthreads();
+    // ---- transform this slice of the vertices with the NEW pose (next iteration's pose_xfm)
+    float q[4], t[3], M[16], F[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = snew[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = snew[4 + i];
+    pose_matrices(q, t, sc + 16, M, F);
+    if (writer && tid == 0) {
+        float* dst = E.mats + (size_t)b * 32;
+        float* logm = (E.b.mtx_log && it + 1 < d.max_iters) ? E.b.mtx_log + ((size_t)(it + 1) * B + b) * 16 : nullptr;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            dst[i] = M[i];
+            dst[16 + i] = F[i];
+            if (logm) logm[i] = M[i];
+        }
     }
+    const int per = (V + UPD_SLICES - 1) / UPD_SLICES;
+    const int n_begin = slice * per, n_end = min(V, n_begin + per);
+    for (int n0 = n_begin; n0 < n_end; n0 += 256) xfm_vertex(E, F, b, n0 + tid, n_end, lane);
 }
 
-__global__ void set_it_kernel(EngineState* st, int it) { st->it = it; }
+__global__ void set_it_kernel(EngineState* st, int it) { st->it = it; st->it_next = it; }
 
 // ---------------------------------------------------------------------------------------------
-enum { K_XFM, K_SCATTER, K_RASTER_BIG, K_SHADE, K_UPDATE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"pose_xfm_kernel", "scatter_kernel", "compact_big_kernel", "shade_kernel", "update_kernel"};
+enum { K_SCATTER, K_COMPACT_BIG, K_SHADE, K_UPDATE, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"scatter_kernel", "compact_big_kernel", "shade_kernel", "update_xfm_kernel"};
+
+// shading grid (S, B): enough x-slices that a hypothesis' active tiles (a few dozen) get one workgroup each
+static dim3 shade_grid(const ddx_engine_desc& d)
+{
+    int S = RASTER_GRID / d.B;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    return dim3(S, d.B);
+}
+
+// first iteration of a run: pose -> clip/snap (later iterations inherit them from update_xfm_kernel)
+static int run_prologue(ddx_engine* e, int it0, hipStream_t s)
+{
+    EngineDev& E = e->dev;
+    set_it_kernel<<<1, 1, 0, s>>>(E.st, it0);
+    pose_xfm_kernel<<<dim3(ddx_cdiv(E.d.V, 256), E.d.B), 256, 0, s>>>(E);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
 
 static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
 {
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
-    if (ev) DDX_HIP(hipEventRecord(ev[K_XFM], s));
-    pose_xfm_kernel<<<dim3(ddx_cdiv(d.V, 256), d.B), 256, 0, s>>>(E);
     if (int err = raster_run(E.clip, E.b.tri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_SCATTER : nullptr)) return err;
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
-    shade_kernel<<<RASTER_GRID, 256, (size_t)(d.B + 1) * sizeof(int), s>>>(E);
+    shade_kernel<<<shade_grid(d), 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
-    update_kernel<<<d.B, 256, 0, s>>>(E);
+    update_xfm_kernel<<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
     DDX_LAUNCH_CHECK();
     return 0;
@@ -725,8 +802,8 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     EngineDev& E = e->dev;
     DDX_HIP(hipMemsetAsync(E.st, 0, sizeof(EngineState), s));
     DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)14 * E.d.B * sizeof(float), s));
-    DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // kept zero by update_kernel afterwards
-    DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_kernel
+    DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // kept zero by update_xfm_kernel afterwards
+    DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
     e->setup_done = true;
@@ -741,7 +818,8 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
     hipStream_t s = (hipStream_t)stream;
     if (!e->setup_done)
         if (int err = engine_setup(e, s)) return err;
-    set_it_kernel<<<1, 1, 0, s>>>(e->dev.st, it0);
+    if (n == 0) return 0;
+    if (int err = run_prologue(e, it0, s)) return err;
     if (use_graph && !e->exec) {
         hipStream_t cs;
         DDX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -775,7 +853,7 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     hipStream_t s = (hipStream_t)stream;
     if (!e->setup_done)
         if (int err = engine_setup(e, s)) return err;
-    set_it_kernel<<<1, 1, 0, s>>>(e->dev.st, it0);
+    if (int err = run_prologue(e, it0, s)) return err;
     hipEvent_t ev[K_COUNT + 1];
     for (auto& x : ev) DDX_HIP(hipEventCreate(&x));
     for (int k = 0; k < K_COUNT; ++k) ms_out[k] = 0.f;

@@ -11,7 +11,7 @@ struct RasterScratch {
     int* counters;            // [16]: 3 = large triangles of this pass
     int* tile_flag;           // [B,NT] != 0: tile holds or borders a possibly covered pixel (plain stores of 1)
     int* tile_big;            // [B,NT] != 0: a large triangle overlaps the tile
-    int* active;              // [B,NT] per-hypothesis ordered list of active tile ids (first b_count[b] entries)
+    int* active;              // [B,NT] per-hypothesis ordered list of active tiles, packed ty << 16 | tx (first b_count[b] entries)
     int* b_count;             // [B] active tiles of each hypothesis
     int2* snap;               // [B,V] window coordinates in 1/256 px (x = INT_MIN if w <= 0)
     unsigned* trirange;       // [B,T] packed tile range of a LARGE triangle: tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24; ~0u otherwise

@@ -96,7 +96,7 @@ class RefineEngine:
         self.it = it
 
     def status(self):
-        """dict(overflow (always 0), big_triangles, active_tiles, it, n_seg) -- synchronises."""
+        """dict(overflow (always 0), big_triangles (0/1: the tile pass ran), active_tiles, it, n_seg) -- synchronises."""
         p = self.lib.ddx_engine_status_ptr(self.handle)
         off = p - self.scratch.data_ptr()
         st = self.scratch[off:off + 32].view(torch.int32).cpu().tolist()
