@@ -16,3 +16,18 @@ from .render import (  # noqa: F401
 )
 from .engine import RefineEngine  # noqa: F401
 from .pose import matrix_batch_44_from_position_quat  # noqa: F401
+from .api import (  # noqa: F401
+    Camera,
+    Cfg,
+    DiffDope,
+    Image,
+    Mesh,
+    Object3D,
+    Scene,
+    dist_batch_lr,
+    l1_depth_with_mask,
+    l1_mask,
+    l1_rgb_with_mask,
+    load_config,
+    opencv_2_opengl,
+)

@@ -1,0 +1,599 @@
+"""The diff-dope Python API (diffdope/diffdope.py) on top of the MI355X engine: same class names,
+constructor arguments, attributes and tensor layouts -- Camera, Mesh, Object3D, Image, Scene, DiffDope,
+the loss functions and pose helpers -- without trimesh / cv2 / pyrr / hydra / nvdiffrast.
+
+What differs on purpose ("Logging semantics"):
+  * `set_batchsize` makes stride-0 batch VIEWS (`expand`) instead of B physical copies of the mesh,
+    texture and images (diffdope.py:875-893,1176); shapes are unchanged;
+  * `run_optimization` takes the fused engine when every loss function is a built-in one (a single
+    hipGraph-replayed launch chain per iteration, no per-iteration device->host copies); any user loss
+    function switches to the op-by-op autograd path, which behaves like the reference's loop;
+  * `optimization_results[i]` always holds "mtx"; "rgb"/"depth"/"mask" are rendered on first access from
+    the stored pose instead of being copied to the host every iteration (diffdope.py:1698-1703).
+"""
+import logging
+import math
+import random
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import io_img, io_ply
+from . import ops as dd_ops
+from .engine import RefineEngine
+from .pose import matrix_batch_44_from_position_quat
+from .render import RasterizeGLContext, render_texture_batch
+
+log = logging.getLogger(__name__)
+
+
+# ------------------------------------------------------------------------------------------------
+# config: any attribute/item mapping with the keys of configs/diffdope.yaml works; this one needs no hydra
+class Cfg(dict):
+    """dict with attribute access, usable as `**cfg.camera` like an omegaconf DictConfig."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def wrap(obj):
+        if isinstance(obj, dict):
+            return Cfg({k: Cfg.wrap(v) for k, v in obj.items()})
+        if isinstance(obj, (list, tuple)):
+            return [Cfg.wrap(v) for v in obj]
+        return obj
+
+
+def load_config(path):
+    """Read a diffdope.yaml (configs/diffdope.yaml layout) into a Cfg."""
+    import yaml
+
+    with open(path) as f:
+        return Cfg.wrap(yaml.safe_load(f))
+
+
+# ------------------------------------------------------------------------------------------------
+# pose helpers (diffdope.py:92-140 without pyrr)
+def quat_from_matrix(m):
+    """xyzw quaternion of a 3x3 rotation matrix (column-vector convention, what pyrr.Matrix33(m).quaternion gives)."""
+    m = np.asarray(m, np.float64).reshape(3, 3)
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s = 0.5 / math.sqrt(tr + 1.0)
+        q = [(m[2, 1] - m[1, 2]) * s, (m[0, 2] - m[2, 0]) * s, (m[1, 0] - m[0, 1]) * s, 0.25 / s]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = 2.0 * math.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2])
+        q = [0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s]
+    elif m[1, 1] > m[2, 2]:
+        s = 2.0 * math.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2])
+        q = [(m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s]
+    else:
+        s = 2.0 * math.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1])
+        q = [(m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s]
+    q = np.array(q, np.float64)
+    return q / np.linalg.norm(q)
+
+
+def matrix_from_quat(q):
+    x, y, z, w = np.asarray(q, np.float64) / np.linalg.norm(q)
+    return np.array([
+        [1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w],
+        [2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w],
+        [2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y],
+    ])
+
+
+def opencv_2_opengl(p, q):
+    """OpenCV camera frame -> OpenGL camera frame (diffdope.py:92-140): [R|t] -> diag(1,-1,-1) [R|t].
+    The reference's trailing "legacy" quaternion product Rz(90) Ry(-90) Rz(-90) Rx(-90) is the identity
+    (checked numerically), so it is not reproduced.  q is xyzw; returns (p', q')."""
+    flip = np.diag([1.0, -1.0, -1.0])
+    R = flip @ matrix_from_quat(q)
+    return flip @ np.asarray(p, np.float64), quat_from_matrix(R)
+
+
+# ------------------------------------------------------------------------------------------------
+# losses (diffdope.py:534-613): f(ddope) -> scalar, reading ddope.renders / gt_tensors / learning_rates / cfg
+def dist_batch_lr(tensor, learning_rates, channels=[1, 2, 3]):
+    return torch.mean(tensor, channels) * learning_rates
+
+
+def l1_rgb_with_mask(ddope):
+    diff_rgb = torch.abs((ddope.renders["rgb"] - ddope.gt_tensors["rgb"]) * ddope.gt_tensors["segmentation"])
+    lr_diff_rgb = dist_batch_lr(diff_rgb, ddope.learning_rates)
+    ddope.add_loss_value("rgb", torch.mean(diff_rgb.detach(), (1, 2, 3)) * ddope.cfg.losses.weight_rgb)
+    return lr_diff_rgb.mean() * ddope.cfg.losses.weight_rgb
+
+
+def l1_depth_with_mask(ddope):
+    diff_depth = torch.abs((ddope.renders["depth"] - ddope.gt_tensors["depth"]) * ddope.gt_tensors["segmentation"][..., 0])
+    lr_diff_depth = dist_batch_lr(diff_depth, ddope.learning_rates, [1, 2])
+    ddope.add_loss_value("depth", torch.mean(diff_depth.detach(), (1, 2)) * ddope.cfg.losses.weight_depth)
+    return lr_diff_depth.mean() * ddope.cfg.losses.weight_depth
+
+
+def l1_mask(ddope):
+    mask = ddope.renders["mask"]
+    diff_mask = torch.abs(mask - ddope.gt_tensors["segmentation"])
+    lr_diff_mask = dist_batch_lr(diff_mask, ddope.learning_rates)
+    ddope.add_loss_value("mask_selection", torch.mean(torch.abs(diff_mask.detach()), (1, 2, 3)) * ddope.cfg.losses.weight_mask)
+    return lr_diff_mask.mean() * ddope.cfg.losses.weight_mask
+
+
+_BUILTIN_LOSSES = {l1_rgb_with_mask: "rgb", l1_depth_with_mask: "depth", l1_mask: "mask"}
+_LOG_KEYS = {"rgb": "rgb", "depth": "depth", "mask": "mask_selection"}
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Camera:
+    """Intrinsics -> OpenGL projection (diffdope.py:621-742)."""
+
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    im_width: int
+    im_height: int
+    znear: Optional[float] = 0.01
+    zfar: Optional[float] = 200
+
+    def __post_init__(self):
+        self.cam_proj = self.get_projection_matrix()
+
+    def set_batchsize(self, batchsize):
+        base = self.cam_proj if self.cam_proj.dim() == 2 else self.cam_proj[0]
+        self.cam_proj = base[None].expand(batchsize, 4, 4)
+
+    def cuda(self):
+        self.cam_proj = self.cam_proj.cuda().float()
+
+    def resize(self, percentage):
+        self.fx *= percentage
+        self.fy *= percentage
+        self.cx = (int)(percentage * self.cx)
+        self.cy = (int)(percentage * self.cy)
+        self.im_width = (int)(percentage * self.im_width)
+        self.im_height = (int)(percentage * self.im_height)
+
+    def get_projection_matrix(self):
+        """'y_down' window convention of diffdope.py:726-740."""
+        w, h, nc, fc = self.im_width, self.im_height, self.znear, self.zfar
+        depth = float(fc - nc)
+        q = -(fc + nc) / depth
+        qn = -2 * (fc * nc) / depth
+        proj = np.array([
+            [2 * self.fx / w, -2 * 0 / w, (-2 * self.cx + w) / w, 0],
+            [0, 2 * self.fy / h, (2 * self.cy - h) / h, 0],
+            [0, 0, q, qn],
+            [0, 0, -1, 0],
+        ])
+        return torch.tensor(proj)
+
+
+class Mesh(torch.nn.Module):
+    """Mesh tensors for the renderer (diffdope.py:746-935).  `path_model` is a PLY file (with
+    `texture_u/texture_v` + `comment TextureFile` for a textured model, or per-vertex colours); or build one
+    from arrays with Mesh.from_arrays."""
+
+    def __init__(self, path_model=None, scale=1, _arrays=None):
+        super().__init__()
+        self.path_model = path_model
+        self.to_process = ["pos", "pos_idx", "vtx_color", "tex", "uv", "uv_idx", "vtx_normals"]
+        if _arrays is None:
+            m = io_ply.read_ply(path_model)
+            tex = None
+            if m["uv"] is not None and m["texture_file"] is not None:
+                from PIL import Image as PILImage
+
+                tex = np.asarray(PILImage.open(m["texture_file"]).convert("RGB")).astype(np.float64) / 255.0
+            colors = None if m["colors"] is None else m["colors"].astype(np.float64) / 255.0
+            _arrays = dict(pos=m["pos"], faces=m["faces"], normals=m["normals"], uv=m["uv"], tex=tex, colors=colors)
+        a = _arrays
+        pos_idx = torch.from_numpy(np.ascontiguousarray(a["faces"]).astype(np.int32))
+        vtx_pos = torch.from_numpy(np.ascontiguousarray(a["pos"]).astype(np.float32)) * scale
+        normals = a.get("normals")
+        if normals is None:
+            normals = io_ply.vertex_normals(np.asarray(a["pos"], np.float64), np.asarray(a["faces"]))
+        self.pos_idx = pos_idx
+        self.pos = vtx_pos
+        self.vtx_normals = torch.from_numpy(np.ascontiguousarray(normals).astype(np.float32))
+        lo, hi = vtx_pos.min(0).values, vtx_pos.max(0).values
+        self.bounding_volume = [[lo[0], lo[1], lo[2]], [hi[0], hi[1], hi[2]]]
+        self.dimensions = [hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]]
+        self.center_point = [((lo[i] + hi[i]) / 2).item() for i in range(3)]
+        if a.get("tex") is not None and a.get("uv") is not None:
+            uv = np.array(a["uv"], np.float32, copy=True)
+            if a.get("flip_v", True):
+                uv[:, 1] = 1 - uv[:, 1]  # diffdope.py:822
+            self.tex = torch.from_numpy(np.ascontiguousarray(a["tex"]).astype(np.float32))
+            self.uv = torch.from_numpy(uv)
+            self.uv_idx = pos_idx.clone()
+            self.has_textured_map = True
+        else:
+            col = a.get("colors")
+            if col is None:
+                col = np.full((vtx_pos.shape[0], 3), 0.5)
+            self.vtx_color = torch.from_numpy(np.ascontiguousarray(col).astype(np.float32))
+            self.has_textured_map = False
+        log.info(f"loaded mesh @{self.path_model}. Does it have texture map? {self.has_textured_map} ")
+        self._batchsize_set = False
+
+    @classmethod
+    def from_arrays(cls, pos, faces, uv=None, tex=None, vtx_color=None, normals=None, scale=1, flip_v=False):
+        """Mesh from numpy arrays (pos [V,3], faces [T,3], and uv [V,2] + tex [Th,Tw,3] or vtx_color [V,3] in 0..1).
+        flip_v=False: uv is already in the renderer's convention."""
+        return cls(None, scale, _arrays=dict(pos=pos, faces=faces, uv=uv, tex=tex, colors=vtx_color, normals=normals, flip_v=flip_v))
+
+    def __str__(self):
+        return f"mesh @{self.path_model}. vtx:{self.pos.shape} on {self.pos.device}"
+
+    __repr__ = __str__
+
+    def set_batchsize(self, batchsize):
+        """Batch VIEWS of every array in `to_process` ([B,...], stride 0 on the batch axis)."""
+        for key in list(vars(self).keys()):
+            if key not in self.to_process:
+                continue
+            v = vars(self)[key]
+            base = v[0] if self._batchsize_set else v
+            vars(self)[key] = base[None].expand(batchsize, *base.shape)
+        self._batchsize_set = True
+
+    def cuda(self):
+        super().cuda()
+        for key in list(vars(self).keys()):
+            if key in self.to_process:
+                vars(self)[key] = vars(self)[key].cuda()
+
+    def enable_gradients_texture(self):
+        if self.has_textured_map:
+            self.tex = torch.nn.Parameter(self.tex.contiguous(), requires_grad=True).to(self.tex.device)
+        else:
+            self.vtx_color = torch.nn.Parameter(self.vtx_color.contiguous(), requires_grad=True).to(self.vtx_color.device)
+
+    def forward(self):
+        return {key: vars(self)[key] for key in vars(self) if key in self.to_process}
+
+
+class Object3D(torch.nn.Module):
+    """The 7 pose parameters, each an nn.Parameter of shape [B] (diffdope.py:938-1098)."""
+
+    def __init__(self, position, rotation, batchsize=32, opencv2opengl=True, model_path=None, scale=1, mesh=None):
+        super().__init__()
+        self.qx = None
+        self.mesh = mesh if mesh is not None else (None if model_path is None else Mesh(path_model=model_path, scale=scale))
+        self.set_pose(position, rotation, batchsize, scale=scale, opencv2opengl=opencv2opengl)
+
+    def _make_params(self, batchsize, rotation, position):
+        for name, val in zip(("qx", "qy", "qz", "qw"), rotation):
+            setattr(self, name, torch.nn.Parameter(torch.ones(batchsize) * float(val)))
+        for name, val in zip(("x", "y", "z"), position):
+            setattr(self, name, torch.nn.Parameter(torch.ones(batchsize) * float(val)))
+
+    def set_pose(self, position, rotation, batchsize=32, opencv2opengl=True, scale=1):
+        assert len(position) == 3
+        position = np.array(position, np.float64) * scale
+        rotation = np.asarray(rotation, np.float64)
+        assert rotation.size in (4, 9)
+        rotation = rotation.reshape(-1) if rotation.size == 4 else quat_from_matrix(rotation)
+        if opencv2opengl:
+            position, rotation = opencv_2_opengl(position, rotation)
+        log.info(f"translation loaded: {position}")
+        log.info(f"rotation loaded as quaternion: {rotation}")
+        self._position, self._rotation = position, rotation
+        device = "cpu" if self.qx is None else self.qx.device
+        self._make_params(batchsize, rotation, position)
+        self.to(device)
+        if self.mesh is not None and torch.cuda.is_available():
+            self.mesh.cuda()
+
+    def set_batchsize(self, batchsize):
+        device = self.qx.device
+        self._make_params(batchsize, self._rotation, self._position)
+        self.to(device)
+        if self.mesh is not None:
+            self.mesh.set_batchsize(batchsize=batchsize)
+            if torch.cuda.is_available():
+                self.mesh.cuda()
+
+    def __repr__(self):
+        return f"Object3D( \n (pos): {self.x.shape} ,[0]:[{self.x[0].item(), self.y[0].item(), self.z[0].item()}] on {self.x.device}\n (mesh): {self.mesh} \n)"
+
+    def cuda(self):
+        super().cuda()
+        if self.mesh is not None:
+            self.mesh.cuda()
+
+    def reset_pose(self):
+        device = self.qx.device
+        self._make_params(self.qx.shape[0], self._rotation, self._position)
+        self.to(device)
+
+    def params_tensor(self):
+        """[7,B] contiguous copy: qx,qy,qz,qw,x,y,z (the engine's parameter layout)."""
+        return torch.stack([self.qx, self.qy, self.qz, self.qw, self.x, self.y, self.z]).detach().contiguous()
+
+    def load_params_tensor(self, p):
+        with torch.no_grad():
+            for i, name in enumerate(("qx", "qy", "qz", "qw", "x", "y", "z")):
+                getattr(self, name).copy_(p[i])
+
+    def forward(self):
+        q = torch.stack([self.qx, self.qy, self.qz, self.qw], dim=0).T
+        q = q / torch.norm(q, dim=1).reshape(-1, 1)
+        to_return = self.mesh()
+        to_return["quat"] = q
+        to_return["trans"] = torch.stack([self.x, self.y, self.z], dim=0).T
+        return to_return
+
+
+@dataclass
+class Image:
+    """rgb / segmentation / depth image tensor, stored bottom-up (diffdope.py:1101-1180)."""
+
+    img_path: Optional[str] = None
+    img_tensor: Optional[torch.Tensor] = None
+    img_resize: Optional[float] = 1
+    flip_img: Optional[bool] = True
+    depth: Optional[bool] = False
+    depth_scale: Optional[float] = 100
+
+    def __post_init__(self):
+        if self.img_path is not None:
+            if self.depth:
+                im = io_img.imread_depth(self.img_path) / self.depth_scale
+            else:
+                im = io_img.imread_rgb(self.img_path)
+            if self.flip_img:
+                im = im[::-1]
+            if self.img_resize is not None and self.img_resize < 1.0:
+                ow, oh = int(im.shape[1] * self.img_resize), int(im.shape[0] * self.img_resize)
+                im = io_img.resize_nearest(im, ow, oh) if self.depth else io_img.resize_linear(im, ow, oh)
+            self.img_tensor = torch.tensor(np.ascontiguousarray(im)).float()
+            log.info(f"Loaded image {self.img_path}, shape: {self.img_tensor.shape}")
+        self._batchsize_set = False
+
+    def __repr__(self):
+        return f"{self.img_tensor.shape} @ {self.img_path} on {self.img_tensor.device}"
+
+    __str__ = __repr__
+
+    def cuda(self):
+        self.img_tensor = self.img_tensor.cuda().float()
+
+    def set_batchsize(self, batchsize):
+        base = self.img_tensor[0] if self._batchsize_set else self.img_tensor
+        self.img_tensor = base[None].expand(batchsize, *base.shape)
+        self._batchsize_set = True
+
+
+@dataclass
+class Scene:
+    """Observed images (diffdope.py:1183-1264)."""
+
+    path_img: Optional[str] = None
+    path_depth: Optional[str] = None
+    path_segmentation: Optional[str] = None
+    image_resize: Optional[float] = None
+    tensor_rgb: Optional[Image] = None
+    tensor_depth: Optional[Image] = None
+    tensor_segmentation: Optional[Image] = None
+
+    def __post_init__(self):
+        if self.path_img is not None:
+            self.tensor_rgb = Image(self.path_img, img_resize=self.image_resize)
+        if self.path_depth is not None:
+            self.tensor_depth = Image(self.path_depth, img_resize=self.image_resize, depth=True)
+        if self.path_segmentation is not None:
+            self.tensor_segmentation = Image(self.path_segmentation, img_resize=self.image_resize)
+
+    def _images(self):
+        return [t for t in (self.tensor_rgb, self.tensor_depth, self.tensor_segmentation) if t is not None]
+
+    def set_batchsize(self, batchsize):
+        for t in self._images():
+            t.set_batchsize(batchsize)
+
+    def get_resolution(self):
+        """[H, W] of the optimisation images (diffdope.py:1231-1252)."""
+        if self.tensor_rgb is not None:
+            return [self.tensor_rgb.img_tensor.shape[-3], self.tensor_rgb.img_tensor.shape[-2]]
+        if self.tensor_depth is not None:
+            return [self.tensor_depth.img_tensor.shape[-2], self.tensor_depth.img_tensor.shape[-1]]
+        if self.tensor_segmentation is not None:
+            return [self.tensor_segmentation.img_tensor.shape[-3], self.tensor_segmentation.img_tensor.shape[-2]]
+
+    def cuda(self):
+        for t in self._images():
+            t.cuda()
+
+
+class _LazyResult(dict):
+    """optimization_results entry: "mtx" is stored; "rgb"/"depth"/"mask" are rendered on first access."""
+
+    def __init__(self, mtx, render_fn):
+        super().__init__(mtx=mtx)
+        self._render_fn = render_fn
+
+    def __missing__(self, key):
+        if key in ("rgb", "depth", "mask"):
+            for k, v in self._render_fn(self["mtx"]).items():
+                self[k] = v
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+
+@dataclass
+class DiffDope:
+    """The optimisation driver (diffdope.py:1267-1725).  `cfg` is any attribute mapping with the keys of
+    configs/diffdope.yaml (see load_config); camera / object3d / scene may be passed ready-made."""
+
+    cfg: Optional[dict] = None
+    camera: Optional[Camera] = None
+    object3d: Optional[Object3D] = None
+    scene: Optional[Scene] = None
+    resolution: Optional[list] = None
+    batchsize: Optional[int] = 16
+
+    def __post_init__(self):
+        self.cfg = Cfg.wrap(self.cfg)
+        if self.camera is None:
+            self.camera = Camera(**self.cfg.camera)
+        if self.object3d is None:
+            self.object3d = Object3D(**self.cfg.object3d)
+        if self.scene is None:
+            self.scene = Scene(**self.cfg.scene)
+        self.batchsize = self.cfg.hyperparameters.batchsize
+        self.glctx = RasterizeGLContext()
+        self.cuda()
+        self.resolution = self.scene.get_resolution()
+        self.optimization_results = []
+        self.gt_tensors = {}
+        self._refresh_gt()
+        self.set_batchsize(self.batchsize)
+        self.losses_values = {}
+        self.loss_functions = []
+        if self.cfg.losses.l1_rgb_with_mask:
+            self.loss_functions.append(l1_rgb_with_mask)
+        if self.cfg.losses.l1_depth_with_mask:
+            self.loss_functions.append(l1_depth_with_mask)
+        if self.cfg.losses.l1_mask:
+            self.loss_functions.append(l1_mask)
+        self.last_engine = None
+        log.info(f"batchsize is {self.batchsize}")
+
+    def _refresh_gt(self):
+        if self.scene.tensor_rgb is not None:
+            self.gt_tensors["rgb"] = self.scene.tensor_rgb.img_tensor
+        if self.scene.tensor_depth is not None:
+            self.gt_tensors["depth"] = self.scene.tensor_depth.img_tensor
+        if self.scene.tensor_segmentation is not None:
+            self.gt_tensors["segmentation"] = self.scene.tensor_segmentation.img_tensor
+
+    def set_batchsize(self, batchsize):
+        self.batchsize = batchsize
+        self.scene.set_batchsize(batchsize)
+        self.object3d.set_batchsize(batchsize)
+        self.camera.set_batchsize(batchsize)
+        self._refresh_gt()
+        self.optimizer = torch.optim.SGD(self.object3d.parameters(), lr=self.cfg.hyperparameters.learning_rate_base)
+        lo, hi = self.cfg.hyperparameters.learning_rates_bound
+        rng = random.Random(self.cfg.hyperparameters.get("seed")) if self.cfg.hyperparameters.get("seed") is not None else random
+        self.learning_rates = torch.tensor([rng.uniform(lo, hi) for _ in range(batchsize)]).float().cuda()
+
+    # ---- results ---------------------------------------------------------------------------------
+    def get_argmin(self):
+        """argmin over hypotheses of the mean over loss keys of the last-step losses (diffdope.py:1488-1513)."""
+        stacked = torch.stack([t[-1] for t in self.losses_values.values()], dim=0)
+        return torch.argmin(stacked.mean(dim=0), dim=-1)
+
+    def get_pose(self, batch_index=-1):
+        """4x4 numpy pose (OpenGL camera frame) of hypothesis `batch_index` (argmin if -1), diffdope.py:1618-1632."""
+        if batch_index == -1:
+            batch_index = self.get_argmin()
+        return self.optimization_results[-1]["mtx"][batch_index].numpy()
+
+    def add_loss_value(self, key, values, values_weighted=None):
+        v = values.detach().cpu().unsqueeze(0)
+        self.losses_values[key] = v if key not in self.losses_values else torch.cat((self.losses_values[key], v), dim=0)
+
+    # ---- rendering -------------------------------------------------------------------------------
+    def _render(self, mtx):
+        r = self.object3d.mesh()
+        kw = dict(uv=r["uv"], uv_idx=r["uv_idx"], tex=r["tex"]) if self.object3d.mesh.has_textured_map else dict(vtx_color=r["vtx_color"])
+        return render_texture_batch(glctx=self.glctx, proj_cam=self.camera.cam_proj, mtx=mtx, pos=r["pos"], pos_idx=r["pos_idx"],
+                                    resolution=self.resolution, **kw)
+
+    def _render_cpu(self, mtx_cpu):
+        with torch.no_grad():
+            out = self._render(mtx_cpu.cuda())
+        return {k: out[k].detach().cpu() for k in ("rgb", "depth", "mask")}
+
+    def render_img(self, index=None, batch_index=None, render_selection="rgb"):
+        """The render of iteration `index` (default last) for hypothesis `batch_index` (default argmin) as an
+        upright uint8 RGB numpy image (the reference's overlays / crops / grids are presentation code and not
+        reproduced)."""
+        index = -1 if index is None else index
+        b = int(self.get_argmin()) if batch_index is None else batch_index
+        img = self.optimization_results[index][render_selection][b]
+        img = img if img.dim() == 3 else img[..., None].expand(-1, -1, 3) / max(float(img.max()), 1e-6)
+        return (img.flip(0).clamp(0, 1) * 255).byte().numpy()
+
+    # ---- optimisation ----------------------------------------------------------------------------
+    def lr_schedule(self):
+        hp = self.cfg.hyperparameters
+        return [hp.base_lr * hp.lr_decay ** (it / hp.nb_iterations + 1) for it in range(hp.nb_iterations + 1)]
+
+    def run_optimization(self, fused=None, optimizer="sgd", global_batch=None):
+        """diffdope.py:1634-1714.  fused=None picks the fused engine when every loss function is a built-in."""
+        self.losses_values = {}
+        self.optimization_results = []
+        self._refresh_gt()
+        builtin = all(f in _BUILTIN_LOSSES for f in self.loss_functions) and len(self.loss_functions) > 0
+        if fused is None:
+            fused = builtin
+        if fused and not builtin:
+            raise RuntimeError("the fused engine only knows l1_rgb_with_mask / l1_depth_with_mask / l1_mask")
+        if fused:
+            self._run_fused(optimizer, global_batch)
+        else:
+            self._run_autograd()
+
+    def _run_fused(self, optimizer, global_batch):
+        r = self.object3d.mesh()
+        lw = self.cfg.losses
+        weights = {}
+        for f in self.loss_functions:
+            k = _BUILTIN_LOSSES[f]
+            weights[k] = float({"rgb": lw.weight_rgb, "depth": lw.weight_depth, "mask": lw.weight_mask}[k])
+        params = self.object3d.params_tensor()
+        gt = {k: v[0] for k, v in self.gt_tensors.items()}
+        tex = dict(uv=r["uv"][0], tex=r["tex"][0]) if self.object3d.mesh.has_textured_map else dict(vtx_color=r["vtx_color"][0])
+        eng = RefineEngine(r["pos"][0], r["pos_idx"][0], self.camera.cam_proj[0], self.resolution, gt, params, self.learning_rates,
+                           self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, **tex)
+        eng.run()
+        eng.check()
+        self.object3d.load_params_tensor(params)
+        losses = eng.losses().cpu()
+        for i, k in enumerate(("rgb", "depth", "mask")):
+            if k in weights:
+                self.losses_values[_LOG_KEYS[k]] = losses[:, i].clone()
+        mtx = eng.mtx_log.reshape(eng.max_iters, self.batchsize, 4, 4).cpu()
+        self.optimization_results = [_LazyResult(mtx[i], self._render_cpu) for i in range(mtx.shape[0])]
+        self.last_engine = eng
+
+    def _run_autograd(self):
+        hp = self.cfg.hyperparameters
+        self.optimizer = torch.optim.SGD(self.object3d.parameters(), lr=hp.learning_rate_base)
+        for lr in self.lr_schedule():
+            for g in self.optimizer.param_groups:
+                g["lr"] = lr
+            self.optimizer.zero_grad()
+            result = self.object3d()
+            mtx_gu = matrix_batch_44_from_position_quat(p=result["trans"], q=result["quat"])
+            self.renders = self._render(mtx_gu)
+            entry = _LazyResult(mtx_gu.detach().cpu(), self._render_cpu)
+            self.optimization_results.append(entry)
+            loss = torch.zeros(1, device=mtx_gu.device)
+            for loss_function in self.loss_functions:
+                l = loss_function(self)
+                if l is None:
+                    continue
+                loss = loss + l
+            loss.backward()
+            self.optimizer.step()
+
+    def cuda(self):
+        self.object3d.cuda()
+        self.scene.cuda()
+        self.camera.cuda()

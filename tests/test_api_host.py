@@ -1,0 +1,153 @@
+"""CPU-only tests of the ingest side of the API: PLY / image readers, resize rules,
+pose ingest conventions, config mapping, batch views."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import diffdope_amd as dd
+from diffdope_amd import api, io_img, io_ply, synthetic as syn
+
+
+def _write_ascii_ply(path, pos, faces, uv=None, colors=None, tex_name=None, quads=None):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\n")
+        if tex_name:
+            f.write(f"comment TextureFile {tex_name}\n")
+        f.write(f"element vertex {len(pos)}\nproperty float x\nproperty float y\nproperty float z\n")
+        if uv is not None:
+            f.write("property float texture_u\nproperty float texture_v\n")
+        if colors is not None:
+            f.write("property uchar red\nproperty uchar green\nproperty uchar blue\n")
+        nf = len(faces) + (len(quads) if quads is not None else 0)
+        f.write(f"element face {nf}\nproperty list uchar int vertex_indices\nend_header\n")
+        for i, p in enumerate(pos):
+            row = [f"{v:.6f}" for v in p]
+            if uv is not None:
+                row += [f"{v:.6f}" for v in uv[i]]
+            if colors is not None:
+                row += [str(int(c)) for c in colors[i]]
+            f.write(" ".join(row) + "\n")
+        for t in faces:
+            f.write("3 " + " ".join(str(int(i)) for i in t) + "\n")
+        for q in (quads if quads is not None else []):
+            f.write("4 " + " ".join(str(int(i)) for i in q) + "\n")
+
+
+def test_ply_ascii_binary_and_mesh_class(tmp_path):
+    from PIL import Image as PILImage
+
+    pos, tri, uv = syn.blob_mesh(4, 6, seed=1)
+    tex = (syn.texture(8, seed=2) * 255).astype(np.uint8)
+    PILImage.fromarray(tex).save(tmp_path / "t.png")
+    p = str(tmp_path / "m.ply")
+    _write_ascii_ply(p, pos, tri, uv=uv, tex_name="t.png")
+    m = io_ply.read_ply(p)
+    np.testing.assert_allclose(m["pos"], pos, atol=1e-5)
+    assert np.array_equal(m["faces"], tri) and m["texture_file"].endswith("t.png")
+    np.testing.assert_allclose(m["uv"], uv, atol=1e-5)
+    mesh = dd.Mesh(p, scale=0.5)
+    assert mesh.has_textured_map and tuple(mesh.tex.shape) == (8, 8, 3)
+    np.testing.assert_allclose(mesh.pos.numpy(), pos * 0.5, atol=1e-5)
+    np.testing.assert_allclose(mesh.uv.numpy()[:, 1], 1 - uv[:, 1], atol=1e-5)  # v flip, diffdope.py:822
+    np.testing.assert_allclose(mesh.tex.numpy(), tex / 255.0, atol=1e-6)
+    assert mesh.uv_idx.dtype == torch.int32 and torch.equal(mesh.uv_idx, mesh.pos_idx)
+    mesh.set_batchsize(5)
+    assert tuple(mesh.pos.shape) == (5,) + pos.shape and mesh.pos.stride(0) == 0  # a view, not 5 copies
+    assert tuple(mesh.tex.shape) == (5, 8, 8, 3) and mesh.tex.stride(0) == 0
+    mesh.set_batchsize(2)
+    assert tuple(mesh.pos_idx.shape) == (2,) + tri.shape
+    assert set(mesh().keys()) == {"pos", "pos_idx", "tex", "uv", "uv_idx", "vtx_normals"}
+    # binary little endian with vertex colours and a quad (fan triangulated)
+    pb = str(tmp_path / "b.ply")
+    cols = (np.random.RandomState(0).uniform(size=(4, 3)) * 255).astype(np.uint8)
+    quad_pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    with open(pb, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                b"property uchar red\nproperty uchar green\nproperty uchar blue\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n")
+        for i in range(4):
+            f.write(struct.pack("<fffBBB", *quad_pos[i], *cols[i]))
+        f.write(struct.pack("<Biiii", 4, 0, 1, 2, 3))
+    mb = io_ply.read_ply(pb)
+    assert np.array_equal(mb["faces"], [[0, 1, 2], [0, 2, 3]]) and np.array_equal(mb["colors"], cols)
+    mesh2 = dd.Mesh(pb, scale=1)
+    assert not mesh2.has_textured_map
+    np.testing.assert_allclose(mesh2.vtx_color.numpy(), cols / 255.0, atol=1e-6)
+    np.testing.assert_allclose(mesh2.vtx_normals.numpy(), [[0, 0, 1]] * 4, atol=1e-6)
+
+
+def test_image_loading_flip_and_resize_rules(tmp_path):
+    from PIL import Image as PILImage
+
+    rng = np.random.RandomState(0)
+    rgb = (rng.uniform(size=(6, 8, 3)) * 255).astype(np.uint8)
+    PILImage.fromarray(rgb).save(tmp_path / "rgb.png")
+    depth = (rng.uniform(size=(6, 8)) * 2000).astype(np.uint16)
+    PILImage.fromarray(depth).save(tmp_path / "depth.png")
+    seg = ((rng.uniform(size=(6, 8)) > 0.5) * 255).astype(np.uint8)
+    PILImage.fromarray(seg, mode="L").save(tmp_path / "seg.png")
+    im = dd.Image(str(tmp_path / "rgb.png"))
+    np.testing.assert_allclose(im.img_tensor.numpy(), rgb[::-1] / 255.0, atol=1e-6)  # vertical flip, diffdope.py:1131
+    d = dd.Image(str(tmp_path / "depth.png"), depth=True)
+    np.testing.assert_allclose(d.img_tensor.numpy(), depth[::-1] / 100.0, atol=1e-4)  # depth_scale 100
+    s = dd.Image(str(tmp_path / "seg.png"))
+    assert tuple(s.img_tensor.shape) == (6, 8, 3) and set(np.unique(s.img_tensor.numpy())) <= {0.0, 1.0}
+    # cv2.resize rules: INTER_LINEAR half-pixel centres; INTER_NEAREST floor(dst*scale)
+    a = np.arange(16, dtype=np.float64).reshape(4, 4)
+    out = io_img.resize_linear(a, 2, 2)
+    np.testing.assert_allclose(out, [[2.5, 4.5], [10.5, 12.5]])  # average of each 2x2 block for exact 2x down
+    np.testing.assert_allclose(io_img.resize_nearest(a, 2, 2), [[0, 2], [8, 10]])
+    sc = dd.Scene(path_img=str(tmp_path / "rgb.png"), path_depth=str(tmp_path / "depth.png"),
+                  path_segmentation=str(tmp_path / "seg.png"), image_resize=0.5)
+    assert sc.get_resolution() == [3, 4]
+    sc.set_batchsize(3)
+    assert tuple(sc.tensor_rgb.img_tensor.shape) == (3, 3, 4, 3) and sc.tensor_depth.img_tensor.stride(0) == 0
+
+
+def test_pose_ingest_conventions():
+    rng = np.random.RandomState(1)
+    for _ in range(20):
+        q = syn.random_quat(rng)
+        R = api.matrix_from_quat(q)
+        q2 = api.quat_from_matrix(R)
+        assert min(np.abs(q2 - q).max(), np.abs(q2 + q).max()) < 1e-9
+        t = rng.normal(size=3)
+        p_gl, q_gl = dd.opencv_2_opengl(t, q)
+        flip = np.diag([1.0, -1.0, -1.0])
+        np.testing.assert_allclose(api.matrix_from_quat(q_gl), flip @ R, atol=1e-9)
+        np.testing.assert_allclose(p_gl, flip @ t, atol=1e-12)
+    # a row-major flattened 3x3 (the yaml `rotation`) is accepted and ends up as xyzw parameters
+    R = api.matrix_from_quat(syn.random_quat(rng))
+    obj = dd.Object3D(position=[10, 20, 300], rotation=list(R.reshape(-1)), batchsize=4, opencv2opengl=True, scale=0.01)
+    got = np.array([obj.qx[0].item(), obj.qy[0].item(), obj.qz[0].item(), obj.qw[0].item()])
+    np.testing.assert_allclose(api.matrix_from_quat(got), np.diag([1.0, -1.0, -1.0]) @ R, atol=1e-6)
+    np.testing.assert_allclose([obj.x[0].item(), obj.y[0].item(), obj.z[0].item()], [0.1, -0.2, -3.0], atol=1e-6)
+    assert obj.qx.shape == (4,) and isinstance(obj.qx, torch.nn.Parameter)
+    obj.set_batchsize(7)
+    assert obj.z.shape == (7,) and abs(obj.z[3].item() + 3.0) < 1e-6
+    assert tuple(obj.params_tensor().shape) == (7, 7)
+
+
+def test_config_mapping_and_camera(tmp_path):
+    cfg_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "diffdope.yaml")
+    cfg = dd.load_config(cfg_path)
+    assert cfg.hyperparameters.nb_iterations >= 1 and cfg.losses.weight_mask > 0 and "fx" in cfg.camera
+    cam = dd.Camera(**cfg.camera)
+    assert tuple(cam.cam_proj.shape) == (4, 4) and cam.cam_proj.dtype == torch.float64
+    cam.set_batchsize(3)
+    assert tuple(cam.cam_proj.shape) == (3, 4, 4)
+    cam2 = dd.Camera(fx=100, fy=100, cx=64, cy=48, im_width=128, im_height=96)
+    cam2.resize(0.5)
+    assert (cam2.im_width, cam2.im_height, cam2.cx, cam2.cy) == (64, 48, 32, 24)
+
+
+def test_alias_package_exposes_reference_names():
+    import diffdope
+
+    for name in ("xfm_points", "xfm_vectors", "DiffDope", "Object3D", "Mesh", "Scene", "Image", "Camera", "render_texture_batch",
+                 "l1_rgb_with_mask", "l1_depth_with_mask", "l1_mask", "dist_batch_lr", "matrix_batch_44_from_position_quat",
+                 "opencv_2_opengl"):
+        assert hasattr(diffdope, name), name
+    assert diffdope.__all__ == ["xfm_points", "xfm_vectors"]
