@@ -154,6 +154,17 @@ def main():
         dom_bytes = alg["shade_kernel"] if dom == "shade_kernel" else alg["raster_stage"]
         achieved = dom_bytes / (kms[dom] * 1e-3) / 1e9
         ms_per_step = elapsed / args.steps * 1e3
+        # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, profiles/summarize_pmc.py); null if no pass matches this workload
+        traffic, traffic_src = None, None
+        try:
+            if args.config == "cfg2":
+                pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/" + pmc_files[-1]
+        except Exception:
+            pass
         out = {
             "metric": "render+backward iters/sec at 640x480, 64 hypotheses per iteration",
             "value": world * args.steps / elapsed,
@@ -169,7 +180,7 @@ def main():
             "iteration_model_GBps": alg["iteration"] * args.steps / elapsed / 1e9,
             "iteration_model_frac_of_hbm_peak": alg["iteration"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kms[dom],
                          "note": "algorithmic bytes = SURVEY 8(d) visibility-buffer model (full-frame G-buffer streams); this "
                                  "engine touches active tiles only, so frac can exceed 1 -- see DESIGN.md and profiles/"},
