@@ -54,16 +54,20 @@ struct EngineDev {
     RasterScratch L;
     float* clip;      // [B,V,4]
     float* mats;      // [B,2,16]: mtx | final
-    float* partials;  // [B*NT*4, NPART]: one per 8x8 quadrant, indexed by (b*NT + tile)*4 + quadrant
+    float* partials;  // [B*NT*4*2, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*2 + role
     float* adam;      // [2,7,B]
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
     EngineState* st;
+    int st_role;      // shade role that advances the iteration counter (0 if colour/depth terms are on, else 1)
+    int n_roles;      // 1 or 2 shade launches per iteration
 };
 
 struct ddx_engine {
     EngineDev dev;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipStream_t side = nullptr;    // second branch of the iteration (mask role of the shading stage)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool setup_done = false;
 };
 
@@ -83,7 +87,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
-    const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * NPART * sizeof(float));  // one partial per 8x8 quadrant
+    const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * 2 * NPART * sizeof(float));  // per 8x8 quadrant and shade role
     const size_t o_rast = carve(0);
     const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W);
     off += rast_bytes;
@@ -273,7 +277,12 @@ __device__ __forceinline__ void pair_decode(int desc, int& h0, int& h1, int& d)
     h1 = d ? h0 + QH : h0 + 1;
 }
 
-__global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
+// ROLE 0: colour + depth terms (per covered pixel).  ROLE 1: antialiased-coverage (mask) term (silhouette
+// pairs).  The two roles only share the zbuf they read, so they are separate workgroups of ONE launch
+// (blockIdx.z picks the role): they overlap on the chip, and each body keeps its own, smaller register
+// footprint instead of the union of both.  Each role writes its own partial per quadrant.
+template <int ROLE>
+__device__ __forceinline__ void shade_body(const EngineDev& E)
 {
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
     // grid (S, B): workgroup (s, b) takes tiles s, s+S, ... of hypothesis b's ordered active list -- no
     // prefix over hypotheses, no global list, workgroups beyond the count leave after one scalar load
     const int b = blockIdx.y;
-    if (blockIdx.x == 0 && b == 0 && tid == 0) E.st->it = E.st->it_next;  // see update_xfm_kernel
+    if (ROLE == E.st_role && blockIdx.x == 0 && b == 0 && tid == 0) E.st->it = E.st->it_next;  // see update_xfm_kernel
     const int n_tiles = L.b_count[b];
     for (int k = blockIdx.x; k < n_tiles; k += gridDim.x) {
         const int txy = L.active[(size_t)b * L.NT + k];
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
         const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
-        float* part = E.partials + ((size_t)flat * WAVES_PER_TILE + wave) * NPART;
+        float* part = E.partials + (((size_t)flat * WAVES_PER_TILE + wave) * 2 + ROLE) * NPART;
         // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
         bool anycov = false;
 #pragma unroll
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         const size_t pix = (size_t)py * W + px;
         if (id >= 0) { s0 = E.b.gt_seg[pix * 3 + 0]; s1 = E.b.gt_seg[pix * 3 + 1]; s2 = E.b.gt_seg[pix * 3 + 2]; }
-        if (id > 0) {
+        if (ROLE == 0 && id > 0) {
             const int t = id - 1;
             const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
             const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
                 acc_vertex(A, pos, v2, gx[2], gy[2], gw[2]);
             }
         }
-        if (d.use_mask) {
+        if (ROLE == 1) {
             // ---- antialias, pair-parallel: compact the candidate pairs (exactly one side covered, at least
             // one side in this quadrant) with ballots, then ONE lane per pair instead of 4 divergent
             // neighbour probes per pixel.  A pair deposits alpha*(c1-c0) into its target pixel (LDS add);
@@ -532,6 +541,13 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
     }
 }
 
+__global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
+{
+    const int role = E.n_roles == 2 ? (int)blockIdx.z : E.st_role;
+    if (role == 0) shade_body<0>(E);
+    else shade_body<1>(E);
+}
+
 // ---------------------------------------------------------------------------------------------
 // update + next iteration's transform, one launch: grid (UPD_SLICES, B).
 // Every workgroup of hypothesis b redundantly reduces b's quadrant partials (a few KB from L2, fixed order),
@@ -583,9 +599,23 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         }
         __syncthreads();
         const int na = min(256, n_act - start);
-        if (j < 19)
-            for (int s = grp; s < na * 4; s += 8)
-                acc += E.partials[((size_t)(b * NT + s_tidx[s >> 2]) * 4 + (s & 3)) * NPART + j];
+        if (j < 19) {
+            // slots = (tile, quadrant, role) in fixed order; loads are issued 8 at a time before they are
+            // consumed (a load-add-load-add chain would pay one L2 round trip per slot)
+            const int nslot = na * 8;
+            const bool both = E.n_roles == 2;
+            for (int s0 = grp; s0 < nslot; s0 += 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = s0 + u * 8;
+                    const bool ok = s < nslot && (both || (s & 1) == E.st_role);
+                    v[u] = ok ? E.partials[((size_t)(b * NT + s_tidx[s >> 3]) * 8 + (s & 7)) * NPART + j] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+        }
         const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
         for (int s = slice; s < na; s += UPD_SLICES) {  // (start is a multiple of 256, hence of UPD_SLICES)
             const int txy = s_tiles[s];
@@ -748,7 +778,11 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
     const ddx_engine_desc& d = E.d;
     if (int err = raster_run(E.clip, E.b.tri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_SCATTER : nullptr)) return err;
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
-    shade_kernel<<<shade_grid(d), 256, 0, s>>>(E);
+    {
+        dim3 g = shade_grid(d);
+        g.z = E.n_roles;
+        shade_kernel<<<g, 256, 0, s>>>(E);
+    }
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
     update_xfm_kernel<<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
@@ -788,10 +822,18 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     DDX_REQUIRE(e, DDX_E_NULL, "engine_create: out of host memory");
     e->dev.d = *desc;
     e->dev.b = *bufs;
+    e->dev.st_role = (desc->use_rgb || desc->use_depth) ? 0 : 1;
+    e->dev.n_roles = ((desc->use_rgb || desc->use_depth) && desc->use_mask) ? 2 : 1;
     const size_t need = engine_layout(e->dev, *desc, b.scratch);
     if (b.scratch_bytes < need) {
         delete e;
         DDX_REQUIRE(false, DDX_E_SCRATCH, "engine_create: scratch %zu < required %zu bytes", b.scratch_bytes, need);
+    }
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+        ddx_engine_destroy(e);
+        DDX_REQUIRE(false, 1, "engine_create: could not create the side stream / events");
     }
     *out = e;
     return 0;
@@ -879,5 +921,8 @@ extern "C" void ddx_engine_destroy(ddx_engine* e)
     if (!e) return;
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
 }
