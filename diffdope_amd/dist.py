@@ -49,3 +49,13 @@ def global_argmin(per_hyp_loss, mtx, lo=0, group=None):
     cand = torch.where(losses == best, gidx, torch.full_like(gidx, float("inf")))
     row = int(torch.argmin(cand))
     return int(table[row, 1].item()), float(table[row, 0].item()), table[row, 2:].reshape(4, 4).to(mtx.dtype)
+
+
+def merge_object_tables(table, group=None):
+    """Multi-object jobs (bop.refine_frame): row i of `table` [n_obj, 18] is filled by the one rank that owns
+    object i and zero elsewhere, so a single all_reduce(SUM) gives every rank the complete table."""
+    import torch.distributed as dist
+
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return table

@@ -28,6 +28,16 @@ def _worker(rank, world, port, losses, mtx, out_q):
         lo, hi = shard_range(losses.shape[1], rank, world)
         gi, gl, gm = global_argmin(torch.tensor(losses[case, lo:hi]), torch.tensor(mtx[case, lo:hi]), lo=lo)
         res.append((gi, gl, gm.numpy().copy()))
+    # multi-object table: object i is owned by rank i % world
+    from diffdope_amd.bop import owner_of
+    from diffdope_amd.dist import merge_object_tables
+
+    full = torch.tensor(mtx[0].reshape(losses.shape[1], 16)[:6, :])
+    tab = torch.zeros(6, 18)
+    for i in range(6):
+        if owner_of(i, world) == rank:
+            tab[i, 0], tab[i, 1], tab[i, 2:] = float(losses[0, i]), i, full[i]
+    res.append(merge_object_tables(tab).numpy().copy())
     out_q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -51,6 +61,11 @@ def test_global_argmin_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    for rank in (0, 1):
+        tab = got[rank][cases]
+        np.testing.assert_allclose(tab[:, 0], losses[0, :6], rtol=1e-6)
+        np.testing.assert_allclose(tab[:, 2:], mtx[0].reshape(B, 16)[:6], rtol=1e-6)
+        assert list(tab[:, 1]) == list(range(6))
     for case in range(cases):
         expect = int(np.argmin(losses[case]))
         for rank in (0, 1):
