@@ -186,6 +186,25 @@ __device__ __forceinline__ void pose_matrices(float q[4], const float t[3], cons
 // one vertex per lane on the matrix core: four v_mfma_f32_4x4x1_16b_f32 with A = row (lane%4) of final and
 // B = p[k] (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain), then the
 // 1/256-pixel window-coordinate snap.  Must be called by all 64 lanes of a wave.
+__device__ __forceinline__ void xfm_vertex_regs(const EngineDev& E, const float F[16], int b, int n, bool live, int lane,
+                                                float px, float py, float pz)
+{
+    const int V = E.d.V;
+    const int r = lane & 3;
+    const float a0 = r == 0 ? F[0] : (r == 1 ? F[4] : (r == 2 ? F[8] : F[12]));
+    const float a1 = r == 0 ? F[1] : (r == 1 ? F[5] : (r == 2 ? F[9] : F[13]));
+    const float a2 = r == 0 ? F[2] : (r == 1 ? F[6] : (r == 2 ? F[10] : F[14]));
+    const float a3 = r == 0 ? F[3] : (r == 1 ? F[7] : (r == 2 ? F[11] : F[15]));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, px, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, py, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, pz, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, 1.0f, acc, 0, 0, 0);
+    if (!live) return;
+    *reinterpret_cast<f32x4*>(E.clip + ((size_t)b * V + n) * 4) = acc;
+    E.L.snap[(size_t)b * V + n] = snap_vertex(make_float4(acc.x, acc.y, acc.z, acc.w), E.d.H, E.d.W);
+}
+
 __device__ __forceinline__ void xfm_vertex(const EngineDev& E, const float F[16], int b, int n, int n_end, int lane)
 {
     const int V = E.d.V;
@@ -555,7 +574,7 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
 // vertices with the NEW pose on the matrix core (as pose_xfm_kernel), so the next iteration starts at the
 // rasteriser.  Slice 0 also writes parameters, optimiser state and logs; the zbuf / tile-flag re-arm is split
 // over the slices.
-#define UPD_SLICES 4
+#define UPD_SLICES 8
 
 __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 {
@@ -744,7 +763,22 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     }
     const int per = (V + UPD_SLICES - 1) / UPD_SLICES;
     const int n_begin = slice * per, n_end = min(V, n_begin + per);
-    for (int n0 = n_begin; n0 < n_end; n0 += 256) xfm_vertex(E, F, b, n0 + tid, n_end, lane);
+    // positions of 4 strides are fetched before any is consumed (a load-transform-store loop would pay one
+    // memory round trip per stride)
+    for (int n0 = n_begin; n0 < n_end; n0 += 4 * 256) {
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + u * 256 + tid;
+            const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
+            px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + u * 256 + tid;
+            if (n0 + u * 256 < n_end) xfm_vertex_regs(E, F, b, n, n < n_end, lane, px[u], py[u], pz[u]);
+        }
+    }
 }
 
 __global__ void set_it_kernel(EngineState* st, int it) { st->it = it; st->it_next = it; }

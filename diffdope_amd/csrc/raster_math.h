@@ -123,6 +123,35 @@ __device__ __forceinline__ bool pixel_bary(const float4& p0, const float4& p1, c
     return true;
 }
 
+// z/w only (what the depth test needs): same operations, in the same order, as pixel_bary computes them,
+// with the pixel's NDC centre (fx, fy) supplied by the caller; false if the triangle is degenerate there
+// or the fragment falls outside the near/far planes
+__device__ __forceinline__ bool pixel_depth(const float4& p0, const float4& p1, const float4& p2, float fx, float fy, float& zw)
+{
+    const float p0x = __fmaf_rn(-fx, p0.w, p0.x), p0y = __fmaf_rn(-fy, p0.w, p0.y);
+    const float p1x = __fmaf_rn(-fx, p1.w, p1.x), p1y = __fmaf_rn(-fy, p1.w, p1.y);
+    const float p2x = __fmaf_rn(-fx, p2.w, p2.x), p2y = __fmaf_rn(-fy, p2.w, p2.y);
+    const float a0 = __fmaf_rn(p1x, p2y, -(p1y * p2x));
+    const float a1 = __fmaf_rn(p2x, p0y, -(p2y * p0x));
+    const float a2 = __fmaf_rn(p0x, p1y, -(p0y * p1x));
+    const float s = (a0 + a1) + a2;
+    if (!(fabsf(s) > 0.f)) return false;
+    const float zn = __fmaf_rn(a2, p2.z, __fmaf_rn(a1, p1.z, a0 * p0.z));
+    const float wn = __fmaf_rn(a2, p2.w, __fmaf_rn(a1, p1.w, a0 * p0.w));
+    zw = __fdiv_rn(zn, wn) + 0.0f;
+    return zw >= -1.0f && zw <= 1.0f;
+}
+
+// pixel index -> NDC centre: fx = fma(px, xs, xo) with xs = 2/W, xo = 1/W - 1 (as pixel_bary)
+struct PixNdc { float xs, xo, ys, yo; };
+__device__ __forceinline__ PixNdc make_pixndc(int H, int W)
+{
+    PixNdc n;
+    n.xs = __fdiv_rn(2.0f, (float)W); n.xo = __fdiv_rn(1.0f, (float)W) - 1.0f;
+    n.ys = __fdiv_rn(2.0f, (float)H); n.yo = __fdiv_rn(1.0f, (float)H) - 1.0f;
+    return n;
+}
+
 __device__ __forceinline__ unsigned int depth_key(float zw)
 {
     unsigned int bits = __float_as_uint(zw);

@@ -86,8 +86,10 @@ class RefineEngine:
         self.handle = h
         self.it = 0
 
-    def run(self, n=None, use_graph=True):
-        """Run n iterations (default: all remaining) asynchronously on the current stream."""
+    def run(self, n=None, use_graph=False):
+        """Run n iterations (default: all remaining) asynchronously on the current stream.
+        use_graph=True replays one captured hipGraph per iteration; with 4 launches per iteration plain stream
+        launches measured ~5 % faster on MI355X, so that is the default."""
         n = self.max_iters - self.it if n is None else n
         _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
         self.it += n

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc passes (one counter per pass, as MI355X_MICROARCH.md prescribes: FETCH_SIZE needs
 3 TCC slots, WRITE_SIZE 2) into per-kernel HBM-side bytes per launch.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_<tag>_FETCH_SIZE -o pmc --output-format csv -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-graph
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_<tag>_FETCH_SIZE -o pmc --output-format csv -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_<tag>_WRITE_SIZE -o pmc --output-format csv -- python bench.py ... (same)
     python profiles/summarize_pmc.py <tag> > profiles/<tag>_pmc_traffic.json
 

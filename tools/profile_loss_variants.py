@@ -1,5 +1,5 @@
 import sys, time, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import diffdope_amd as dd
 from diffdope_amd import workloads as wl
 dev = torch.device('cuda:0')
