@@ -150,3 +150,52 @@ def test_render_texture_batch_autograd_matches_oracle():
         loss.backward()
         g = np.stack([p.grad.cpu().numpy() for p in params])
         np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+
+
+@pytest.mark.parametrize("rows,cols,H,W,B,dist", [(4, 6, 50, 70, 1, 1.2), (6, 8, 120, 160, 3, 1.0), (16, 20, 37, 53, 2, 1.8)])
+def test_engine_large_triangles_ragged_sizes_single_hypothesis(rows, cols, H, W, B, dist):
+    """Low-poly meshes close to the camera (every triangle takes the tile pass), resolutions that are not
+    multiples of the tile size, B = 1: losses and gradients still match the oracle."""
+    sc = make_scene(rows, cols, H, W, B=B, dist=dist, tex_size=16)
+    R = sc["oracle"]
+    w = dict(rgb=0.7, depth=1.0, mask=1.0)
+    R.weights = w
+    total, logs, g_ref, r_ref = R.loss_and_grad(sc["params"], sc["lr_mult"])
+    eng, params = _engine(sc, w, [0.25])
+    eng.run()
+    torch.cuda.synchronize()
+    st = eng.check()
+    if rows <= 6:
+        assert st["big_triangles"] == 1  # the tile pass ran
+    g = (sc["params"] - params.cpu().numpy()) / 0.25
+    np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    lg = eng.losses()[0].cpu().numpy()
+    for i, key in enumerate(KEYS):
+        np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
+
+
+def test_engine_hypothesis_leaving_the_frame():
+    """One hypothesis looks away from the object: no active tile, the loss is the whole-frame background
+    term (incl. the -t_z depth quirk of diffdope.py:204-209) and only t_z receives a gradient."""
+    sc = make_scene(16, 20, 60, 80, B=2, dist=1.8)
+    sc["params"][4, 1] = 50.0  # x far outside the frustum
+    R = sc["oracle"]
+    w = dict(rgb=0.7, depth=1.0, mask=1.0)
+    R.weights = w
+    total, logs, g_ref, r_ref = R.loss_and_grad(sc["params"], sc["lr_mult"])
+    assert (r_ref["rast"][1, ..., 3] > 0).sum() == 0
+    eng, params = _engine(sc, w, [0.25])
+    eng.run()
+    torch.cuda.synchronize()
+    g = (sc["params"] - params.cpu().numpy()) / 0.25
+    np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    assert abs(g[6, 1]) > 0 and np.abs(g[:6, 1]).max() < 1e-9
+    lg = eng.losses()[0].cpu().numpy()
+    for i, key in enumerate(KEYS):
+        np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
+    # and the engine keeps working on later iterations (tile flags / zbuf re-armed correctly)
+    eng2, p2 = _engine(sc, w, [0.01] * 4)
+    eng2.run()
+    torch.cuda.synchronize()
+    p_ref, logs_ref, _ = R.optimise(sc["params"], sc["lr_mult"], [0.01] * 4)
+    np.testing.assert_allclose(p2.cpu().numpy(), p_ref, rtol=0, atol=2e-5)
