@@ -57,6 +57,7 @@ struct EngineDev {
     float* partials;  // [B*NT*4*2, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*2 + role
     float* adam;      // [2,7,B]
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
+    int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     EngineState* st;
     int st_role;      // shade role that advances the iteration counter (0 if colour/depth terms are on, else 1)
     int n_roles;      // 1 or 2 shade launches per iteration
@@ -86,6 +87,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_adam = carve((size_t)2 * 7 * d.B * sizeof(float));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
+    const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
     const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * 2 * NPART * sizeof(float));  // per 8x8 quadrant and shade role
     const size_t o_rast = carve(0);
@@ -96,6 +98,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.adam = (float*)(p + o_adam);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
+    E.trirec = (int4*)(p + o_rec);
     E.partials = (float*)(p + o_part);
     return off;
 }
@@ -296,6 +299,125 @@ __device__ __forceinline__ void pair_decode(int desc, int& h0, int& h1, int& d)
     h1 = d ? h0 + QH : h0 + 1;
 }
 
+// Antialias pair analysis for the fused engine (semantics = aa_eval_pair + aa_pair_backward of raster_math.h).
+// Differences in mechanics only: the triangle record (3 vertex ids + 3 opposite-vertex ids, packed once at
+// setup) comes with two 16-byte loads; the clip positions of the 3 vertices, of the 3 opposite vertices and the
+// object-space positions are all requested in ONE dependent level; and because the backward is linear in
+// d loss / d alpha, the pair's contribution to d loss / d final PER UNIT d alpha (12 numbers) is produced here,
+// so the backward pass after the pixel phase is 12 FMAs with no memory access.
+struct AAUnit {
+    bool valid, clamped;
+    float alpha;
+    bool target0;   // the contribution lands on pixel0 (else pixel1)
+    float C[12];    // d(final rows x,y,w) per unit d alpha (zero if clamped)
+};
+
+__device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const int4* __restrict__ rec, const float* __restrict__ pos,
+                                             int H, int W, int px, int py, int d, int t0, int t1, AAUnit& o)
+{
+    o.valid = false; o.clamped = true; o.alpha = 0.f; o.target0 = true;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o.C[i] = 0.f;
+    if (t0 == t1) return;
+    const bool chosen1 = t0 < 0;  // exactly one side is covered on this path
+    const int t = chosen1 ? t1 : t0;
+    const int cx = chosen1 ? px + (d == 0) : px, cy = chosen1 ? py + (d == 1) : py;
+    const float ds = chosen1 ? -1.0f : 1.0f;
+    const int4 r0 = rec[t * 2 + 0], r1 = rec[t * 2 + 1];  // {v0,v1,v2,opp0} {opp1,opp2,-,-}
+    const int vi[3] = {r0.x, r0.y, r0.z};
+    const int ov[3] = {r0.w, r1.x, r1.y};
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    const float fx = (float)cx + 0.5f - hw, fy = (float)cy + 0.5f - hh;
+    float4 p[3], q[3];
+    float ps[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        p[i] = ld4(P + (size_t)vi[i] * 4);
+        q[i] = ld4(P + (size_t)(ov[i] >= 0 ? ov[i] : vi[i]) * 4);
+        ps[i][0] = pos[(size_t)vi[i] * 3 + 0]; ps[i][1] = pos[(size_t)vi[i] * 3 + 1]; ps[i][2] = pos[(size_t)vi[i] * 3 + 2];
+    }
+    float x[3], y[3], ox[3], oy[3], iw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!(p[i].w > 0.f)) return;
+        iw[i] = __fdiv_rn(1.0f, p[i].w);
+        x[i] = __fmaf_rn(p[i].x * iw[i], hw, -fx);
+        y[i] = __fmaf_rn(p[i].y * iw[i], hh, -fy);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ox[k] = x[k]; oy[k] = y[k];
+        if (ov[k] >= 0 && q[k].w > 0.f) {
+            const float iwq = __fdiv_rn(1.0f, q[k].w);
+            ox[k] = __fmaf_rn(q[k].x * iwq, hw, -fx);
+            oy[k] = __fmaf_rn(q[k].y * iwq, hh, -fy);
+        }
+    }
+    const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+    float aw[3];
+    aw[0] = (x[1] - ox[0]) * (y[2] - oy[0]) - (x[2] - ox[0]) * (y[1] - oy[0]);
+    aw[1] = (x[2] - ox[1]) * (y[0] - oy[1]) - (x[0] - ox[1]) * (y[2] - oy[1]);
+    aw[2] = (x[0] - ox[2]) * (y[1] - oy[2]) - (x[1] - ox[2]) * (y[0] - oy[2]);
+    bool sil[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sil[k] = sign_bit(aw[k]) == sign_bit(bb);
+    if (!(sil[0] || sil[1] || sil[2])) return;
+    if (d) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float tmp = x[i]; x[i] = y[i]; y[i] = tmp; }
+    }
+    int best = -1;
+    float rbest = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ia = (k + 1) % 3, ib = (k + 2) % 3;
+        if (sign_bit(y[ia]) == sign_bit(y[ib])) continue;
+        const float dx = x[ib] - x[ia], dy = y[ib] - y[ia];
+        const float r = ds * __fdiv_rn(x[ia] * dy - y[ia] * dx, dy);
+        if (best < 0 || r > rbest) { best = k; rbest = r; }
+    }
+    if (best < 0) return;
+    const int ia = (best + 1) % 3, ib = (best + 2) % 3;
+#define SEL3(arr, i) ((i) == 0 ? arr[0] : ((i) == 1 ? arr[1] : arr[2]))
+    const float xa = SEL3(x, ia), ya = SEL3(y, ia), xb = SEL3(x, ib), yb = SEL3(y, ib);
+    const bool silb = SEL3(sil, best);
+    const float dx = xb - xa, dy = yb - ya;
+    if (!(silb && fabsf(dy) >= fabsf(dx))) return;
+    const float eps = 0.0625f;
+    if (!(rbest > -eps && rbest < 1.0f + eps)) return;
+    o.valid = true;
+    o.clamped = !(rbest > 0.f && rbest < 1.f);
+    const float dcc = rbest < 0.f ? 0.f : (rbest > 1.f ? 1.f : rbest);
+    o.alpha = ds * (0.5f - dcc);
+    o.target0 = o.alpha > 0.f;
+    if (o.clamped) return;
+    // unit backward (galpha = 1): same expressions as aa_pair_backward
+    const float gr = -1.0f;
+    const float D = yb - ya;
+    const float r = __fdiv_rn(xa * yb - ya * xb, D);
+    const float g_xa = gr * yb / D, g_xb = gr * (-ya) / D;
+    const float g_ya = gr * (r - xb) / D, g_yb = gr * (xa - r) / D;
+    const float gX[2] = {d ? g_ya : g_xa, d ? g_yb : g_xb};
+    const float gY[2] = {d ? g_xa : g_ya, d ? g_xb : g_yb};
+    const float ix[2] = {d ? ya : xa, d ? yb : xb};
+    const float iy[2] = {d ? xa : ya, d ? xb : yb};
+    const float iwa = SEL3(iw, ia), iwb = SEL3(iw, ib);
+    const float iwv[2] = {iwa, iwb};
+    const float pa[3] = {SEL3(ps, ia)[0], SEL3(ps, ia)[1], SEL3(ps, ia)[2]};
+    const float pb[3] = {SEL3(ps, ib)[0], SEL3(ps, ib)[1], SEL3(ps, ib)[2]};
+#undef SEL3
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float gx = gX[i] * 0.5f * (float)W * iwv[i];
+        const float gy = gY[i] * 0.5f * (float)H * iwv[i];
+        const float gw = -(gX[i] * (ix[i] + fx) + gY[i] * (iy[i] + fy)) * iwv[i];
+        const float* pp = i == 0 ? pa : pb;
+        o.C[0] = __fmaf_rn(gx, pp[0], o.C[0]); o.C[1] = __fmaf_rn(gx, pp[1], o.C[1]); o.C[2] = __fmaf_rn(gx, pp[2], o.C[2]); o.C[3] += gx;
+        o.C[4] = __fmaf_rn(gy, pp[0], o.C[4]); o.C[5] = __fmaf_rn(gy, pp[1], o.C[5]); o.C[6] = __fmaf_rn(gy, pp[2], o.C[6]); o.C[7] += gy;
+        o.C[8] = __fmaf_rn(gw, pp[0], o.C[8]); o.C[9] = __fmaf_rn(gw, pp[1], o.C[9]); o.C[10] = __fmaf_rn(gw, pp[2], o.C[10]); o.C[11] += gw;
+    }
+}
+
 // ROLE 0: colour + depth terms (per covered pixel).  ROLE 1: antialiased-coverage (mask) term (silhouette
 // pairs).  The two roles only share the zbuf they read, so they are separate workgroups of ONE launch
 // (blockIdx.z picks the role): they overlap on the chip, and each body keeps its own, smaller register
@@ -470,23 +592,24 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             if (c3) s_pairs[wave][n0 + n1 + n2 + __popcll(m3 & lt)] = (unsigned short)(lane | (3 << 6));
             wave_lds_sync();
             // forward: each lane owns pair `lane` (+64, ... in the rare quadrant with more than 64 pairs)
-            AAPair pr0;
-            pr0.valid = false;
+            float C0[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) C0[i] = 0.f;
             int tl0 = -1;
             float cd0 = 0.f;
             for (int j0 = 0; j0 < np; j0 += 64) {
                 const int j = j0 + lane;
-                AAPair pr;
-                pr.valid = false;
                 int tl = -1;
                 float cd = 0.f;
+                AAUnit pr;
+                pr.valid = false;
                 if (j < np) {
                     int h0, h1, dd;
                     pair_decode(s_pairs[wave][j], h0, h1, dd);
                     const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
-                    aa_eval_pair(P, tri, E.b.opp, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, 0.f, 0.f, pr);
+                    aa_eval_unit(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
                     if (pr.valid) {
-                        const int ht = pr.alpha > 0.f ? h0 : h1;
+                        const int ht = pr.target0 ? h0 : h1;
                         const int tx = ht % QH - 1, ty = ht / QH - 1;
                         cd = (float)((t1 >= 0) - (t0 >= 0));
                         if (tx >= 0 && tx < QUAD && ty >= 0 && ty < QUAD) {
@@ -495,7 +618,12 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                         }
                     }
                 }
-                if (j0 == 0) { pr0 = pr; tl0 = tl; cd0 = cd; }
+                if (j0 == 0) {
+                    tl0 = (pr.valid && !pr.clamped) ? tl : -1;
+                    cd0 = cd;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) C0[i] = pr.C[i];
+                }
             }
             wave_lds_sync();
             // pixel: mask value, loss term, d loss / d mask
@@ -509,36 +637,36 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             s_gm[wave][lane] = gm;
             s_m[wave][lane] = 0.f;  // re-arm for the next tile
             wave_lds_sync();
-            // backward: pairs whose target pixel is ours send d alpha to their two edge vertices
+            // backward: a pair whose target pixel is ours scales its unit contribution by d loss / d alpha
             for (int j0 = 0; j0 < np; j0 += 64) {
-                AAPair pr = pr0;
                 int tl = tl0;
                 float cd = cd0;
+                float C[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) C[i] = C0[i];
                 if (j0 > 0) {  // rare: re-evaluate the overflow pairs
                     const int j = j0 + lane;
-                    pr.valid = false;
                     tl = -1;
                     if (j < np) {
                         int h0, h1, dd;
                         pair_decode(s_pairs[wave][j], h0, h1, dd);
                         const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
-                        aa_eval_pair(P, tri, E.b.opp, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, 0.f, 0.f, pr);
-                        if (pr.valid) {
-                            const int ht = pr.alpha > 0.f ? h0 : h1;
+                        AAUnit pr;
+                        aa_eval_unit(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
+                        if (pr.valid && !pr.clamped) {
+                            const int ht = pr.target0 ? h0 : h1;
                             const int tx = ht % QH - 1, ty = ht / QH - 1;
                             cd = (float)((t1 >= 0) - (t0 >= 0));
                             if (tx >= 0 && tx < QUAD && ty >= 0 && ty < QUAD) tl = ty * QUAD + tx;
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) C[i] = pr.C[i];
                         }
                     }
                 }
-                if (pr.valid && tl >= 0 && !pr.clamped) {
+                if (tl >= 0) {
                     const float ga = s_gm[wave][tl] * cd;
-                    if (ga != 0.f) {
-                        float g[2][3];
-                        aa_pair_backward(pr, P, H, W, ga, g);
-                        acc_vertex(A, pos, pr.va, g[0][0], g[0][1], g[0][2]);
-                        acc_vertex(A, pos, pr.vb, g[1][0], g[1][1], g[1][2]);
-                    }
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) A.dF[i] = __fmaf_rn(ga, C[i], A.dF[i]);
                 }
             }
             wave_lds_sync();
@@ -551,10 +679,15 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
         for (int i = 0; i < 4; ++i) vals[12 + i] = A.dM2[i];
         vals[16] = A.L[0]; vals[17] = A.L[1]; vals[18] = A.L[2];
         float mine = 0.f;
+        bool nz = false;
 #pragma unroll
-        for (int i = 0; i < 19; ++i) {
-            const float s = wave_sum(vals[i]);
-            if (lane == i) mine = s;
+        for (int i = 0; i < 19; ++i) nz |= vals[i] != 0.f;
+        if (__ballot(nz) != 0ull) {  // e.g. mask role on an interior quadrant: every term is exactly zero
+#pragma unroll
+            for (int i = 0; i < 19; ++i) {
+                const float s = wave_sum(vals[i]);
+                if (lane == i) mine = s;
+            }
         }
         if (lane < NPART) part[lane] = mine;
     }
@@ -873,6 +1006,14 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     return 0;
 }
 
+__global__ void trirec_kernel(EngineDev E)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= E.d.T) return;
+    E.trirec[t * 2 + 0] = make_int4(E.b.tri[t * 3 + 0], E.b.tri[t * 3 + 1], E.b.tri[t * 3 + 2], E.b.opp[t * 3 + 0]);
+    E.trirec[t * 2 + 1] = make_int4(E.b.opp[t * 3 + 1], E.b.opp[t * 3 + 2], 0, 0);
+}
+
 static int engine_setup(ddx_engine* e, hipStream_t s)
 {
     EngineDev& E = e->dev;
@@ -881,6 +1022,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // kept zero by update_xfm_kernel afterwards
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
+    trirec_kernel<<<ddx_cdiv(E.d.T, 256), 256, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
     e->setup_done = true;
     return 0;
