@@ -108,60 +108,78 @@ __device__ __forceinline__ Edge32 make_edge(int ax, int ay, int bx, int by, int 
     return e;
 }
 
-#define SCATTER_TPL 2  // triangles per lane
+#define SCATTER_TPL 2  // triangles per lane: both index/vertex gathers are issued before either is consumed
 
-// Per-triangle state between the phases of scatter_kernel.  The kernel is ordered so that every LOAD of
-// both triangles is issued before the first store/atomic: on CDNA vmcnt counts stores and (device-scope)
-// atomics as well, so a load issued behind the 64-bit atomicMin of the previous triangle waits for that
-// atomic's round trip to memory.  PMC before the reordering: 60 % of the wave cycles in s_waitcnt.
-struct ScatterTri {
-    int t, i0, i1, i2;
-    int px0, py0, nxp, nyp;
-    int tx0, ty0, tx1, ty1;
-    unsigned mask;   // covered pixel centres of a small triangle, bit j*nxp+i
-    bool alive, small;
-};
-
-__device__ __forceinline__ void scatter_setup(ScatterTri& s, const int2& a, const int2& bq, const int2& c, int H, int W)
+__device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V, int T, int H, int W, const RasterScratch& L,
+                                            int b, int t, int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c)
 {
-    s.alive = false; s.small = false; s.mask = 0u;
-    if (a.x == INT_MIN || bq.x == INT_MIN || c.x == INT_MIN) return;
-    const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
-    const int ymin = min(a.y, min(bq.y, c.y)), ymax = max(a.y, max(bq.y, c.y));
-    int px0 = (xmin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, px1 = (xmax - DDX_SUBPIX / 2) >> 8;
-    int py0 = (ymin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, py1 = (ymax - DDX_SUBPIX / 2) >> 8;
-    px0 = max(px0, 0); py0 = max(py0, 0);
-    px1 = min(px1, W - 1); py1 = min(py1, H - 1);
-    if (px0 > px1 || py0 > py1) return;
-    s.px0 = px0; s.py0 = py0; s.nxp = px1 - px0 + 1; s.nyp = py1 - py0 + 1;
-    s.small = s.nxp * s.nyp <= RASTER_SMALL_PX && (xmax - xmin) < 8192 && (ymax - ymin) < 8192;
-    if (s.small) {
-        // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
-        const int area = (bq.x - a.x) * (c.y - a.y) - (c.x - a.x) * (bq.y - a.y);
-        if (area == 0) return;
-        const bool flip = area < 0;
-        const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
-        const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
-        const Edge32 e1 = make_edge(c.x, c.y, a.x, a.y, X0, Y0, flip);
-        const Edge32 e2 = make_edge(a.x, a.y, bq.x, bq.y, X0, Y0, flip);
-        unsigned bit = 1u;
-        for (int j = 0; j < s.nyp; ++j) {
-            int v0 = e0.e00 + j * e0.sy, v1 = e1.e00 + j * e1.sy, v2 = e2.e00 + j * e2.sy;
-            for (int i = 0; i < s.nxp; ++i, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx, bit <<= 1) {
-                const bool in = (v0 > 0 || (v0 == 0 && e0.own)) && (v1 > 0 || (v1 == 0 && e1.own)) &&
-                                (v2 > 0 || (v2 == 0 && e2.own));
-                if (in) s.mask |= bit;
+    unsigned range = ~0u;  // packed tile range of a LARGE triangle
+    if (a.x != INT_MIN && bq.x != INT_MIN && c.x != INT_MIN) {
+        const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
+        const int ymin = min(a.y, min(bq.y, c.y)), ymax = max(a.y, max(bq.y, c.y));
+        int px0 = (xmin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, px1 = (xmax - DDX_SUBPIX / 2) >> 8;
+        int py0 = (ymin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, py1 = (ymax - DDX_SUBPIX / 2) >> 8;
+        px0 = max(px0, 0); py0 = max(py0, 0);
+        px1 = min(px1, W - 1); py1 = min(py1, H - 1);
+        if (px0 <= px1 && py0 <= py1) {
+            const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
+            const bool small = nxp * nyp <= RASTER_SMALL_PX && (xmax - xmin) < 8192 && (ymax - ymin) < 8192;
+            bool alive = false;
+            if (small) {
+                // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
+                const int area = (bq.x - a.x) * (c.y - a.y) - (c.x - a.x) * (bq.y - a.y);
+                if (area != 0) {
+                    alive = true;
+                    const bool flip = area < 0;
+                    const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
+                    const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
+                    const Edge32 e1 = make_edge(c.x, c.y, a.x, a.y, X0, Y0, flip);
+                    const Edge32 e2 = make_edge(a.x, a.y, bq.x, bq.y, X0, Y0, flip);
+                    bool loaded = false;
+                    float4 p0, p1, p2;
+                    unsigned long long* Z = L.zbuf + (size_t)b * H * W;
+                    const PixNdc ndc = make_pixndc(H, W);
+                    for (int j = 0; j < nyp; ++j) {
+                        int v0 = e0.e00 + j * e0.sy, v1 = e1.e00 + j * e1.sy, v2 = e2.e00 + j * e2.sy;
+                        for (int i = 0; i < nxp; ++i, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx) {
+                            const bool in = (v0 > 0 || (v0 == 0 && e0.own)) && (v1 > 0 || (v1 == 0 && e1.own)) &&
+                                            (v2 > 0 || (v2 == 0 && e2.own));
+                            if (!in) continue;
+                            if (!loaded) {  // clip-space vertices only for triangles that own a pixel centre
+                                const float* P = pos + (size_t)b * V * 4;
+                                p0 = ld4(P + (size_t)i0 * 4); p1 = ld4(P + (size_t)i1 * 4); p2 = ld4(P + (size_t)i2 * 4);
+                                loaded = true;
+                            }
+                            float zw;
+                            const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
+                            if (pixel_depth(p0, p1, p2, fx, fy, zw))
+                                atomicMin(Z + (size_t)(py0 + j) * W + px0 + i, ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
+                        }
+                    }
+                }
+            } else {
+                const long long area = (long long)(bq.x - a.x) * (long long)(c.y - a.y) - (long long)(c.x - a.x) * (long long)(bq.y - a.y);
+                alive = area != 0;
+            }
+            if (alive) {
+                // tiles under bbox + 1 px: every pixel adjacent to a covered pixel lies in an active tile
+                // (conservative: a centre inside the bbox need not be covered)
+                const int tx0 = max(px0 - 1, 0) / DDX_TILE, tx1 = min(px1 + 1, W - 1) / DDX_TILE;
+                const int ty0 = max(py0 - 1, 0) / DDX_TILE, ty1 = min(py1 + 1, H - 1) / DDX_TILE;
+                int* flag = L.tile_flag + (size_t)b * L.NT;
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) flag[ty * L.ntx + tx] = 1;  // plain store, no atomics
+                if (!small) {
+                    int* big = L.tile_big + (size_t)b * L.NT;
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) big[ty * L.ntx + tx] = 1;
+                    range = (unsigned)tx0 | ((unsigned)ty0 << 8) | ((unsigned)(tx1 - tx0) << 16) | ((unsigned)(ty1 - ty0) << 24);
+                    L.counters[3] = 1;  // plain store: "the batch has a large triangle"
+                }
             }
         }
-    } else {
-        const long long area = (long long)(bq.x - a.x) * (long long)(c.y - a.y) - (long long)(c.x - a.x) * (long long)(bq.y - a.y);
-        if (area == 0) return;
     }
-    s.alive = true;
-    // tiles under bbox + 1 px: every pixel adjacent to a covered pixel lies in an active tile
-    // (conservative: a centre inside the bbox need not be covered)
-    s.tx0 = max(px0 - 1, 0) / DDX_TILE; s.tx1 = min(px1 + 1, W - 1) / DDX_TILE;
-    s.ty0 = max(py0 - 1, 0) / DDX_TILE; s.ty1 = min(py1 + 1, H - 1) / DDX_TILE;
+    L.trirange[(size_t)b * T + t] = range;
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
@@ -169,73 +187,26 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
 {
     const int b = blockIdx.y;
     const int2* S = L.snap + (size_t)b * V;
-    const float* P = pos + (size_t)b * V * 4;
-    ScatterTri s[SCATTER_TPL];
+    int t[SCATTER_TPL], i0[SCATTER_TPL], i1[SCATTER_TPL], i2[SCATTER_TPL];
     bool ok[SCATTER_TPL];
     int2 va[SCATTER_TPL], vb[SCATTER_TPL], vc[SCATTER_TPL];
-    // ---- phase 1: index loads, then the three 8-byte snap gathers of both triangles
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
-        s[k].t = (blockIdx.x * SCATTER_TPL + k) * 256 + threadIdx.x;
-        const int tt = min(s[k].t, T - 1);
-        s[k].i0 = tri[tt * 3 + 0]; s[k].i1 = tri[tt * 3 + 1]; s[k].i2 = tri[tt * 3 + 2];
+        t[k] = (blockIdx.x * SCATTER_TPL + k) * 256 + threadIdx.x;
+        const int tt = min(t[k], T - 1);
+        i0[k] = tri[tt * 3 + 0]; i1[k] = tri[tt * 3 + 1]; i2[k] = tri[tt * 3 + 2];
     }
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
-        ok[k] = s[k].t < T && (unsigned)s[k].i0 < (unsigned)V && (unsigned)s[k].i1 < (unsigned)V && (unsigned)s[k].i2 < (unsigned)V;
-        va[k] = S[ok[k] ? s[k].i0 : 0]; vb[k] = S[ok[k] ? s[k].i1 : 0]; vc[k] = S[ok[k] ? s[k].i2 : 0];
-    }
-    // ---- phase 2: integer setup + coverage masks (no memory traffic)
-#pragma unroll
-    for (int k = 0; k < SCATTER_TPL; ++k) {
-        s[k].alive = false; s[k].small = false; s[k].mask = 0u;
-        if (ok[k]) scatter_setup(s[k], va[k], vb[k], vc[k], H, W);
-    }
-    // ---- phase 3: clip-space vertices, only for triangles that own a pixel centre
-    float4 p0[SCATTER_TPL], p1[SCATTER_TPL], p2[SCATTER_TPL];
-#pragma unroll
-    for (int k = 0; k < SCATTER_TPL; ++k)
-        if (s[k].mask) {
-            p0[k] = ld4(P + (size_t)s[k].i0 * 4); p1[k] = ld4(P + (size_t)s[k].i1 * 4); p2[k] = ld4(P + (size_t)s[k].i2 * 4);
-        }
-    // ---- phase 4: stores and atomics only from here on
-    unsigned long long* Z = L.zbuf + (size_t)b * H * W;
-    const PixNdc ndc = make_pixndc(H, W);  // wave-uniform: lands in SGPRs
-#pragma unroll
-    for (int k = 0; k < SCATTER_TPL; ++k) {
-        if (s[k].mask) {
-            unsigned bit = 1u;
-            for (int j = 0; j < s[k].nyp; ++j)
-                for (int i = 0; i < s[k].nxp; ++i, bit <<= 1) {
-                    if (!(s[k].mask & bit)) continue;
-                    float zw;
-                    const float fx = __fmaf_rn((float)(s[k].px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(s[k].py0 + j), ndc.ys, ndc.yo);
-                    if (pixel_depth(p0[k], p1[k], p2[k], fx, fy, zw)) {
-                        unsigned long long* zp = Z + (size_t)(s[k].py0 + j) * W + s[k].px0 + i;
-                        const unsigned long long key = ((unsigned long long)depth_key(zw) << 32) | (unsigned)s[k].t;
-                        atomicMin(zp, key);  // (an early-z hint load in front of it was measured: +11 us, the dependent load stalls the lane)
-                    }
-                }
-        }
+        ok[k] = t[k] < T && (unsigned)i0[k] < (unsigned)V && (unsigned)i1[k] < (unsigned)V && (unsigned)i2[k] < (unsigned)V;
+        const int j0 = ok[k] ? i0[k] : 0, j1 = ok[k] ? i1[k] : 0, j2 = ok[k] ? i2[k] : 0;
+        va[k] = S[j0]; vb[k] = S[j1]; vc[k] = S[j2];
     }
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
-        if (s[k].t >= T) continue;
-        unsigned range = ~0u;  // packed tile range of a LARGE triangle
-        if (s[k].alive) {
-            int* flag = L.tile_flag + (size_t)b * L.NT;
-            for (int ty = s[k].ty0; ty <= s[k].ty1; ++ty)
-                for (int tx = s[k].tx0; tx <= s[k].tx1; ++tx) flag[ty * L.ntx + tx] = 1;  // plain store, no atomics
-            if (!s[k].small) {
-                int* big = L.tile_big + (size_t)b * L.NT;
-                for (int ty = s[k].ty0; ty <= s[k].ty1; ++ty)
-                    for (int tx = s[k].tx0; tx <= s[k].tx1; ++tx) big[ty * L.ntx + tx] = 1;
-                range = (unsigned)s[k].tx0 | ((unsigned)s[k].ty0 << 8) | ((unsigned)(s[k].tx1 - s[k].tx0) << 16) |
-                        ((unsigned)(s[k].ty1 - s[k].ty0) << 24);
-                L.counters[3] = 1;  // plain store: "the batch has a large triangle"
-            }
-        }
-        L.trirange[(size_t)b * T + s[k].t] = range;
+        if (t[k] >= T) continue;
+        if (!ok[k]) { L.trirange[(size_t)b * T + t[k]] = ~0u; continue; }
+        scatter_one(pos, V, T, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k]);
     }
 }
 

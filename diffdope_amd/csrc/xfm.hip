@@ -137,15 +137,18 @@ __global__ __launch_bounds__(XFM_BLOCK) void xfm_bwd_mtx_kernel(const float* __r
         // each wave walks 16 vertices per MFMA: block q = lane/4 owns vertex base+q, lane%4 = channel
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int ch = lane & 3, q = lane >> 2;
-        for (int base = n_begin + wave * 16; base < n_end; base += 64) {
-            const int n = base + q;
-            const bool live = n < n_end;
-            float a = 0.f, bq = 0.f;
-            if (live) {
-                if (ch < R) a = G[(size_t)n * R + ch];
-                bq = (ch < 3) ? P[(size_t)n * 3 + ch] : (POINTS ? 1.0f : 0.0f);
+        // 8 MFMA steps per trip, all 16 loads of a trip issued before the first MFMA consumes one
+        for (int base0 = n_begin + wave * 16; base0 < n_end; base0 += 64 * 8) {
+            float a[8], bq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = base0 + u * 64 + q;
+                const bool live = n < n_end;
+                a[u] = (live && ch < R) ? G[(size_t)n * R + ch] : 0.f;
+                bq[u] = live ? ((ch < 3) ? P[(size_t)n * 3 + ch] : (POINTS ? 1.0f : 0.0f)) : 0.f;
             }
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bq, acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u], bq[u], acc, 0, 0, 0);
         }
         // fold the 16 blocks: lanes with equal lane%4 across lane/4
         float v[4] = {acc.x, acc.y, acc.z, acc.w};
