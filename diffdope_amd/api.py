@@ -5,8 +5,8 @@ the loss functions and pose helpers -- without trimesh / cv2 / pyrr / hydra / nv
 What differs on purpose ("Logging semantics"):
   * `set_batchsize` makes stride-0 batch VIEWS (`expand`) instead of B physical copies of the mesh,
     texture and images (diffdope.py:875-893,1176); shapes are unchanged;
-  * `run_optimization` takes the fused engine when every loss function is a built-in one (a single
-    hipGraph-replayed launch chain per iteration, no per-iteration device->host copies); any user loss
+  * `run_optimization` takes the fused engine when every loss function is a built-in one (four kernel
+    launches per iteration, no per-iteration device->host copies); any user loss
     function switches to the op-by-op autograd path, which behaves like the reference's loop;
   * `optimization_results[i]` always holds "mtx"; "rgb"/"depth"/"mask" are rendered on first access from
     the stored pose instead of being copied to the host every iteration (diffdope.py:1698-1703).
@@ -520,14 +520,54 @@ class DiffDope:
         return {k: out[k].detach().cpu() for k in ("rgb", "depth", "mask")}
 
     def render_img(self, index=None, batch_index=None, render_selection="rgb"):
-        """The render of iteration `index` (default last) for hypothesis `batch_index` (default argmin) as an
-        upright uint8 RGB numpy image (the reference's overlays / crops / grids are presentation code and not
-        reproduced)."""
+        """Overlay of the render of iteration `index` (default: last) on the observed image, as an upright uint8
+        RGB numpy image: one hypothesis (`batch_index`) or, with batch_index=None, a grid of all of them.
+        Honours cfg.render_images.{nrow, add_background, alpha_overlay, flip_result, crop_around_mask} when the
+        config has them (diffdope.py:1377-1486; contours are not drawn)."""
+        from . import viz
+
+        ri = self.cfg.get("render_images", {}) if isinstance(self.cfg, dict) else {}
         index = -1 if index is None else index
-        b = int(self.get_argmin()) if batch_index is None else batch_index
-        img = self.optimization_results[index][render_selection][b]
-        img = img if img.dim() == 3 else img[..., None].expand(-1, -1, 3) / max(float(img.max()), 1e-6)
-        return (img.flip(0).clamp(0, 1) * 255).byte().numpy()
+        entry = self.optimization_results[index]
+        fg_all = entry[render_selection]
+        bg_all = self.gt_tensors.get(render_selection)
+        which = range(fg_all.shape[0]) if batch_index is None else [int(batch_index)]
+        crop = None
+        if ri.get("crop_around_mask", False):
+            src = self.gt_tensors["segmentation"][0].cpu() if "segmentation" in self.gt_tensors else fg_all[0]
+            crop = viz.find_crop(src.numpy())
+        tiles = []
+        for b in which:
+            fg = fg_all[b].numpy()
+            bg = None if bg_all is None else bg_all[b].cpu().numpy()
+            if crop is not None:
+                r0, c0, sz = crop
+                fg = fg[r0:r0 + sz + 1, c0:c0 + sz + 1]
+                bg = None if bg is None else bg[r0:r0 + sz + 1, c0:c0 + sz + 1]
+            im = viz.overlay(bg, fg, alpha=ri.get("alpha_overlay", 0.7), add_background=ri.get("add_background", True))
+            tiles.append(im[::-1] if ri.get("flip_result", True) else im)
+        img = tiles[0] if len(tiles) == 1 else viz.make_grid(tiles, nrow=ri.get("nrow", 4))
+        return viz.to_uint8(img)
+
+    def make_animation(self, output_file_path="animation.gif", frame_rate=10, batch_index=-1):
+        """One frame per iteration of hypothesis `batch_index` (argmin if -1), written as a GIF through PIL (the
+        reference writes mp4 through imageio/libx264, diffdope.py:1515-1552)."""
+        from . import viz
+
+        if batch_index == -1:
+            batch_index = int(self.get_argmin())
+        frames = [self.render_img(index=i, batch_index=batch_index) for i in range(len(self.optimization_results))]
+        return viz.save_gif(frames, output_file_path, fps=frame_rate)
+
+    def plot_losses(self, keys=None, batch_index=-1):
+        """Loss curves of one hypothesis as an RGB image array (diffdope.py:1573-1616); None before a run."""
+        from . import viz
+
+        if len(self.losses_values) == 0:
+            return None
+        if batch_index == -1:
+            batch_index = int(self.get_argmin())
+        return viz.plot_losses(self.losses_values, batch_index, keys)
 
     # ---- optimisation ----------------------------------------------------------------------------
     def lr_schedule(self):

@@ -25,7 +25,7 @@ def main():
     try:
         from PIL import Image as PILImage
 
-        PILImage.fromarray(ddope.render_img()).save("simple_scene_render.png")
+        PILImage.fromarray(ddope.render_img(batch_index=int(ddope.get_argmin()))).save("simple_scene_render.png")
         print("wrote simple_scene_render.png")
     except Exception as e:  # presentation only
         print("render_img skipped:", e)

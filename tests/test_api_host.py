@@ -173,3 +173,21 @@ def test_bop_pose_json_reader(tmp_path):
         np.testing.assert_allclose(o["R"] @ o["R"].T, np.eye(3), atol=1e-6)
         q = api.quat_from_matrix(o["R"])
         np.testing.assert_allclose(api.matrix_from_quat(q), o["R"], atol=1e-6)
+
+
+def test_viz_helpers():
+    from diffdope_amd import viz
+
+    m = np.zeros((40, 60))
+    m[10:20, 30:45] = 1
+    r0, c0, sz = viz.find_crop(m)
+    assert r0 <= 10 and c0 <= 30 and r0 + sz >= 19 and c0 + sz >= 44
+    bg = np.full((8, 8, 3), 0.5, np.float32)
+    fg = np.zeros((8, 8, 3), np.float32)
+    fg[2:4, 2:4] = 1.0
+    o = viz.overlay(bg, fg, alpha=0.5)
+    assert abs(o[0, 0, 0] - 0.5) < 1e-6 and abs(o[2, 2, 0] - 0.75) < 1e-6
+    g = viz.make_grid([o] * 5, nrow=4)
+    assert g.shape[0] > 16 and g.shape[1] > 32
+    img = viz.plot_losses({"mask_selection": np.random.rand(5, 3)}, 1)
+    assert img.ndim == 3 and img.dtype == np.uint8

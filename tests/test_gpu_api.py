@@ -49,8 +49,16 @@ def test_fused_and_autograd_paths_agree_and_results_api():
     # images are rendered on demand from the stored poses and agree between the two paths
     ra, rb = a.optimization_results[-1]["rgb"], b.optimization_results[-1]["rgb"]
     assert tuple(ra.shape) == (B, 60, 80, 3) and float((ra - rb).abs().max()) < 5e-2
-    img = a.render_img()
+    img = a.render_img(batch_index=0)
     assert img.shape == (60, 80, 3) and img.dtype == np.uint8
+    grid = a.render_img()
+    assert grid.ndim == 3 and grid.shape[0] > 60 and grid.shape[1] > 80 * 3
+    curves = a.plot_losses()
+    assert curves.ndim == 3 and curves.shape[2] == 3
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = a.make_animation(os.path.join(td, "anim.gif"))
+        assert os.path.getsize(out) > 1000
 
 
 def test_user_loss_function_forces_the_autograd_path():
