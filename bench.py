@@ -114,7 +114,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    used = [i for i, k in enumerate(("rgb", "depth", "mask")) if w["weights"].get(k) is not None]
+    used = [i for i, k in enumerate(("rgb", "depth", "mask", "edge")) if w["weights"].get(k) is not None]
 
     def select_best(it):
         # the one collective of the job: global arg-min hypothesis + its pose (diffdope.py:1488-1513,1618-1632)

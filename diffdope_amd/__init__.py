@@ -26,6 +26,7 @@ from .api import (  # noqa: F401
     Scene,
     dist_batch_lr,
     l1_depth_with_mask,
+    l1_edge,
     l1_mask,
     l1_rgb_with_mask,
     load_config,

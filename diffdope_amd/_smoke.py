@@ -16,7 +16,7 @@ def run():
     proj = orc.projection_matrix(**syn.camera_intrinsics(W, H)).astype(np.float32)
     rng = np.random.RandomState(2)
     q_gt, t_gt = syn.random_quat(rng), np.array([0.09, -0.05, -1.8])
-    weights = dict(rgb=0.7, depth=1.0, mask=1.0)
+    weights = dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.5)
     R = orc.RenderOracle(pos, tri, proj, H, W, {}, weights, uv=uv, tex=tex, dtype=np.float32)
     r = R.render(orc.pose_fwd(np.concatenate([q_gt, t_gt])[:, None].astype(np.float32)))
     cov = r["rast"][0, ..., 3] > 0
@@ -42,6 +42,6 @@ def run():
     g = (params - p.cpu().numpy()) / 0.5
     np.testing.assert_allclose(g, g_ref, rtol=2e-3, atol=2e-3 * np.abs(g_ref).max())
     lg = eng.losses()[0].cpu().numpy()
-    for i, k in enumerate(("rgb", "depth", "mask_selection")):
+    for i, k in enumerate(("rgb", "depth", "mask_selection", "edge")):
         np.testing.assert_allclose(lg[i], logs[k], rtol=2e-5, atol=1e-7)
     print("smoke ok: ids bit-identical, losses and pose gradients match the oracle; max |grad| =", float(np.abs(g).max()))

@@ -129,8 +129,33 @@ def l1_mask(ddope):
     return lr_diff_mask.mean() * ddope.cfg.losses.weight_mask
 
 
-_BUILTIN_LOSSES = {l1_rgb_with_mask: "rgb", l1_depth_with_mask: "depth", l1_mask: "mask"}
-_LOG_KEYS = {"rgb": "rgb", "depth": "depth", "mask": "mask_selection"}
+_SOBEL = None
+
+
+def _sobel_xy(img):
+    """[B,H,W,3] -> [B,2,H,W]: Sobel gradients (coefficients / 8, zero padding) of the luminance (r+g+b)/3."""
+    global _SOBEL
+    if _SOBEL is None or _SOBEL.device != img.device:
+        kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], device=img.device) / 8.0
+        _SOBEL = torch.stack([kx, kx.t()])[:, None].contiguous()
+    lum = ((img[..., 0] + img[..., 1]) + img[..., 2]) * (1.0 / 3.0)
+    return torch.nn.functional.conv2d(lum[:, None], _SOBEL.to(img.dtype), padding=1)
+
+
+def l1_edge(ddope):
+    """EXTENSION -- the reference has no edge loss (BASELINE configs 3/5 name one).  L1 between the Sobel
+    gradients of the luminance of the rendered colour image and of the observed image masked by its
+    segmentation (both "object on black"); definition shared with oracle/ddx_oracle.c:orc_loss_edge and the
+    fused engine.  Enabled by cfg.losses.l1_edge / weight_edge."""
+    w = float(ddope.cfg.losses.get("weight_edge", 1.0))
+    diff = torch.abs(_sobel_xy(ddope.renders["rgb"]) - _sobel_xy(ddope.gt_tensors["rgb"] * ddope.gt_tensors["segmentation"]))
+    lr_diff = dist_batch_lr(diff, ddope.learning_rates)
+    ddope.add_loss_value("edge", torch.mean(diff.detach(), (1, 2, 3)) * w)
+    return lr_diff.mean() * w
+
+
+_BUILTIN_LOSSES = {l1_rgb_with_mask: "rgb", l1_depth_with_mask: "depth", l1_mask: "mask", l1_edge: "edge"}
+_LOG_KEYS = {"rgb": "rgb", "depth": "depth", "mask": "mask_selection", "edge": "edge"}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -469,6 +494,8 @@ class DiffDope:
             self.loss_functions.append(l1_depth_with_mask)
         if self.cfg.losses.l1_mask:
             self.loss_functions.append(l1_mask)
+        if self.cfg.losses.get("l1_edge", False):  # extension, absent from the reference's yaml
+            self.loss_functions.append(l1_edge)
         self.last_engine = None
         log.info(f"batchsize is {self.batchsize}")
 
@@ -583,7 +610,7 @@ class DiffDope:
         if fused is None:
             fused = builtin
         if fused and not builtin:
-            raise RuntimeError("the fused engine only knows l1_rgb_with_mask / l1_depth_with_mask / l1_mask")
+            raise RuntimeError("the fused engine only knows l1_rgb_with_mask / l1_depth_with_mask / l1_mask / l1_edge")
         if fused:
             self._run_fused(optimizer, global_batch)
         else:
@@ -595,7 +622,8 @@ class DiffDope:
         weights = {}
         for f in self.loss_functions:
             k = _BUILTIN_LOSSES[f]
-            weights[k] = float({"rgb": lw.weight_rgb, "depth": lw.weight_depth, "mask": lw.weight_mask}[k])
+            weights[k] = float({"rgb": lw.weight_rgb, "depth": lw.weight_depth, "mask": lw.weight_mask,
+                                "edge": lw.get("weight_edge", 1.0)}[k])
         params = self.object3d.params_tensor()
         gt = {k: v[0] for k, v in self.gt_tensors.items()}
         tex = dict(uv=r["uv"][0], tex=r["tex"][0]) if self.object3d.mesh.has_textured_map else dict(vtx_color=r["vtx_color"][0])
@@ -605,7 +633,7 @@ class DiffDope:
         eng.check()
         self.object3d.load_params_tensor(params)
         losses = eng.losses().cpu()
-        for i, k in enumerate(("rgb", "depth", "mask")):
+        for i, k in enumerate(("rgb", "depth", "mask", "edge")):
             if k in weights:
                 self.losses_values[_LOG_KEYS[k]] = losses[:, i].clone()
         mtx = eng.mtx_log.reshape(eng.max_iters, self.batchsize, 4, 4).cpu()

@@ -34,7 +34,9 @@
 
 #include "raster.h"
 
-#define NPART 24  // floats per tile partial: 12 dFinal(x,y,w rows) | 4 dMtx row 2 | 3 losses | pad
+#define NPART 24  // floats per tile partial: 12 dFinal(x,y,w rows) | 4 dMtx row 2 | 4 losses (rgb, depth, mask, edge) | pad
+#define NVALS 20  // of which are used
+#define MAX_ROLES 3
 
 struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_status_ptr exposes
     int overflow;
@@ -46,6 +48,7 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int pad[2];
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
+    double c_edge;   // sum over the frame of |Gx| + |Gy| of the observed, masked image (edge extension)
 };
 
 struct EngineDev {
@@ -54,13 +57,16 @@ struct EngineDev {
     RasterScratch L;
     float* clip;      // [B,V,4]
     float* mats;      // [B,2,16]: mtx | final
-    float* partials;  // [B*NT*4*2, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*2 + role
+    float* partials;  // [B*NT*4*NR, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*NR + role, NR = 2 (3 with the edge role)
+    float2* gtedge;   // [H*W] Sobel gradients of lum(gt_rgb * seg) (edge extension), or null
     float* adam;      // [2,7,B]
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     EngineState* st;
-    int st_role;      // shade role that advances the iteration counter (0 if colour/depth terms are on, else 1)
-    int n_roles;      // 1 or 2 shade launches per iteration
+    int st_role;      // shade role that advances the iteration counter (= roles[0])
+    int n_roles;      // enabled shade roles (grid z of shade_kernel): 0 colour+depth, 1 antialiased mask, 2 edge
+    int roles[MAX_ROLES];    // grid z -> role
+    int role_mask;           // bit r set = role r runs
 };
 
 struct ddx_engine {
@@ -89,7 +95,8 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
-    const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * 2 * NPART * sizeof(float));  // per 8x8 quadrant and shade role
+    const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * MAX_ROLES * NPART * sizeof(float));  // per 8x8 quadrant and shade role
+    const size_t o_edge = carve(d.use_edge ? (size_t)d.H * d.W * sizeof(float2) : 0);
     const size_t o_rast = carve(0);
     const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W);
     off += rast_bytes;
@@ -100,6 +107,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.seglist = (float2*)(p + o_seg);
     E.trirec = (int4*)(p + o_rec);
     E.partials = (float*)(p + o_part);
+    E.gtedge = d.use_edge ? (float2*)(p + o_edge) : nullptr;
     return off;
 }
 
@@ -153,6 +161,54 @@ __global__ __launch_bounds__(1024) void setup_kernel(EngineDev E)
         E.st->c_rgb = a;
         E.st->c_mask = bq;
         E.st->n_seg = carry;
+    }
+}
+
+// Edge extension (no reference counterpart; definition: oracle/ddx_oracle.c orc_loss_edge): Sobel gradients of the
+// luminance of the observed image masked by its segmentation, and their whole-frame L1 norm.  One workgroup,
+// fixed-shape reduction.
+__device__ __forceinline__ float lum3(float r, float g, float b) { return ((r + g) + b) * (1.0f / 3.0f); }
+
+__device__ __forceinline__ void sobel3(const float v[3][3], float& gx, float& gy)
+{
+    gx = (((v[0][2] - v[0][0]) + 2.0f * (v[1][2] - v[1][0])) + (v[2][2] - v[2][0])) * 0.125f;
+    gy = (((v[2][0] - v[0][0]) + 2.0f * (v[2][1] - v[0][1])) + (v[2][2] - v[0][2])) * 0.125f;
+}
+
+__global__ __launch_bounds__(1024) void edge_setup_kernel(EngineDev E)
+{
+    const int H = E.d.H, W = E.d.W, n = H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = tid; i < n; i += 1024) {
+        const int y = i / W, x = i - y * W;
+        float v[3][3];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                float l = 0.f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const size_t q = ((size_t)yy * W + xx) * 3;
+                    l = lum3(E.b.gt_rgb[q] * E.b.gt_seg[q], E.b.gt_rgb[q + 1] * E.b.gt_seg[q + 1], E.b.gt_rgb[q + 2] * E.b.gt_seg[q + 2]);
+                }
+                v[dy + 1][dx + 1] = l;
+            }
+        float gx, gy;
+        sobel3(v, gx, gy);
+        E.gtedge[i] = make_float2(gx, gy);
+        s += (double)(fabsf(gx) + fabsf(gy));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0;
+        for (int w = 0; w < 16; ++w) a += red[w];
+        E.st->c_edge = a;
     }
 }
 
@@ -264,7 +320,7 @@ __device__ __forceinline__ float sgnf(float x) { return (float)((x > 0.f) - (x <
 struct PixAcc {
     float dF[12];  // rows x,y,w of d loss / d final
     float dM2[4];  // d loss / d mtx[2][:]
-    float L[3];    // rgb, depth, mask loss sums (actual - background)
+    float L[4];    // rgb, depth, mask, edge loss sums (actual - background)
 };
 
 __device__ __forceinline__ void acc_vertex(PixAcc& A, const float* __restrict__ pos, int v, float gx, float gy, float gw)
@@ -418,17 +474,88 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     }
 }
 
+// Edge role: luminance of the rendered colour at pixel (px,py), covered by triangle t, and U = d lum / d final (rows
+// x,y,w), i.e. the whole chain lum -> colour -> (texture ->) uv -> barycentrics -> clip vertices -> final, per unit
+// d loss / d lum.  The backward of the edge term is linear in d loss / d lum, so the pixel keeps 12 numbers and
+// the pass after the Sobel stage is 12 FMAs with no memory access (same trick as AAUnit).
+__device__ __forceinline__ float lum_unit(const EngineDev& E, const float* __restrict__ P, int t, int px, int py, float U[12])
+{
+    const ddx_engine_desc& d = E.d;
+    const float* __restrict__ pos = E.b.pos;
+    const int* __restrict__ tri = E.b.tri;
+    const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
+    const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
+    Bary bc;
+    pixel_bary(p0, p1, p2, px, py, d.H, d.W, bc);
+    const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
+    const float third = 1.0f / 3.0f;
+    float gu = 0.f, gv = 0.f, col[3];
+    if (d.Th > 0) {
+        const float* uv = E.b.uv;
+        const float a0x = uv[(size_t)v0 * 2], a0y = uv[(size_t)v0 * 2 + 1];
+        const float a1x = uv[(size_t)v1 * 2], a1y = uv[(size_t)v1 * 2 + 1];
+        const float a2x = uv[(size_t)v2 * 2], a2y = uv[(size_t)v2 * 2 + 1];
+        const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x));
+        const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
+        TexelSetup ts;
+        tex_setup(tu, tv, d.Th, d.Tw, ts);
+        const float* TX = E.b.tex;
+        const float *t00 = TX + ((size_t)ts.y0 * d.Tw + ts.x0) * 3, *t10 = TX + ((size_t)ts.y0 * d.Tw + ts.x1) * 3,
+                    *t01 = TX + ((size_t)ts.y1 * d.Tw + ts.x0) * 3, *t11 = TX + ((size_t)ts.y1 * d.Tw + ts.x1) * 3;
+        float gU = 0.f, gV = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
+            const float a = __fmaf_rn(ts.fx, c10 - c00, c00);
+            const float bq = __fmaf_rn(ts.fx, c11 - c01, c01);
+            col[c] = __fmaf_rn(ts.fy, bq - a, a);
+            gU = __fmaf_rn(third, __fmaf_rn(ts.fy, (c11 - c01) - (c10 - c00), c10 - c00), gU);
+            gV = __fmaf_rn(third, __fmaf_rn(ts.fx, (c11 - c10) - (c01 - c00), c01 - c00), gV);
+        }
+        gU *= (float)d.Tw;
+        gV *= (float)d.Th;
+        gu = gU * (a0x - a2x) + gV * (a0y - a2y);
+        gv = gU * (a1x - a2x) + gV * (a1y - a2y);
+    } else {
+        const float* vc = E.b.vtx_color;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float c0 = vc[(size_t)v0 * 3 + c], c1 = vc[(size_t)v1 * 3 + c], c2 = vc[(size_t)v2 * 3 + c];
+            col[c] = __fmaf_rn(w2, c2, __fmaf_rn(v, c1, u * c0));
+            gu = __fmaf_rn(third, c0 - c2, gu);
+            gv = __fmaf_rn(third, c1 - c2, gv);
+        }
+    }
+    if (gu != 0.f || gv != 0.f) {
+        float gx[3], gy[3], gw[3];
+        bary_backward(bc, gu, gv, gx, gy, gw);
+        PixAcc T;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T.dF[i] = 0.f;
+        acc_vertex(T, pos, v0, gx[0], gy[0], gw[0]);
+        acc_vertex(T, pos, v1, gx[1], gy[1], gw[1]);
+        acc_vertex(T, pos, v2, gx[2], gy[2], gw[2]);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) U[i] = T.dF[i];
+    }
+    return lum3(col[0], col[1], col[2]);
+}
+
 // ROLE 0: colour + depth terms (per covered pixel).  ROLE 1: antialiased-coverage (mask) term (silhouette
 // pairs).  The two roles only share the zbuf they read, so they are separate workgroups of ONE launch
 // (blockIdx.z picks the role): they overlap on the chip, and each body keeps its own, smaller register
 // footprint instead of the union of both.  Each role writes its own partial per quadrant.
-template <int ROLE>
+// ROLE 2: edge term (extension): the wave owns the Sobel loss terms of its 8x8 quadrant, shades the luminance of
+// the 10x10 halo those terms read, and backpropagates into all 100 halo pixels (the neighbouring quadrants add
+// their own terms' share for the same pixels -- the chain is linear).
+template <int ROLE, int NR>
 __device__ __forceinline__ void shade_body(const EngineDev& E)
 {
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
     __shared__ float s_gm[WAVES_PER_TILE][64];          // d loss / d mask of each pixel
-    __shared__ unsigned short s_pairs[WAVES_PER_TILE][PAIR_CAP];
+    __shared__ unsigned short s_pairs[WAVES_PER_TILE][ROLE == 1 ? PAIR_CAP : 4];
+    __shared__ float s_lum[WAVES_PER_TILE][ROLE == 2 ? QH * QH + 4 : 4];
     const ddx_engine_desc& d = E.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W, V = d.V;
@@ -448,7 +575,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
         const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
-        float* part = E.partials + (((size_t)flat * WAVES_PER_TILE + wave) * 2 + ROLE) * NPART;
+        float* part = E.partials + (((size_t)flat * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
         // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
         bool anycov = false;
 #pragma unroll
@@ -477,7 +604,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
         for (int i = 0; i < 12; ++i) A.dF[i] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) A.dM2[i] = 0.f;
-        A.L[0] = A.L[1] = A.L[2] = 0.f;
+        A.L[0] = A.L[1] = A.L[2] = A.L[3] = 0.f;
         const float lrb = E.b.lr_mult[b];
         const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -671,20 +798,85 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             }
             wave_lds_sync();
         }
+        if (ROLE == 2) {
+            // ---- A: luminance + unit gradient of the 100 halo pixels, two rounds of lanes (halo index e, 64 + e)
+            float U0[12], U1[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { U0[i] = 0.f; U1[i] = 0.f; }
+            float l0 = 0.f, l1 = 0.f;
+            {
+                const int t = ids[lane] - 1;
+                if (t >= 0) l0 = lum_unit(E, P, t, qx - 1 + lane % QH, qy - 1 + lane / QH, U0);
+            }
+            const int e1 = 64 + lane;
+            if (e1 < QH * QH) {
+                const int t = ids[e1] - 1;
+                if (t >= 0) l1 = lum_unit(E, P, t, qx - 1 + e1 % QH, qy - 1 + e1 / QH, U1);
+                s_lum[wave][e1] = l1;
+            }
+            s_lum[wave][lane] = l0;
+            wave_lds_sync();
+            // ---- B: the quadrant's Sobel terms (zero padding = the halo's zeros outside the image)
+            float cx = 0.f, cy = 0.f;
+            if (id >= 0) {
+                const float* Lm = s_lum[wave];
+                float v[3][3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) v[dy][dx] = Lm[hidx + (dy - 1) * QH + (dx - 1)];
+                float gx, gy;
+                sobel3(v, gx, gy);
+                const float2 g = E.gtedge[pix];
+                const float ex = gx - g.x, ey = gy - g.y;
+                A.L[3] += (fabsf(ex) + fabsf(ey)) - (fabsf(g.x) + fabsf(g.y));
+                const float k = d.w_edge * lrb * inv_b / (2.0f * (float)H * (float)W) * 0.125f;
+                cx = k * sgnf(ex);
+                cy = k * sgnf(ey);
+            }
+            s_m[wave][lane] = cx;
+            s_gm[wave][lane] = cy;
+            wave_lds_sync();
+            // ---- C: d loss / d lum of every halo pixel from the quadrant's terms, times the unit gradient
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int e = r * 64 + lane;
+                if (e < QH * QH) {
+                    const int ex = e % QH - 1, ey = e / QH - 1;
+                    float g = 0.f;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int nx = ex - dx, ny = ey - dy;  // loss pixel whose (dy,dx) neighbour is e
+                            if (nx >= 0 && nx < QUAD && ny >= 0 && ny < QUAD) {
+                                const int n = ny * QUAD + nx;
+                                g = __fmaf_rn(s_m[wave][n], (float)(dx * (2 - (dy < 0 ? -dy : dy))), g);
+                                g = __fmaf_rn(s_gm[wave][n], (float)(dy * (2 - (dx < 0 ? -dx : dx))), g);
+                            }
+                        }
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) A.dF[i] = __fmaf_rn(g, r == 0 ? U0[i] : U1[i], A.dF[i]);
+                }
+            }
+            wave_lds_sync();
+            s_m[wave][lane] = 0.f;
+        }
         // ---- wave reduction -> one partial per quadrant (fixed order: bit-reproducible)
-        float vals[19];
+        constexpr int NV = NR == 3 ? NVALS : NVALS - 1;  // the edge loss slot only exists in the edge build
+        float vals[NVALS];
 #pragma unroll
         for (int i = 0; i < 12; ++i) vals[i] = A.dF[i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) vals[12 + i] = A.dM2[i];
-        vals[16] = A.L[0]; vals[17] = A.L[1]; vals[18] = A.L[2];
+        vals[16] = A.L[0]; vals[17] = A.L[1]; vals[18] = A.L[2]; vals[19] = A.L[3];
         float mine = 0.f;
         bool nz = false;
 #pragma unroll
-        for (int i = 0; i < 19; ++i) nz |= vals[i] != 0.f;
+        for (int i = 0; i < NV; ++i) nz |= vals[i] != 0.f;
         if (__ballot(nz) != 0ull) {  // e.g. mask role on an interior quadrant: every term is exactly zero
 #pragma unroll
-            for (int i = 0; i < 19; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const float s = wave_sum(vals[i]);
                 if (lane == i) mine = s;
             }
@@ -693,11 +885,16 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     }
 }
 
+// Two builds of the same kernel: without and with the edge role, so that the register allocation (and scratch
+// footprint) of the reference-loss configurations does not depend on the extension.
+template <bool EDGE>
 __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
 {
-    const int role = E.n_roles == 2 ? (int)blockIdx.z : E.st_role;
-    if (role == 0) shade_body<0>(E);
-    else shade_body<1>(E);
+    const int z = blockIdx.z;
+    const int role = EDGE ? (z == 0 ? E.roles[0] : (z == 1 ? E.roles[1] : E.roles[2])) : (E.n_roles == 2 ? z : E.st_role);
+    if (role == 0) shade_body<0, EDGE ? 3 : 2>(E);
+    else if (role == 1) shade_body<1, EDGE ? 3 : 2>(E);
+    else if (EDGE) shade_body<2, 3>(E);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -709,6 +906,7 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
 // over the slices.
 #define UPD_SLICES 8
 
+template <int NR>
 __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 {
     const ddx_engine_desc& d = E.d;
@@ -733,7 +931,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     // ---- this hypothesis' active tiles come ordered by tile index (compact_big_kernel): sum their quadrant
     // partials in that fixed order (bit-reproducible); re-arm what the iteration dirtied (zbuf of the active
     // tiles, their flags) so that the next iteration needs no memset -- tile k is re-armed by slice k % UPD_SLICES.
-    const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < 19 of group g sums value j
+    const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < NVALS of group g sums value j
     float acc = 0.f;
     const int n_act = E.L.b_count[b];
     const int* tiles = E.L.active + (size_t)b * NT;
@@ -751,18 +949,20 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         }
         __syncthreads();
         const int na = min(256, n_act - start);
-        if (j < 19) {
-            // slots = (tile, quadrant, role) in fixed order; loads are issued 8 at a time before they are
+        if (j < NVALS) {
+            // slots = (tile, quadrant, role slot) in fixed order; loads are issued 8 at a time before they are
             // consumed (a load-add-load-add chain would pay one L2 round trip per slot)
-            const int nslot = na * 8;
-            const bool both = E.n_roles == 2;
+            constexpr int PER = 4 * NR;  // slots per tile
+            const int nslot = na * PER;
+            const int rmask = E.role_mask;
             for (int s0 = grp; s0 < nslot; s0 += 64) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int s = s0 + u * 8;
-                    const bool ok = s < nslot && (both || (s & 1) == E.st_role);
-                    v[u] = ok ? E.partials[((size_t)(b * NT + s_tidx[s >> 3]) * 8 + (s & 7)) * NPART + j] : 0.f;
+                    const int ti = s / PER, within = s % PER;
+                    const bool ok = s < nslot && ((rmask >> (within % NR)) & 1);
+                    v[u] = ok ? E.partials[((size_t)(b * NT + s_tidx[ti]) * PER + within) * NPART + j] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += v[u];
@@ -806,12 +1006,13 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         const float npx = (float)d.H * (float)d.W;
         const float lrb = sc[7];
         // loss log: weighted, not LR-scaled (diffdope.py:558-560,576-578,604-608)
-        if (writer && lane < 3 && E.b.loss_log) {
+        if (writer && lane < 4 && E.b.loss_log) {
             float v = 0.f;
             if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
             if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
             if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
-            E.b.loss_log[((size_t)it * 3 + lane) * B + b] = v;
+            if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
+            E.b.loss_log[((size_t)it * 4 + lane) * B + b] = v;
         }
         // d loss / d mtx = proj^T . dFinal (+ direct depth row): lane = k*4 + j
         if (lane < 16) {
@@ -948,10 +1149,12 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
     {
         dim3 g = shade_grid(d);
         g.z = E.n_roles;
-        shade_kernel<<<g, 256, 0, s>>>(E);
+        if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E);
+        else shade_kernel<false><<<g, 256, 0, s>>>(E);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
-    update_xfm_kernel<<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
+    if (d.use_edge) update_xfm_kernel<3><<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
+    else update_xfm_kernel<2><<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
     DDX_LAUNCH_CHECK();
     return 0;
@@ -984,13 +1187,31 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     DDX_REQUIRE(!desc->use_rgb || (b.gt_rgb && ((desc->Th > 0) ? (b.uv && b.tex) : (b.vtx_color != nullptr))), DDX_E_NULL,
                 "engine_create: rgb loss needs gt_rgb and (uv+tex | vtx_color)");
     DDX_REQUIRE(!desc->use_depth || b.gt_depth, DDX_E_NULL, "engine_create: depth loss needs gt_depth");
+    DDX_REQUIRE(!desc->use_edge || (b.gt_rgb && ((desc->Th > 0) ? (b.uv && b.tex) : (b.vtx_color != nullptr))), DDX_E_NULL,
+                "engine_create: edge loss needs gt_rgb and (uv+tex | vtx_color)");
     DDX_REQUIRE(((uintptr_t)b.scratch & 255) == 0, DDX_E_ALIGN, "engine_create: scratch must be 256-byte aligned");
     ddx_engine* e = new (std::nothrow) ddx_engine();
     DDX_REQUIRE(e, DDX_E_NULL, "engine_create: out of host memory");
     e->dev.d = *desc;
     e->dev.b = *bufs;
-    e->dev.st_role = (desc->use_rgb || desc->use_depth) ? 0 : 1;
-    e->dev.n_roles = ((desc->use_rgb || desc->use_depth) && desc->use_mask) ? 2 : 1;
+    {
+        EngineDev& E = e->dev;
+        const bool on[MAX_ROLES] = {desc->use_rgb || desc->use_depth, desc->use_mask != 0, desc->use_edge != 0};
+        E.n_roles = 0;
+        E.role_mask = 0;
+        for (int r = 0; r < MAX_ROLES; ++r) E.roles[r] = 0;
+        for (int r = 0; r < MAX_ROLES; ++r)
+            if (on[r]) {
+                E.role_mask |= 1 << r;
+                E.roles[E.n_roles++] = r;
+            }
+        if (E.n_roles == 0) {  // no term at all: run the mask role with weight 0 semantics (nothing to optimise)
+            E.n_roles = 1;
+            E.roles[0] = 1;
+            E.role_mask = 2;
+        }
+        E.st_role = E.roles[0];
+    }
     const size_t need = engine_layout(e->dev, *desc, b.scratch);
     if (b.scratch_bytes < need) {
         delete e;
@@ -1023,6 +1244,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
     trirec_kernel<<<ddx_cdiv(E.d.T, 256), 256, 0, s>>>(E);
+    if (E.d.use_edge) edge_setup_kernel<<<1, 1024, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
     e->setup_done = true;
     return 0;

@@ -23,7 +23,8 @@ class RefineEngine:
         params [7,B]: qx,qy,qz,qw,x,y,z (diffdope.py:1019-1026) -- updated in place
         lr_mult [B]: per-hypothesis loss multipliers (diffdope.py:1368-1375)
         lr_sched: list/1-D tensor of optimiser learning rates, one per iteration (diffdope.py:1657-1661)
-        weights: dict(rgb=, depth=, mask=) -- None/absent disables the term (cfg.losses)
+        weights: dict(rgb=, depth=, mask=, edge=) -- None/absent disables the term (cfg.losses); "edge" is this
+            build's extension (Sobel-gradient L1 of the luminance, no reference counterpart: oracle orc_loss_edge)
         global_batch: batch size of the whole job when hypotheses are sharded over GPUs
     """
 
@@ -54,15 +55,16 @@ class RefineEngine:
         self.lr_sched = torch.as_tensor(lr_sched, dtype=torch.float64).to(torch.float32).to(dev).contiguous()
         n_it = self.lr_sched.numel()
         self.max_iters = n_it
-        self.loss_log = torch.zeros((n_it, 3, B), dtype=torch.float32, device=dev)
+        self.loss_log = torch.zeros((n_it, 4, B), dtype=torch.float32, device=dev)
         self.mtx_log = torch.zeros((n_it, B, 16), dtype=torch.float32, device=dev) if log_mtx else None
-        w = {k: weights.get(k) for k in ("rgb", "depth", "mask")}
+        w = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
         d = _lib.EngineDesc()
         d.B, d.B_global = B, int(global_batch or B)
         d.V, d.T, d.H, d.W = self.pos.shape[0], self.tri.shape[0], H, W
         d.Th, d.Tw = (self.tex.shape[0], self.tex.shape[1]) if (self.tex is not None and self.vtx_color is None) else (0, 0)
         d.use_rgb, d.use_depth, d.use_mask = int(w["rgb"] is not None), int(w["depth"] is not None), int(w["mask"] is not None)
         d.w_rgb, d.w_depth, d.w_mask = float(w["rgb"] or 0), float(w["depth"] or 0), float(w["mask"] or 0)
+        d.use_edge, d.w_edge = int(w["edge"] is not None), float(w["edge"] or 0)
         d.optimizer = {"sgd": 0, "adam": 1}[optimizer]
         d.adam_beta1, d.adam_beta2, d.adam_eps = adam
         d.max_iters = n_it
@@ -120,7 +122,7 @@ class RefineEngine:
         return {names[i].decode(): float(ms[i]) for i in range(k)}
 
     def losses(self):
-        """[iters_done, 3, B] weighted un-LR'd per-hypothesis losses (rgb, depth, mask)."""
+        """[iters_done, 4, B] weighted un-LR'd per-hypothesis losses (rgb, depth, mask, edge)."""
         return self.loss_log[: self.it]
 
     def __del__(self):

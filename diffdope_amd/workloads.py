@@ -17,8 +17,10 @@ CONFIGS = {
     "cfg1": dict(rows=77, cols=90, B=1, H=120, W=160, textured=True, weights=dict(mask=1.0), tex=2048),
     # configs[1]: the configuration the headline metric is quoted on
     "cfg2": dict(rows=80, cols=128, B=64, H=480, W=640, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
-    # configs[2] without the edge loss (an extension with no reference counterpart)
-    "cfg3": dict(rows=160, cols=160, B=128, H=480, W=640, textured=True, weights=dict(rgb=0.7, depth=1.0), tex=2048),
+    # configs[2]: rgb + depth + edge (the edge term is this build's extension, no reference counterpart)
+    "cfg3": dict(rows=160, cols=160, B=128, H=480, W=640, textured=True, weights=dict(rgb=0.7, depth=1.0, edge=1.0), tex=2048),
+    # configs[2] restricted to the reference's own losses
+    "cfg3ref": dict(rows=160, cols=160, B=128, H=480, W=640, textured=True, weights=dict(rgb=0.7, depth=1.0), tex=2048),
     # configs[3]: per-GPU share of the 512-hypothesis untextured job
     "cfg4": dict(rows=100, cols=150, B=64, H=480, W=640, textured=False, weights=dict(depth=1.0, mask=1.0), tex=0),
     "tiny": dict(rows=16, cols=20, B=4, H=60, W=80, textured=True, weights=dict(rgb=0.7, depth=1.0, mask=1.0), tex=64),

@@ -121,6 +121,9 @@ int ddx_antialias_bwd(const float* color, int C, const float* rast, const float*
  * built-in losses (l1_rgb_with_mask / l1_depth_with_mask / l1_mask, diffdope.py:547-613):
  * pose -> matrices -> vertex transform -> tile binning/raster -> shade + loss + analytic backward
  * -> d loss / d(q,t) -> optimiser step, B hypotheses at a time, no G-buffer ever written to HBM.
+ * use_edge / w_edge add this build's EXTENSION term (the reference has no edge loss): L1 between the
+ * 3x3 Sobel/8 gradients (zero padding) of the luminance (r+g+b)/3 of the rendered colour image and of
+ * gt_rgb * gt_seg, mean over pixels and the two components (oracle/ddx_oracle.c:orc_loss_edge).
  * ------------------------------------------------------------------------------------------- */
 typedef struct ddx_engine_desc {
     int32_t B;        /* hypotheses on this device */
@@ -132,7 +135,9 @@ typedef struct ddx_engine_desc {
     int32_t optimizer; /* 0 = SGD (reference, diffdope.py:1363), 1 = Adam */
     float adam_beta1, adam_beta2, adam_eps;
     int32_t max_iters; /* rows available in lr_sched / loss_log / mtx_log */
-    int32_t reserved[8];
+    int32_t use_edge;  /* EXTENSION (no reference counterpart): Sobel-gradient L1 term, needs gt_rgb and a colour source */
+    float w_edge;
+    int32_t reserved[6];
 } ddx_engine_desc;
 
 typedef struct ddx_engine_buffers {
@@ -151,7 +156,7 @@ typedef struct ddx_engine_buffers {
     const float* lr_mult;    /* [B] per-hypothesis loss multipliers (diffdope.py:1368-1375) */
     const float* lr_sched;   /* [max_iters] optimiser lr per iteration (diffdope.py:1657-1664) */
     float* params;           /* [7,B] qx,qy,qz,qw,x,y,z -- read and updated in place */
-    float* loss_log;         /* [max_iters,3,B] weighted, un-LR'd per-hypothesis losses (rgb,depth,mask) */
+    float* loss_log;         /* [max_iters,4,B] weighted, un-LR'd per-hypothesis losses (rgb,depth,mask,edge) */
     float* mtx_log;          /* [max_iters,B,16] pose matrix used by each iteration's forward */
     void* scratch;
     size_t scratch_bytes;

@@ -247,6 +247,12 @@ def loss_mask(mask, seg, scale=None, want_grad=False):
     return _loss("mask", mask, None, seg, scale, want_grad)
 
 
+def loss_edge(rgb, gt_rgb, seg, scale=None, want_grad=False):
+    """EXTENSION, no reference counterpart (see orc_loss_edge): L1 between the Sobel gradients of the
+    luminance of the rendered colour image and of gt_rgb * seg."""
+    return _loss("edge", rgb, gt_rgb, seg, scale, want_grad)
+
+
 # --------------------------------------------------------------------------------------------
 # The op-by-op render graph of render_texture_batch (diffdope.py:156-234) and its reverse.
 class RenderOracle:
@@ -254,7 +260,8 @@ class RenderOracle:
 
     pos [V,3], tri [T,3], and either (uv [V,2], tex [Th,Tw,3]) or vtx_color [V,3];
     gt: dict with 'rgb' [H,W,3], 'depth' [H,W], 'segmentation' [H,W,3] (any subset);
-    weights: dict(rgb=, depth=, mask=) of floats or None to disable that term.
+    weights: dict(rgb=, depth=, mask=, edge=) of floats or None to disable that term ("edge" is this
+    build's extension, see orc_loss_edge).
     """
 
     def __init__(self, pos, tri, proj, H, W, gt, weights, uv=None, tex=None, vtx_color=None, dtype=np.float32):
@@ -322,6 +329,12 @@ class RenderOracle:
             per, d_mask = loss_mask(r["mask"], seg, lr_mult * dt.type(w["mask"] / GB), want_grad)
             logs["mask_selection"] = per * w["mask"]
             total += float(np.sum(per.astype(np.float64) * lr_mult) / GB * w["mask"])
+        if w.get("edge") is not None:
+            per, d_edge = loss_edge(r["rgb"], self.gt["rgb"], seg, lr_mult * dt.type(w["edge"] / GB), want_grad)
+            logs["edge"] = per * w["edge"]
+            total += float(np.sum(per.astype(np.float64) * lr_mult) / GB * w["edge"])
+            if want_grad:
+                d_rgb = d_edge if d_rgb is None else d_rgb + d_edge
         if not want_grad:
             return total, logs, None, r
         rast, tri = r["rast"], self.tri

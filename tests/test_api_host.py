@@ -191,3 +191,30 @@ def test_viz_helpers():
     assert g.shape[0] > 16 and g.shape[1] > 32
     img = viz.plot_losses({"mask_selection": np.random.rand(5, 3)}, 1)
     assert img.ndim == 3 and img.dtype == np.uint8
+
+
+def test_l1_edge_extension_matches_oracle_and_logs():
+    """l1_edge (this build's extension; the reference has no edge loss): the torch loss function of the
+    op-by-op path equals the oracle's definition, value and gradient, and logs the weighted per-hypothesis term."""
+    from types import SimpleNamespace
+
+    import diffdope_amd as dd
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(11)
+    B, h, w = 3, 10, 12
+    rgb, gt = rng.random((B, h, w, 3)), rng.random((1, h, w, 3))
+    seg = np.repeat((rng.random((1, h, w, 1)) > 0.4).astype(np.float64), 3, -1)
+    lr = np.array([0.3, 1.0, 2.5])
+    logged = {}
+    t_rgb = torch.tensor(rgb, requires_grad=True)
+    dp = SimpleNamespace(renders={"rgb": t_rgb}, gt_tensors={"rgb": torch.tensor(gt).expand(B, -1, -1, -1), "segmentation": torch.tensor(seg).expand(B, -1, -1, -1)},
+                         learning_rates=torch.tensor(lr), cfg=dd.Cfg(losses=dd.Cfg(weight_edge=0.8)),
+                         add_loss_value=lambda k, v: logged.setdefault(k, v))
+    loss = dd.l1_edge(dp)
+    loss.backward()
+    per, d = orc.loss_edge(rgb, gt, seg, lr * 0.8 / B, True)
+    assert np.allclose(logged["edge"].numpy(), per * 0.8, rtol=1e-12)
+    assert np.isclose(float(loss.detach()), (per * lr).sum() / B * 0.8, rtol=1e-12)
+    assert np.allclose(t_rgb.grad.numpy(), d, rtol=1e-10, atol=1e-15)
+    assert "l1_edge" in dir(dd)

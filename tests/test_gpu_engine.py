@@ -10,7 +10,7 @@ from tests.scenes import make_scene
 pytestmark = pytest.mark.gpu
 
 T = lambda a, **k: torch.tensor(np.ascontiguousarray(a), device="cuda", **k)
-KEYS = ("rgb", "depth", "mask_selection")
+KEYS = ("rgb", "depth", "mask_selection", "edge")
 
 
 def _engine(sc, weights, lrs, params=None, **kw):
@@ -24,12 +24,13 @@ def _engine(sc, weights, lrs, params=None, **kw):
     return eng, params
 
 
-@pytest.mark.parametrize("weights", [dict(rgb=0.7), dict(depth=1.0), dict(mask=1.0), dict(rgb=0.7, depth=1.0, mask=1.0)])
+@pytest.mark.parametrize("weights", [dict(rgb=0.7), dict(depth=1.0), dict(mask=1.0), dict(rgb=0.7, depth=1.0, mask=1.0),
+                                     dict(edge=1.0), dict(rgb=0.7, depth=1.0, edge=0.8), dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8)])
 @pytest.mark.parametrize("textured", [True, False])
 def test_engine_one_iteration_losses_and_gradients(weights, textured):
     sc = make_scene(16, 20, 60, 80, B=3, dist=1.8, textured=textured)
     R = sc["oracle"]
-    R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask")}
+    R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
     total, logs, g_ref, _ = R.loss_and_grad(sc["params"], sc["lr_mult"])
     lr = 0.5
     eng, params = _engine(sc, weights, [lr])
@@ -158,7 +159,7 @@ def test_engine_large_triangles_ragged_sizes_single_hypothesis(rows, cols, H, W,
     multiples of the tile size, B = 1: losses and gradients still match the oracle."""
     sc = make_scene(rows, cols, H, W, B=B, dist=dist, tex_size=16)
     R = sc["oracle"]
-    w = dict(rgb=0.7, depth=1.0, mask=1.0)
+    w = dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8)
     R.weights = w
     total, logs, g_ref, r_ref = R.loss_and_grad(sc["params"], sc["lr_mult"])
     eng, params = _engine(sc, w, [0.25])
@@ -180,7 +181,7 @@ def test_engine_hypothesis_leaving_the_frame():
     sc = make_scene(16, 20, 60, 80, B=2, dist=1.8)
     sc["params"][4, 1] = 50.0  # x far outside the frustum
     R = sc["oracle"]
-    w = dict(rgb=0.7, depth=1.0, mask=1.0)
+    w = dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8)
     R.weights = w
     total, logs, g_ref, r_ref = R.loss_and_grad(sc["params"], sc["lr_mult"])
     assert (r_ref["rast"][1, ..., 3] > 0).sum() == 0
@@ -199,3 +200,29 @@ def test_engine_hypothesis_leaving_the_frame():
     torch.cuda.synchronize()
     p_ref, logs_ref, _ = R.optimise(sc["params"], sc["lr_mult"], [0.01] * 4)
     np.testing.assert_allclose(p2.cpu().numpy(), p_ref, rtol=0, atol=2e-5)
+
+
+def test_engine_with_edge_extension_tracks_oracle_over_iterations():
+    """rgb + depth + edge (BASELINE configs[2]; the edge term is this build's extension, checked against the
+    oracle's definition of it, not against the reference): 20 SGD iterations vs the oracle's op-by-op loop."""
+    from oracle import oracle as orc
+
+    sc = make_scene(16, 20, 60, 80, B=3, dist=1.8, rot_deg=5.0, trans=0.02)
+    w = dict(rgb=0.7, depth=1.0, edge=0.5)
+    R = sc["oracle"]
+    R.weights = w
+    lrs = [l * 0.01 for l in orc.lr_schedule(19, 20, 0.1)]
+    p_ref, logs_ref, _ = R.optimise(sc["params"], sc["lr_mult"], lrs)
+    eng, params = _engine(sc, w, lrs)
+    eng.run()
+    torch.cuda.synchronize()
+    eng.check()
+    p_gpu = params.cpu().numpy()
+    for b in range(sc["B"]):
+        ang = syn.rotation_geodesic(p_gpu[:4, b], p_ref[:4, b])
+        dt = np.linalg.norm(p_gpu[4:, b] - p_ref[4:, b]) * 0.1
+        assert ang < 1e-3 and dt < 1e-3, (b, ang, dt)
+    lg = eng.losses().cpu().numpy()
+    np.testing.assert_allclose(lg[0, 3], logs_ref["edge"][0], rtol=1e-4)
+    assert np.all(lg[:, 2] == 0)
+    assert lg[-1, 3].min() < lg[0, 3].min()

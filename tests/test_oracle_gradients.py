@@ -29,6 +29,7 @@ def scene():
 @pytest.mark.parametrize("weights", [
     dict(rgb=0.7, depth=None, mask=None), dict(rgb=None, depth=1.0, mask=None), dict(rgb=None, depth=None, mask=1.0),
     dict(rgb=0.7, depth=1.0, mask=1.0),
+    dict(rgb=None, depth=None, mask=None, edge=1.0), dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8),  # edge: this build's extension
 ])
 def test_pose_to_loss_chain_matches_finite_differences(scene, weights):
     R, params = scene
@@ -129,3 +130,20 @@ def test_antialias_color_gradient():
             assert abs(dpos[0, v, c] - n1) < 1e-5 * max(1, abs(n1))
             checked += 1
     assert checked >= 10
+
+
+def test_edge_loss_image_gradient_matches_finite_differences():
+    """Extension (no reference counterpart): d edge / d rgb of orc_loss_edge against central differences."""
+    rng = np.random.default_rng(5)
+    B, h, w = 2, 7, 9
+    rgb, gt = rng.random((B, h, w, 3)), rng.random((1, h, w, 3))
+    seg = np.repeat((rng.random((1, h, w, 1)) > 0.4).astype(np.float64), 3, -1)
+    sc = np.array([0.6, 1.7])
+    per, d = orc.loss_edge(rgb, gt, seg, sc, True)
+    eps = 1e-6
+    for idx in [(0, 0, 0, 0), (0, 3, 4, 1), (1, 6, 8, 2), (1, 2, 0, 0), (0, 0, 8, 1)]:
+        p, m = rgb.copy(), rgb.copy()
+        p[idx] += eps
+        m[idx] -= eps
+        num = ((orc.loss_edge(p, gt, seg)[0] - orc.loss_edge(m, gt, seg)[0]) * sc).sum() / (2 * eps)
+        assert abs(d[idx] - num) < 1e-7, (idx, d[idx], num)

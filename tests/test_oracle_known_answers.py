@@ -188,3 +188,37 @@ def test_opposite_vertex_topology():
     assert opp[0, 0] == 3 and opp[0, 1] == -1 and opp[0, 2] == -1
     assert opp[1, 2] == 0  # tri1 edge2 = (2,1)
     assert np.all(opp[2] == -1)
+
+
+def test_edge_extension_known_answers():
+    """Edge term (this build's extension, no reference counterpart): Sobel/8 of the luminance, zero padding.
+    A vertical unit step gives |Gx| = 1/2 on the two columns next to the step (3/8 on the border rows), Gy = 0
+    away from the border rows; the loss equals an independent numpy restatement."""
+    h, w = 6, 8
+    img = np.zeros((1, h, w, 3))
+    img[:, :, 4:, :] = 1.0
+    zero = np.zeros((1, h, w, 3))
+    ones = np.ones((1, h, w, 3))
+    per, _ = orc.loss_edge(img, zero, ones)
+
+    def sob(l):
+        p = np.pad(l, 1)
+        gx = ((p[:-2, 2:] - p[:-2, :-2]) + 2 * (p[1:-1, 2:] - p[1:-1, :-2]) + (p[2:, 2:] - p[2:, :-2])) / 8
+        gy = ((p[2:, :-2] - p[:-2, :-2]) + 2 * (p[2:, 1:-1] - p[:-2, 1:-1]) + (p[2:, 2:] - p[:-2, 2:])) / 8
+        return gx, gy
+
+    gx, gy = sob(img[0].mean(-1))
+    assert np.allclose(gx[1:-1, 3], 0.5) and np.allclose(gx[1:-1, 4], 0.5) and np.allclose(gx[0, 3], 0.375)
+    assert np.allclose(gy[1:-1, :7], 0.0)
+    assert np.isclose(per[0], (np.abs(gx) + np.abs(gy)).sum() / (2 * h * w))
+    rng = np.random.default_rng(3)
+    a, g = rng.random((2, h, w, 3)), rng.random((1, h, w, 3))
+    seg = np.repeat((rng.random((1, h, w, 1)) > 0.5).astype(np.float64), 3, -1)
+    per, _ = orc.loss_edge(a, g, seg)
+    gx0, gy0 = sob((g * seg)[0].mean(-1))
+    for b in range(2):
+        gx, gy = sob(a[b].mean(-1))
+        assert np.isclose(per[b], (np.abs(gx - gx0) + np.abs(gy - gy0)).sum() / (2 * h * w), rtol=1e-12)
+    # identical images: zero loss, zero gradient
+    per, d = orc.loss_edge(g * seg, g, seg, None, True)
+    assert per[0] == 0 and np.all(d == 0)
