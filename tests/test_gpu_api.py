@@ -23,7 +23,7 @@ def _ddope(sc, losses, B, nb=5, **hp):
     cam = dd.Camera(fx=1, fy=1, cx=0, cy=0, im_width=sc["W"], im_height=sc["H"])
     cam.cam_proj = torch.tensor(sc["proj"], dtype=torch.float64)
     cfg = dict(losses=dict(l1_rgb_with_mask="rgb" in losses, weight_rgb=0.7, l1_depth_with_mask="depth" in losses, weight_depth=1.0,
-                           l1_mask="mask" in losses, weight_mask=1.0),
+                           l1_mask="mask" in losses, weight_mask=1.0, l1_edge="edge" in losses, weight_edge=0.6),
                hyperparameters=dict(nb_iterations=nb, batchsize=B, base_lr=hp.get("base_lr", 0.4), learning_rates_bound=[0.5, 2.0],
                                     learning_rate_base=1, lr_decay=0.1, seed=3))
     return dd.DiffDope(cfg=cfg, camera=cam, object3d=obj, scene=scene)
@@ -59,6 +59,22 @@ def test_fused_and_autograd_paths_agree_and_results_api():
     with tempfile.TemporaryDirectory() as td:
         out = a.make_animation(os.path.join(td, "anim.gif"))
         assert os.path.getsize(out) > 1000
+
+
+def test_edge_extension_fused_and_autograd_paths_agree():
+    """cfg.losses.l1_edge (this build's extension): the fused engine's edge role and the torch conv2d loss of the
+    op-by-op path optimise alike."""
+    sc = make_scene(16, 20, 60, 80, B=1, dist=1.8)
+    B = 3
+    a = _ddope(sc, ("rgb", "edge"), B, nb=4, base_lr=0.2)
+    b = _ddope(sc, ("rgb", "edge"), B, nb=4, base_lr=0.2)
+    a.run_optimization(fused=True)
+    b.run_optimization(fused=False)
+    assert set(a.losses_values) == {"rgb", "edge"} == set(b.losses_values)
+    for k in a.losses_values:
+        np.testing.assert_allclose(a.losses_values[k].numpy(), b.losses_values[k].numpy(), rtol=3e-3, atol=1e-6)
+    pa, pb = a.object3d.params_tensor().cpu().numpy(), b.object3d.params_tensor().cpu().numpy()
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=3e-4)
 
 
 def test_user_loss_function_forces_the_autograd_path():
