@@ -33,7 +33,8 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
     """Refine every object of one frame.
 
     cfg: config mapping (losses / hyperparameters as configs/diffdope.yaml); camera: Camera; scene: Scene with the
-    shared rgb/depth; objects: list of dict(obj_id, R, t_mm) (load_scene_poses(...)[frame]); meshes: {obj_id: Mesh};
+    shared rgb/depth; objects: list of dict(obj_id, R, t_mm[, losses]) (load_scene_poses(...)[frame]; an optional
+    per-object "losses" mapping overrides cfg["losses"] entries -- BASELINE config 5's mixed loss sets); meshes: {obj_id: Mesh};
     masks: list of Image (mask_visib of object i).  Returns (table [n_obj,18] float64 tensor identical on every
     rank: loss, arg-min hypothesis, 4x4 pose row-major, and per-object DiffDope handles for the local objects).
     """
@@ -48,7 +49,8 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
         obj = Object3D(position=list(o["t_mm"]), rotation=list(np.asarray(o["R"]).reshape(-1)), batchsize=B, scale=scale,
                        mesh=meshes[o["obj_id"]])
         sc = Scene(tensor_rgb=scene.tensor_rgb, tensor_depth=scene.tensor_depth, tensor_segmentation=masks[i])
-        dd = DiffDope(cfg=cfg, camera=camera, object3d=obj, scene=sc)
+        cfg_i = cfg if "losses" not in o else {**cfg, "losses": {**cfg["losses"], **o["losses"]}}
+        dd = DiffDope(cfg=cfg_i, camera=camera, object3d=obj, scene=sc)
         dd.run_optimization(optimizer=optimizer)
         best = int(dd.get_argmin())
         stacked = torch.stack([t[-1] for t in dd.losses_values.values()], dim=0).mean(0)

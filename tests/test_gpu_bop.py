@@ -50,9 +50,14 @@ def test_three_objects_one_frame(tmp_path):
     cfg = dict(losses=dict(l1_rgb_with_mask=True, weight_rgb=0.7, l1_depth_with_mask=True, weight_depth=1.0, l1_mask=True, weight_mask=1.0),
                hyperparameters=dict(nb_iterations=120, batchsize=8, base_lr=0.1, learning_rates_bound=[0.5, 3.0], learning_rate_base=1,
                                     lr_decay=0.1, seed=2))
+    # mixed per-object loss sets (BASELINE config 5): object 2 rgb+depth+edge (extension), object 3 depth+mask
+    objs[1]["losses"] = dict(l1_mask=False, l1_edge=True, weight_edge=1.0)
+    objs[2]["losses"] = dict(l1_rgb_with_mask=False)
     cam2 = dd.Camera(**intr)
     table, handles = bop.refine_frame(cfg, cam2, scene, objs, meshes, masks, optimizer="adam")
     assert tuple(table.shape) == (3, 18) and len(handles) == 3
+    assert set(handles[0].losses_values) == {"rgb", "depth", "mask_selection"}
+    assert set(handles[1].losses_values) == {"rgb", "depth", "edge"} and set(handles[2].losses_values) == {"depth", "mask_selection"}
     for k, (_, _, mtx_gt) in enumerate(gts):
         pose = table[k, 2:].reshape(4, 4).cpu().numpy()
         ang = syn.matrix_rotation_geodesic(pose[:3, :3], mtx_gt[:3, :3])
