@@ -135,21 +135,28 @@ __device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V
                     const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
                     const Edge32 e1 = make_edge(c.x, c.y, a.x, a.y, X0, Y0, flip);
                     const Edge32 e2 = make_edge(a.x, a.y, bq.x, bq.y, X0, Y0, flip);
-                    bool loaded = false;
-                    float4 p0, p1, p2;
-                    unsigned long long* Z = L.zbuf + (size_t)b * H * W;
-                    const PixNdc ndc = make_pixndc(H, W);
+                    // pass 1: coverage of the <= 16 bbox centres as a bit mask -- integer only; the ownership rule
+                    // (v > 0 || (v == 0 && own)) is folded into the start value: v + own - 1 >= 0
+                    const int b0 = e0.e00 + (int)e0.own - 1, b1 = e1.e00 + (int)e1.own - 1, b2 = e2.e00 + (int)e2.own - 1;
+                    unsigned mask = 0;
+                    int idx = 0;
                     for (int j = 0; j < nyp; ++j) {
-                        int v0 = e0.e00 + j * e0.sy, v1 = e1.e00 + j * e1.sy, v2 = e2.e00 + j * e2.sy;
-                        for (int i = 0; i < nxp; ++i, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx) {
-                            const bool in = (v0 > 0 || (v0 == 0 && e0.own)) && (v1 > 0 || (v1 == 0 && e1.own)) &&
-                                            (v2 > 0 || (v2 == 0 && e2.own));
-                            if (!in) continue;
-                            if (!loaded) {  // clip-space vertices only for triangles that own a pixel centre
-                                const float* P = pos + (size_t)b * V * 4;
-                                p0 = ld4(P + (size_t)i0 * 4); p1 = ld4(P + (size_t)i1 * 4); p2 = ld4(P + (size_t)i2 * 4);
-                                loaded = true;
-                            }
+                        int v0 = b0 + j * e0.sy, v1 = b1 + j * e1.sy, v2 = b2 + j * e2.sy;
+                        for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
+                            mask |= (unsigned)((v0 | v1 | v2) >= 0) << idx;
+                    }
+                    // pass 2: one depth evaluation + one atomic per covered centre: the wave walks max(popcount)
+                    // rounds instead of max(bbox area), and the clip-space vertices are loaded once, up front
+                    if (mask) {
+                        const float* P = pos + (size_t)b * V * 4;
+                        const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
+                        unsigned long long* Z = L.zbuf + (size_t)b * H * W;
+                        const PixNdc ndc = make_pixndc(H, W);
+                        const float rn = __frcp_rn((float)nxp);
+                        while (mask) {
+                            const int k = __ffs(mask) - 1;
+                            mask &= mask - 1;
+                            const int j = (int)(((float)k + 0.5f) * rn), i = k - j * nxp;  // k = j * nxp + i, exact for k < 16
                             float zw;
                             const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
                             if (pixel_depth(p0, p1, p2, fx, fy, zw))
