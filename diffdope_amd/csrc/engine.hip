@@ -31,6 +31,10 @@
 // (summed once at engine creation); the third is evaluated per hypothesis and iteration over the
 // compacted list of pixels with seg0 != 0.  Pixels of active tiles add (actual - background) terms.
 #include <new>
+#ifdef DDX_TRACE
+#include <cstdio>
+#include <vector>
+#endif
 
 #include "raster.h"
 
@@ -56,10 +60,11 @@ struct EngineDev {
     ddx_engine_buffers b;
     RasterScratch L;
     float* clip;      // [B,V,4]
-    float* mats;      // [B,2,16]: mtx | final
+    float* mats;      // [2][B,2,16]: mtx | final, by iteration parity
+    float* params2;   // [2][7,B]: the parameters, by iteration parity (b.params is the user-visible copy)
     float* partials;  // [B*NT*4*NR, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*NR + role, NR = 2 (3 with the edge role)
     float2* gtedge;   // [H*W] Sobel gradients of lum(gt_rgb * seg) (edge extension), or null
-    float* adam;      // [2,7,B]
+    float* adam;      // [2][2,7,B]: first and second moments, by iteration parity
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     EngineState* st;
@@ -67,6 +72,9 @@ struct EngineDev {
     int n_roles;      // enabled shade roles (grid z of shade_kernel): 0 colour+depth, 1 antialiased mask, 2 edge
     int roles[MAX_ROLES];    // grid z -> role
     int role_mask;           // bit r set = role r runs
+#ifdef DDX_TRACE
+    unsigned long long* trace;  // [4 kernels][8192 workgroups][4]: start, end (s_memtime), hw id, work units
+#endif
 };
 
 struct ddx_engine {
@@ -76,6 +84,7 @@ struct ddx_engine {
     hipStream_t side = nullptr;    // second branch of the iteration (mask role of the shading stage)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool setup_done = false;
+    int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -89,8 +98,12 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     };
     char* p = (char*)base;
     const size_t o_state = carve(sizeof(EngineState));
-    const size_t o_mats = carve((size_t)d.B * 32 * sizeof(float));
-    const size_t o_adam = carve((size_t)2 * 7 * d.B * sizeof(float));
+    // per-hypothesis state that update_xfm_kernel both reads and writes is double-buffered by iteration parity:
+    // its workgroups (8 slices per hypothesis) read buffer it&1 and slice 0 writes buffer (it+1)&1, so a slice
+    // that starts late can never see the next iteration's values
+    const size_t o_mats = carve((size_t)2 * d.B * 32 * sizeof(float));
+    const size_t o_adam = carve((size_t)2 * 14 * d.B * sizeof(float));
+    const size_t o_par = carve((size_t)2 * 7 * d.B * sizeof(float));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
@@ -103,6 +116,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.st = (EngineState*)(p + o_state);
     E.mats = (float*)(p + o_mats);
     E.adam = (float*)(p + o_adam);
+    E.params2 = (float*)(p + o_par);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.trirec = (int4*)(p + o_rec);
@@ -302,7 +316,10 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int it = E.st->it;
         if (b == 0) E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
-        float* dst = E.mats + (size_t)b * 32;
+        float* dst = E.mats + ((size_t)(it & 1) * B + b) * 32;
+        float* pp = E.params2 + (size_t)(it & 1) * 7 * B;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pp[(size_t)i * B + b] = E.b.params[(size_t)i * B + b];  // un-normalised, as the user holds them
         float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -331,6 +348,9 @@ __device__ __forceinline__ void acc_vertex(PixAcc& A, const float* __restrict__ 
     A.dF[8] = __fmaf_rn(gw, x, A.dF[8]); A.dF[9] = __fmaf_rn(gw, y, A.dF[9]); A.dF[10] = __fmaf_rn(gw, z, A.dF[10]); A.dF[11] += gw;
 }
 
+#ifndef SHADE_MIN_WAVES
+#define SHADE_MIN_WAVES 4  // waves per SIMD the shade kernel is compiled for (128 VGPRs)
+#endif
 #define QUAD 8             // one wave shades one 8x8 quadrant of a 16x16 tile
 #define QH (QUAD + 2)      // quadrant + 1-pixel halo
 #define PAIR_CAP 160       // >= 2*64 + 8 + 8 candidate antialias pairs per quadrant
@@ -568,7 +588,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     const int b = blockIdx.y;
     if (ROLE == E.st_role && blockIdx.x == 0 && b == 0 && tid == 0) E.st->it = E.st->it_next;  // see update_xfm_kernel
     const int n_tiles = L.b_count[b];
-    for (int k = blockIdx.x; k < n_tiles; k += gridDim.x) {
+    // slice rotation: workgroups land on CUs in a fixed pattern of the linear workgroup id (measured: CU = f(id/8 % 32)),
+    // and slices beyond n_tiles are idle -- without the rotation the CUs that receive the high slices of every
+    // hypothesis sit idle while the others carry 1.7x the mean load
+    const int k_first = (int)((blockIdx.x + 8u * ((unsigned)b >> 3)) % gridDim.x);
+    for (int k = k_first; k < n_tiles; k += gridDim.x) {
         const int txy = L.active[(size_t)b * L.NT + k];
         const int tcx = txy & 0xffff, tcy = txy >> 16;
         const int flat = b * L.NT + tcy * L.ntx + tcx;
@@ -667,7 +691,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             }
             if (d.use_depth) {
                 const float k = d.w_depth * lrb * inv_b / ((float)H * (float)W);
-                const float* M = E.mats + (size_t)b * 32;
+                const float* M = E.mats + ((size_t)(E.st->it_next & 1) * d.B + b) * 32;  // it_next = this iteration (stable here)
                 const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
                 const float x0 = pos[(size_t)v0 * 3], y0 = pos[(size_t)v0 * 3 + 1], z0 = pos[(size_t)v0 * 3 + 2];
                 const float x1 = pos[(size_t)v1 * 3], y1 = pos[(size_t)v1 * 3 + 1], z1 = pos[(size_t)v1 * 3 + 2];
@@ -888,13 +912,28 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
 // Two builds of the same kernel: without and with the edge role, so that the register allocation (and scratch
 // footprint) of the reference-loss configurations does not depend on the extension.
 template <bool EDGE>
-__global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E)
 {
+#ifdef DDX_TRACE
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int z = blockIdx.z;
     const int role = EDGE ? (z == 0 ? E.roles[0] : (z == 1 ? E.roles[1] : E.roles[2])) : (E.n_roles == 2 ? z : E.st_role);
     if (role == 0) shade_body<0, EDGE ? 3 : 2>(E);
     else if (role == 1) shade_body<1, EDGE ? 3 : 2>(E);
     else if (EDGE) shade_body<2, 3>(E);
+#ifdef DDX_TRACE
+    if (threadIdx.x == 0) {
+        const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        if (wg < 8192) {
+            unsigned long long* q = E.trace + (2 * 8192 + wg) * 4;
+            q[0] = t_start; q[1] = __builtin_amdgcn_s_memrealtime();
+            q[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_ID
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // XCC_ID
+            q[3] = ((unsigned long long)role << 32) | (unsigned)max(0, (E.L.b_count[blockIdx.y] - (int)((blockIdx.x + 8u * (blockIdx.y >> 3)) % gridDim.x) + (int)gridDim.x - 1) / (int)gridDim.x);
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -905,6 +944,7 @@ __global__ __launch_bounds__(256, 4) void shade_kernel(EngineDev E)
 // rasteriser.  Slice 0 also writes parameters, optimiser state and logs; the zbuf / tile-flag re-arm is split
 // over the slices.
 #define UPD_SLICES 8
+#define SEG_PRE 16  // seg-list entries per thread requested up front (covers 4096 masked pixels; the rest loops)
 
 template <int NR>
 __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
@@ -921,24 +961,48 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     __shared__ int s_tiles[256], s_tidx[256];
     const int it = E.st->it;
     const int NT = E.L.NT;
+    const int XP = d.reserved[0];  // TEMP ablation
+    if (XP == 4) return;
     // ---- parallel prefetch: params 0..6, lr_mult 7, lr 8, m23 9, proj 16..31, adam 32..45
-    if (tid < 7) sc[tid] = E.b.params[(size_t)tid * B + b];
+    const int cur = it & 1;
+    if (tid < 7) sc[tid] = E.params2[((size_t)cur * 7 + tid) * B + b];
     else if (tid == 7) sc[7] = E.b.lr_mult[b];
     else if (tid == 8) sc[8] = E.b.lr_sched[it];
-    else if (tid == 9) sc[9] = E.mats[(size_t)b * 32 + 11];
     else if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
-    else if (tid >= 32 && tid < 46) sc[tid] = E.adam[(size_t)(tid - 32) * B + b];
+    else if (tid >= 32 && tid < 46) sc[tid] = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
     // ---- this hypothesis' active tiles come ordered by tile index (compact_big_kernel): sum their quadrant
     // partials in that fixed order (bit-reproducible); re-arm what the iteration dirtied (zbuf of the active
     // tiles, their flags) so that the next iteration needs no memset -- tile k is re-armed by slice k % UPD_SLICES.
     const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < NVALS of group g sums value j
     float acc = 0.f;
-    const int n_act = E.L.b_count[b];
+    const int n_act = XP == 2 ? 0 : E.L.b_count[b];
     const int* tiles = E.L.active + (size_t)b * NT;
+    // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the
+    // first chunk of the tile list (speculative: entries beyond n_act are stale and unused), the compact seg list
+    // of the background depth term, and the first batch of vertex positions of the transform at the end.  The
+    // kernel is a chain of dependent round trips; these three would otherwise each add one.
+    const int txy_first = tid < NT ? tiles[tid] : 0;
+    const int ns = (d.use_depth && XP != 3) ? E.st->n_seg : 0;
+    const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
+    float2 sg[SEG_PRE];
+#pragma unroll
+    for (int k = 0; k < SEG_PRE; ++k) {
+        const int i = tid + k * 256;
+        sg[k] = i < ns ? E.seglist[i] : make_float2(0.f, 0.f);
+    }
+    const int per = (V + UPD_SLICES - 1) / UPD_SLICES;
+    const int n_begin = slice * per, n_end = min(V, n_begin + per);
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = n_begin + u * 256 + tid;
+        const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
+        px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+    }
     for (int start = 0; start < n_act; start += 256) {
         __syncthreads();
         if (start + tid < n_act) {
-            const int txy = tiles[start + tid];
+            const int txy = start == 0 ? txy_first : tiles[start + tid];
             const int tile = (txy >> 16) * E.L.ntx + (txy & 0xffff);
             s_tiles[tid] = txy;
             s_tidx[tid] = tile;
@@ -982,11 +1046,15 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     __syncthreads();
     // ---- whole-frame background depth term over the compact seg list
-    const float dbg = -sc[9];
     float bgsum = 0.f, bgder = 0.f;
     if (d.use_depth) {
-        const int ns = E.st->n_seg;
-        for (int i = tid; i < ns; i += 256) {
+#pragma unroll
+        for (int k = 0; k < SEG_PRE; ++k) {  // an absent entry is (0,0): contributes exactly 0 to both sums
+            const float x = (dbg - sg[k].x) * sg[k].y;
+            bgsum += fabsf(x);
+            bgder += sgnf(x) * sg[k].y;
+        }
+        for (int i = tid + SEG_PRE * 256; i < ns; i += 256) {
             const float2 e = E.seglist[i];
             const float x = (dbg - e.x) * e.y;
             bgsum += fabsf(x);
@@ -1054,13 +1122,16 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
                 const float m1 = b1 * sc[32 + lane] + (1.f - b1) * g;
                 const float m2 = b2 * sc[39 + lane] + (1.f - b2) * g * g;
                 if (writer) {
-                    E.adam[(size_t)lane * B + b] = m1;
-                    E.adam[(size_t)(7 + lane) * B + b] = m2;
+                    E.adam[((size_t)(1 - cur) * 14 + lane) * B + b] = m1;
+                    E.adam[((size_t)(1 - cur) * 14 + 7 + lane) * B + b] = m2;
                 }
                 pnew = sc[lane] - lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
             }
             snew[lane] = pnew;
-            if (writer) E.b.params[(size_t)lane * B + b] = pnew;
+            if (writer) {
+                E.params2[((size_t)(1 - cur) * 7 + lane) * B + b] = pnew;
+                E.b.params[(size_t)lane * B + b] = pnew;
+            }
         }
         if (writer && b == 0) {
             // iteration bookkeeping without atomics (kernel boundaries order these single-lane updates):
@@ -1085,8 +1156,9 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = snew[4 + i];
     pose_matrices(q, t, sc + 16, M, F);
+    if (XP == 1) return;
     if (writer && tid == 0) {
-        float* dst = E.mats + (size_t)b * 32;
+        float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
         float* logm = (E.b.mtx_log && it + 1 < d.max_iters) ? E.b.mtx_log + ((size_t)(it + 1) * B + b) * 16 : nullptr;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1095,17 +1167,16 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
             if (logm) logm[i] = M[i];
         }
     }
-    const int per = (V + UPD_SLICES - 1) / UPD_SLICES;
-    const int n_begin = slice * per, n_end = min(V, n_begin + per);
     // positions of 4 strides are fetched before any is consumed (a load-transform-store loop would pay one
-    // memory round trip per stride)
+    // memory round trip per stride); the first batch was requested at the top of the kernel
     for (int n0 = n_begin; n0 < n_end; n0 += 4 * 256) {
-        float px[4], py[4], pz[4];
+        if (n0 > n_begin) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int n = n0 + u * 256 + tid;
-            const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
-            px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + u * 256 + tid;
+                const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
+                px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1134,6 +1205,12 @@ static dim3 shade_grid(const ddx_engine_desc& d)
 static int run_prologue(ddx_engine* e, int it0, hipStream_t s)
 {
     EngineDev& E = e->dev;
+    if ((it0 & 1) != e->adam_parity) {  // a run that does not continue where the last one stopped (rewind)
+        const size_t half = (size_t)14 * E.d.B;
+        DDX_HIP(hipMemcpyAsync(E.adam + (size_t)(it0 & 1) * half, E.adam + (size_t)e->adam_parity * half, half * sizeof(float),
+                               hipMemcpyDeviceToDevice, s));
+        e->adam_parity = it0 & 1;
+    }
     set_it_kernel<<<1, 1, 0, s>>>(E.st, it0);
     pose_xfm_kernel<<<dim3(ddx_cdiv(E.d.V, 256), E.d.B), 256, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
@@ -1223,6 +1300,10 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         ddx_engine_destroy(e);
         DDX_REQUIRE(false, 1, "engine_create: could not create the side stream / events");
     }
+#ifdef DDX_TRACE
+    DDX_HIP(hipMalloc(&e->dev.trace, (size_t)4 * 8192 * 4 * 8));
+    DDX_HIP(hipMemset(e->dev.trace, 0, (size_t)4 * 8192 * 4 * 8));
+#endif
     *out = e;
     return 0;
 }
@@ -1239,7 +1320,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
 {
     EngineDev& E = e->dev;
     DDX_HIP(hipMemsetAsync(E.st, 0, sizeof(EngineState), s));
-    DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)14 * E.d.B * sizeof(float), s));
+    DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)2 * 14 * E.d.B * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // kept zero by update_xfm_kernel afterwards
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
@@ -1281,8 +1362,23 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
             return err;
         }
     }
+    e->adam_parity = (it0 + n) & 1;
     return 0;
 }
+
+#ifdef DDX_TRACE
+extern "C" int ddx_engine_trace_dump(ddx_engine* e, const char* path)
+{
+    std::vector<unsigned long long> h((size_t)4 * 8192 * 4);
+    DDX_HIP(hipDeviceSynchronize());
+    DDX_HIP(hipMemcpy(h.data(), e->dev.trace, h.size() * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    fwrite(h.data(), 8, h.size(), f);
+    fclose(f);
+    return 0;
+}
+#endif
 
 extern "C" const int32_t* ddx_engine_status_ptr(ddx_engine* e) { return e ? &e->dev.st->overflow : nullptr; }
 
@@ -1306,6 +1402,7 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
             ms_out[k] += ms;
         }
     }
+    e->adam_parity = (it0 + iters) & 1;
     for (int k = 0; k < K_COUNT; ++k) {
         ms_out[k] /= (float)iters;
         if (names_out) names_out[k] = kKernelNames[k];
