@@ -592,8 +592,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     // and slices beyond n_tiles are idle -- without the rotation the CUs that receive the high slices of every
     // hypothesis sit idle while the others carry 1.7x the mean load
     const int k_first = (int)((blockIdx.x + 8u * ((unsigned)b >> 3)) % gridDim.x);
+    // the first list entry is requested together with the count (one dependent round trip less; an entry beyond
+    // the count is stale and unused)
+    const int txy_first = k_first < L.NT ? L.active[(size_t)b * L.NT + k_first] : 0;
     for (int k = k_first; k < n_tiles; k += gridDim.x) {
-        const int txy = L.active[(size_t)b * L.NT + k];
+        const int txy = k == k_first ? txy_first : L.active[(size_t)b * L.NT + k];
         const int tcx = txy & 0xffff, tcy = txy >> 16;
         const int flat = b * L.NT + tcy * L.ntx + tcx;
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
@@ -914,26 +917,14 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
 template <bool EDGE>
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E)
 {
-#ifdef DDX_TRACE
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#endif
+    DDX_TRACE_BEGIN();
     const int z = blockIdx.z;
     const int role = EDGE ? (z == 0 ? E.roles[0] : (z == 1 ? E.roles[1] : E.roles[2])) : (E.n_roles == 2 ? z : E.st_role);
     if (role == 0) shade_body<0, EDGE ? 3 : 2>(E);
     else if (role == 1) shade_body<1, EDGE ? 3 : 2>(E);
     else if (EDGE) shade_body<2, 3>(E);
-#ifdef DDX_TRACE
-    if (threadIdx.x == 0) {
-        const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-        if (wg < 8192) {
-            unsigned long long* q = E.trace + (2 * 8192 + wg) * 4;
-            q[0] = t_start; q[1] = __builtin_amdgcn_s_memrealtime();
-            q[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_ID
-                   ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // XCC_ID
-            q[3] = ((unsigned long long)role << 32) | (unsigned)max(0, (E.L.b_count[blockIdx.y] - (int)((blockIdx.x + 8u * (blockIdx.y >> 3)) % gridDim.x) + (int)gridDim.x - 1) / (int)gridDim.x);
-        }
-    }
-#endif
+    DDX_TRACE_END(E.trace, 2, ((unsigned long long)role << 32) |
+                  (unsigned)max(0, (E.L.b_count[blockIdx.y] - (int)((blockIdx.x + 8u * (blockIdx.y >> 3)) % gridDim.x) + (int)gridDim.x - 1) / (int)gridDim.x));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -961,6 +952,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     __shared__ int s_tiles[256], s_tidx[256];
     const int it = E.st->it;
     const int NT = E.L.NT;
+    DDX_TRACE_BEGIN();
     const int XP = d.reserved[0];  // TEMP ablation
     if (XP == 4) return;
     // ---- parallel prefetch: params 0..6, lr_mult 7, lr 8, m23 9, proj 16..31, adam 32..45
@@ -1184,6 +1176,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
             if (n0 + u * 256 < n_end) xfm_vertex_regs(E, F, b, n, n < n_end, lane, px[u], py[u], pz[u]);
         }
     }
+    DDX_TRACE_END(E.trace, 3, 1ull);
 }
 
 __global__ void set_it_kernel(EngineState* st, int it) { st->it = it; st->it_next = it; }
@@ -1303,6 +1296,7 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
 #ifdef DDX_TRACE
     DDX_HIP(hipMalloc(&e->dev.trace, (size_t)4 * 8192 * 4 * 8));
     DDX_HIP(hipMemset(e->dev.trace, 0, (size_t)4 * 8192 * 4 * 8));
+    e->dev.L.trace = e->dev.trace;
 #endif
     *out = e;
     return 0;

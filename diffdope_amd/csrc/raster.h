@@ -19,7 +19,32 @@ struct RasterScratch {
     size_t zbuf_bytes;
     size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big)
     int ntx, nty, NT;
+    PixNdc ndc;               // pixel index -> NDC centre constants for (H, W)
+#ifdef DDX_TRACE
+    unsigned long long* trace;
+#endif
 };
+
+#ifdef DDX_TRACE
+#define DDX_TRACE_BEGIN() const unsigned long long ddx_t0 = __builtin_amdgcn_s_memrealtime()
+#define DDX_TRACE_END(buf, kidx, info)                                                                                   \
+    do {                                                                                                                 \
+        if (threadIdx.x == 0 && (buf)) {                                                                                 \
+            const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);                    \
+            if (wg < 8192) {                                                                                             \
+                unsigned long long* q = (buf) + ((size_t)(kidx) * 8192 + wg) * 4;                                        \
+                q[0] = ddx_t0;                                                                                           \
+                q[1] = __builtin_amdgcn_s_memrealtime();                                                                 \
+                q[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |                 \
+                       ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);         \
+                q[3] = (info);                                                                                           \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
+#else
+#define DDX_TRACE_BEGIN()
+#define DDX_TRACE_END(buf, kidx, info)
+#endif
 
 size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, int W);
 // window-coordinate snap of clip positions (the fused engine does this inside its transform kernel)

@@ -59,6 +59,11 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.zbuf = (unsigned long long*)(p + o_zbuf);
     L.zbuf_bytes = (size_t)B * H * W * sizeof(unsigned long long);
     L.ntx = ntx; L.nty = nty; L.NT = (int)NT;
+    L.ndc.xs = 2.0f / (float)W; L.ndc.xo = 1.0f / (float)W - 1.0f;  // as make_pixndc (host float division is IEEE too)
+    L.ndc.ys = 2.0f / (float)H; L.ndc.yo = 1.0f / (float)H - 1.0f;
+#ifdef DDX_TRACE
+    L.trace = nullptr;
+#endif
     return off;
 }
 
@@ -100,8 +105,9 @@ __device__ __forceinline__ Edge32 make_edge(int ax, int ay, int bx, int by, int 
     int dx = bx - ax, dy = by - ay;
     if (flip) { dx = -dx; dy = -dy; }
     Edge32 e;
-    // e = dx*(PY-ay) - dy*(PX-ax); all factors < 2^14 for a small triangle near its own bbox
-    e.e00 = dx * (Y0 - ay) - dy * (X0 - ax);
+    // e = dx*(PY-ay) - dy*(PX-ax); all factors < 2^14 for a small triangle near its own bbox: 24-bit multiplies
+    // (full rate; a 32-bit v_mul_lo_u32 issues at quarter rate and this kernel is VALU-issue bound)
+    e.e00 = __mul24(dx, Y0 - ay) - __mul24(dy, X0 - ax);
     e.sx = -dy * DDX_SUBPIX;
     e.sy = dx * DDX_SUBPIX;
     e.own = (dy > 0) || (dy == 0 && dx < 0);
@@ -123,11 +129,11 @@ __device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V
         px1 = min(px1, W - 1); py1 = min(py1, H - 1);
         if (px0 <= px1 && py0 <= py1) {
             const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
-            const bool small = nxp * nyp <= RASTER_SMALL_PX && (xmax - xmin) < 8192 && (ymax - ymin) < 8192;
+            const bool small = __mul24(nxp, nyp) <= RASTER_SMALL_PX && (xmax - xmin) < 8192 && (ymax - ymin) < 8192;
             bool alive = false;
             if (small) {
                 // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
-                const int area = (bq.x - a.x) * (c.y - a.y) - (c.x - a.x) * (bq.y - a.y);
+                const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
                 if (area != 0) {
                     alive = true;
                     const bool flip = area < 0;
@@ -140,8 +146,9 @@ __device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V
                     const int b0 = e0.e00 + (int)e0.own - 1, b1 = e1.e00 + (int)e1.own - 1, b2 = e2.e00 + (int)e2.own - 1;
                     unsigned mask = 0;
                     int idx = 0;
-                    for (int j = 0; j < nyp; ++j) {
-                        int v0 = b0 + j * e0.sy, v1 = b1 + j * e1.sy, v2 = b2 + j * e2.sy;
+                    int r0 = b0, r1 = b1, r2 = b2;
+                    for (int j = 0; j < nyp; ++j, r0 += e0.sy, r1 += e1.sy, r2 += e2.sy) {
+                        int v0 = r0, v1 = r1, v2 = r2;
                         for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
                             mask |= (unsigned)((v0 | v1 | v2) >= 0) << idx;
                     }
@@ -151,16 +158,16 @@ __device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V
                         const float* P = pos + (size_t)b * V * 4;
                         const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
                         unsigned long long* Z = L.zbuf + (size_t)b * H * W;
-                        const PixNdc ndc = make_pixndc(H, W);
+                        const PixNdc ndc = L.ndc;  // host-computed (IEEE divisions, same values as make_pixndc)
                         const float rn = __frcp_rn((float)nxp);
                         while (mask) {
                             const int k = __ffs(mask) - 1;
                             mask &= mask - 1;
-                            const int j = (int)(((float)k + 0.5f) * rn), i = k - j * nxp;  // k = j * nxp + i, exact for k < 16
+                            const int j = (int)(((float)k + 0.5f) * rn), i = k - __mul24(j, nxp);  // k = j * nxp + i, exact for k < 16
                             float zw;
                             const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
                             if (pixel_depth(p0, p1, p2, fx, fy, zw))
-                                atomicMin(Z + (size_t)(py0 + j) * W + px0 + i, ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
+                                atomicMin(Z + (unsigned)(__mul24(py0 + j, W) + px0 + i), ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
                         }
                     }
                 }
@@ -173,13 +180,18 @@ __device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V
                 // (conservative: a centre inside the bbox need not be covered)
                 const int tx0 = max(px0 - 1, 0) / DDX_TILE, tx1 = min(px1 + 1, W - 1) / DDX_TILE;
                 const int ty0 = max(py0 - 1, 0) / DDX_TILE, ty1 = min(py1 + 1, H - 1) / DDX_TILE;
+                // (the usual trip count is 1 x 1: keep the compiler from unrolling / vectorising these loops)
                 int* flag = L.tile_flag + (size_t)b * L.NT;
+#pragma clang loop unroll(disable) vectorize(disable)
                 for (int ty = ty0; ty <= ty1; ++ty)
-                    for (int tx = tx0; tx <= tx1; ++tx) flag[ty * L.ntx + tx] = 1;  // plain store, no atomics
+#pragma clang loop unroll(disable) vectorize(disable)
+                    for (int tx = tx0; tx <= tx1; ++tx) flag[__mul24(ty, L.ntx) + tx] = 1;  // plain store, no atomics
                 if (!small) {
                     int* big = L.tile_big + (size_t)b * L.NT;
+#pragma clang loop unroll(disable) vectorize(disable)
                     for (int ty = ty0; ty <= ty1; ++ty)
-                        for (int tx = tx0; tx <= tx1; ++tx) big[ty * L.ntx + tx] = 1;
+#pragma clang loop unroll(disable) vectorize(disable)
+                        for (int tx = tx0; tx <= tx1; ++tx) big[__mul24(ty, L.ntx) + tx] = 1;
                     range = (unsigned)tx0 | ((unsigned)ty0 << 8) | ((unsigned)(tx1 - tx0) << 16) | ((unsigned)(ty1 - ty0) << 24);
                     L.counters[3] = 1;  // plain store: "the batch has a large triangle"
                 }
@@ -192,6 +204,7 @@ __device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V
 __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
                                                       int T, int H, int W, RasterScratch L)
 {
+    DDX_TRACE_BEGIN();
     const int b = blockIdx.y;
     const int2* S = L.snap + (size_t)b * V;
     int t[SCATTER_TPL], i0[SCATTER_TPL], i1[SCATTER_TPL], i2[SCATTER_TPL];
@@ -215,6 +228,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
         if (!ok[k]) { L.trirange[(size_t)b * T + t[k]] = ~0u; continue; }
         scatter_one(pos, V, T, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k]);
     }
+    DDX_TRACE_END(L.trace, 0, 1ull);
 }
 
 // One launch, two roles.

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffdope_amd as dd
 from diffdope_amd import workloads as wl, _lib
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+KIDX = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # 0 scatter, 2 shade, 3 update
 w = wl.build(cfg, torch.device('cuda:0'))
 eng = dd.RefineEngine(w['pos'], w['tri'], w['proj'], [w['H'], w['W']], w['gt'], w['params0'].clone(), w['lr_mult'], [0.0] * 60, w['weights'], uv=w['uv'], tex=w['tex'], vtx_color=w['vtx_color'])
 eng.run(20)
@@ -13,7 +14,7 @@ lib = _lib.load()
 lib.ddx_engine_trace_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
 path = '/tmp/trace.bin'
 assert lib.ddx_engine_trace_dump(eng.handle, path.encode()) == 0
-t = np.fromfile(path, dtype=np.uint64).reshape(4, 8192, 4)[2]
+t = np.fromfile(path, dtype=np.uint64).reshape(4, 8192, 4)[KIDX]
 t = t[t[:, 1] > 0]
 start, end, hw, info = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2], t[:, 3]
 role, units = (info >> np.uint64(32)).astype(int), (info & np.uint64(0xffffffff)).astype(int)
