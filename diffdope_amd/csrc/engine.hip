@@ -348,6 +348,14 @@ __device__ __forceinline__ void acc_vertex(PixAcc& A, const float* __restrict__ 
     A.dF[8] = __fmaf_rn(gw, x, A.dF[8]); A.dF[9] = __fmaf_rn(gw, y, A.dF[9]); A.dF[10] = __fmaf_rn(gw, z, A.dF[10]); A.dF[11] += gw;
 }
 
+__device__ __forceinline__ void acc_vertex_regs(PixAcc& A, float x, float y, float z, float gx, float gy, float gw)
+{
+    A.dF[0] = __fmaf_rn(gx, x, A.dF[0]); A.dF[1] = __fmaf_rn(gx, y, A.dF[1]); A.dF[2] = __fmaf_rn(gx, z, A.dF[2]); A.dF[3] += gx;
+    A.dF[4] = __fmaf_rn(gy, x, A.dF[4]); A.dF[5] = __fmaf_rn(gy, y, A.dF[5]); A.dF[6] = __fmaf_rn(gy, z, A.dF[6]); A.dF[7] += gy;
+    A.dF[8] = __fmaf_rn(gw, x, A.dF[8]); A.dF[9] = __fmaf_rn(gw, y, A.dF[9]); A.dF[10] = __fmaf_rn(gw, z, A.dF[10]); A.dF[11] += gw;
+}
+
+
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4  // waves per SIMD the shade kernel is compiled for (128 VGPRs)
 #endif
@@ -568,9 +576,24 @@ __device__ __forceinline__ float lum_unit(const EngineDev& E, const float* __res
 // ROLE 2: edge term (extension): the wave owns the Sobel loss terms of its 8x8 quadrant, shades the luminance of
 // the 10x10 halo those terms read, and backpropagates into all 100 halo pixels (the neighbouring quadrants add
 // their own terms' share for the same pixels -- the chain is linear).
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+#define DDX_PHASE(i)                                                           \
+    do {                                                                       \
+        if (ROLE == 0) {                                                       \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+            ph[i] = __builtin_amdgcn_s_memrealtime();                          \
+        }                                                                      \
+    } while (0)
+#else
+#define DDX_PHASE(i)
+#endif
+
 template <int ROLE, int NR>
 __device__ __forceinline__ void shade_body(const EngineDev& E)
 {
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
     __shared__ float s_gm[WAVES_PER_TILE][64];          // d loss / d mask of each pixel
@@ -597,6 +620,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     const int txy_first = k_first < L.NT ? L.active[(size_t)b * L.NT + k_first] : 0;
     for (int k = k_first; k < n_tiles; k += gridDim.x) {
         const int txy = k == k_first ? txy_first : L.active[(size_t)b * L.NT + k];
+        DDX_PHASE(0);
         const int tcx = txy & 0xffff, tcy = txy >> 16;
         const int flat = b * L.NT + tcy * L.ntx + tcx;
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
@@ -626,6 +650,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
         const int px = qx + lx, py = qy + ly;
         const int hidx = (ly + 1) * QH + lx + 1;
         const int id = ids[hidx];
+        DDX_PHASE(1);
         PixAcc A;
 #pragma unroll
         for (int i = 0; i < 12; ++i) A.dF[i] = 0.f;
@@ -640,7 +665,14 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
         if (ROLE == 0 && id > 0) {
             const int t = id - 1;
             const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
+            DDX_PHASE(2);
             const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
+            // object-space positions (depth term, and the contraction of the vertex gradients at the end): requested
+            // with the clip vertices, not behind the texture fetch
+            const float x0 = pos[(size_t)v0 * 3], y0 = pos[(size_t)v0 * 3 + 1], z0 = pos[(size_t)v0 * 3 + 2];
+            const float x1 = pos[(size_t)v1 * 3], y1 = pos[(size_t)v1 * 3 + 1], z1 = pos[(size_t)v1 * 3 + 2];
+            const float x2 = pos[(size_t)v2 * 3], y2 = pos[(size_t)v2 * 3 + 1], z2 = pos[(size_t)v2 * 3 + 2];
+            DDX_PHASE(3);
             Bary bc;
             pixel_bary(p0, p1, p2, px, py, H, W, bc);
             const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
@@ -678,6 +710,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                     gV *= (float)d.Th;
                     gu += gU * (a0x - a2x) + gV * (a0y - a2y);
                     gv += gU * (a1x - a2x) + gV * (a1y - a2y);
+                    DDX_PHASE(4);
                 } else {
                     const float* vc = E.b.vtx_color;
 #pragma unroll
@@ -696,9 +729,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                 const float k = d.w_depth * lrb * inv_b / ((float)H * (float)W);
                 const float* M = E.mats + ((size_t)(E.st->it_next & 1) * d.B + b) * 32;  // it_next = this iteration (stable here)
                 const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
-                const float x0 = pos[(size_t)v0 * 3], y0 = pos[(size_t)v0 * 3 + 1], z0 = pos[(size_t)v0 * 3 + 2];
-                const float x1 = pos[(size_t)v1 * 3], y1 = pos[(size_t)v1 * 3 + 1], z1 = pos[(size_t)v1 * 3 + 2];
-                const float x2 = pos[(size_t)v2 * 3], y2 = pos[(size_t)v2 * 3 + 1], z2 = pos[(size_t)v2 * 3 + 2];
                 const float gbx = __fmaf_rn(w2, x2, __fmaf_rn(v, x1, u * x0));
                 const float gby = __fmaf_rn(w2, y2, __fmaf_rn(v, y1, u * y0));
                 const float gbz = __fmaf_rn(w2, z2, __fmaf_rn(v, z1, u * z0));
@@ -719,11 +749,12 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             if (gu != 0.f || gv != 0.f) {
                 float gx[3], gy[3], gw[3];
                 bary_backward(bc, gu, gv, gx, gy, gw);
-                acc_vertex(A, pos, v0, gx[0], gy[0], gw[0]);
-                acc_vertex(A, pos, v1, gx[1], gy[1], gw[1]);
-                acc_vertex(A, pos, v2, gx[2], gy[2], gw[2]);
+                acc_vertex_regs(A, x0, y0, z0, gx[0], gy[0], gw[0]);
+                acc_vertex_regs(A, x1, y1, z1, gx[1], gy[1], gw[1]);
+                acc_vertex_regs(A, x2, y2, z2, gx[2], gy[2], gw[2]);
             }
         }
+        DDX_PHASE(5);
         if (ROLE == 1) {
             // ---- antialias, pair-parallel: compact the candidate pairs (exactly one side covered, at least
             // one side in this quadrant) with ballots, then ONE lane per pair instead of 4 divergent
@@ -909,6 +940,17 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             }
         }
         if (lane < NPART) part[lane] = mine;
+        DDX_PHASE(6);
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+        if (ROLE == 0 && tid == 0 && k == k_first) {
+            const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+            if (wg < 4096) {
+                unsigned long long* q = E.trace + ((size_t)1 * 8192) * 4 + wg * 8;  // kernel slot 1 (unused), 8 stamps per workgroup
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = ph[i];
+            }
+        }
+#endif
     }
 }
 
@@ -953,8 +995,6 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     const int it = E.st->it;
     const int NT = E.L.NT;
     DDX_TRACE_BEGIN();
-    const int XP = d.reserved[0];  // TEMP ablation
-    if (XP == 4) return;
     // ---- parallel prefetch: params 0..6, lr_mult 7, lr 8, m23 9, proj 16..31, adam 32..45
     const int cur = it & 1;
     if (tid < 7) sc[tid] = E.params2[((size_t)cur * 7 + tid) * B + b];
@@ -967,14 +1007,14 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     // tiles, their flags) so that the next iteration needs no memset -- tile k is re-armed by slice k % UPD_SLICES.
     const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < NVALS of group g sums value j
     float acc = 0.f;
-    const int n_act = XP == 2 ? 0 : E.L.b_count[b];
+    const int n_act = E.L.b_count[b];
     const int* tiles = E.L.active + (size_t)b * NT;
     // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the
     // first chunk of the tile list (speculative: entries beyond n_act are stale and unused), the compact seg list
     // of the background depth term, and the first batch of vertex positions of the transform at the end.  The
     // kernel is a chain of dependent round trips; these three would otherwise each add one.
     const int txy_first = tid < NT ? tiles[tid] : 0;
-    const int ns = (d.use_depth && XP != 3) ? E.st->n_seg : 0;
+    const int ns = d.use_depth ? E.st->n_seg : 0;
     const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
     float2 sg[SEG_PRE];
 #pragma unroll
@@ -1148,7 +1188,6 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = snew[4 + i];
     pose_matrices(q, t, sc + 16, M, F);
-    if (XP == 1) return;
     if (writer && tid == 0) {
         float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
         float* logm = (E.b.mtx_log && it + 1 < d.max_iters) ? E.b.mtx_log + ((size_t)(it + 1) * B + b) * 16 : nullptr;

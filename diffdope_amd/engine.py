@@ -68,8 +68,6 @@ class RefineEngine:
         d.optimizer = {"sgd": 0, "adam": 1}[optimizer]
         d.adam_beta1, d.adam_beta2, d.adam_eps = adam
         d.max_iters = n_it
-        import os
-        d.reserved[0] = int(os.environ.get('DDX_XP', '0'))
         self.desc = d
         nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))
         if nbytes == 0:
