@@ -356,6 +356,9 @@ __device__ __forceinline__ void acc_vertex_regs(PixAcc& A, float x, float y, flo
 }
 
 
+#ifndef SHADE_GRID
+#define SHADE_GRID 1024  // shade workgroups per role (slices x hypotheses): measured flat 512..1536, worse above
+#endif
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4  // waves per SIMD the shade kernel is compiled for (128 VGPRs)
 #endif
@@ -513,16 +516,19 @@ __device__ __forceinline__ float lum_unit(const EngineDev& E, const float* __res
     const int* __restrict__ tri = E.b.tri;
     const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
     const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
+    float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f;
+    if (d.Th > 0) {  // requested with the clip vertices, not after them
+        const float* uv = E.b.uv;
+        a0x = uv[(size_t)v0 * 2]; a0y = uv[(size_t)v0 * 2 + 1];
+        a1x = uv[(size_t)v1 * 2]; a1y = uv[(size_t)v1 * 2 + 1];
+        a2x = uv[(size_t)v2 * 2]; a2y = uv[(size_t)v2 * 2 + 1];
+    }
     Bary bc;
     pixel_bary(p0, p1, p2, px, py, d.H, d.W, bc);
     const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
     const float third = 1.0f / 3.0f;
     float gu = 0.f, gv = 0.f, col[3];
     if (d.Th > 0) {
-        const float* uv = E.b.uv;
-        const float a0x = uv[(size_t)v0 * 2], a0y = uv[(size_t)v0 * 2 + 1];
-        const float a1x = uv[(size_t)v1 * 2], a1y = uv[(size_t)v1 * 2 + 1];
-        const float a2x = uv[(size_t)v2 * 2], a2y = uv[(size_t)v2 * 2 + 1];
         const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x));
         const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
         TexelSetup ts;
@@ -608,17 +614,18 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     int* ids = s_ids[wave];
     // grid (S, B): workgroup (s, b) takes tiles s, s+S, ... of hypothesis b's ordered active list -- no
     // prefix over hypotheses, no global list, workgroups beyond the count leave after one scalar load
-    const int b = blockIdx.y;
-    if (ROLE == E.st_role && blockIdx.x == 0 && b == 0 && tid == 0) E.st->it = E.st->it_next;  // see update_xfm_kernel
+    // grid (B, S, roles): x = hypothesis, y = slice.  Workgroups are dispatched in linear-id order and land on CUs
+    // in a fixed pattern of that id (XCD = id % 8, CU = f(id/8 % 32), measured): slice-major order sends the
+    // working slices of every hypothesis first and the idle ones (slice >= n_tiles) last, so the tail of the launch
+    // is made of workgroups that exit at once, and every CU sees the same mix of slices.
+    const int b = blockIdx.x;
+    if (ROLE == E.st_role && blockIdx.y == 0 && b == 0 && tid == 0) E.st->it = E.st->it_next;  // see update_xfm_kernel
     const int n_tiles = L.b_count[b];
-    // slice rotation: workgroups land on CUs in a fixed pattern of the linear workgroup id (measured: CU = f(id/8 % 32)),
-    // and slices beyond n_tiles are idle -- without the rotation the CUs that receive the high slices of every
-    // hypothesis sit idle while the others carry 1.7x the mean load
-    const int k_first = (int)((blockIdx.x + 8u * ((unsigned)b >> 3)) % gridDim.x);
+    const int k_first = blockIdx.y, k_step = gridDim.y;
     // the first list entry is requested together with the count (one dependent round trip less; an entry beyond
     // the count is stale and unused)
     const int txy_first = k_first < L.NT ? L.active[(size_t)b * L.NT + k_first] : 0;
-    for (int k = k_first; k < n_tiles; k += gridDim.x) {
+    for (int k = k_first; k < n_tiles; k += k_step) {
         const int txy = k == k_first ? txy_first : L.active[(size_t)b * L.NT + k];
         DDX_PHASE(0);
         const int tcx = txy & 0xffff, tcy = txy >> 16;
@@ -672,6 +679,15 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             const float x0 = pos[(size_t)v0 * 3], y0 = pos[(size_t)v0 * 3 + 1], z0 = pos[(size_t)v0 * 3 + 2];
             const float x1 = pos[(size_t)v1 * 3], y1 = pos[(size_t)v1 * 3 + 1], z1 = pos[(size_t)v1 * 3 + 2];
             const float x2 = pos[(size_t)v2 * 3], y2 = pos[(size_t)v2 * 3 + 1], z2 = pos[(size_t)v2 * 3 + 2];
+            // ... and the texture coordinates: behind `if (use_rgb && textured)` below they would only be requested
+            // after the clip vertices have arrived (the compiler does not speculate loads across the branch)
+            float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f;
+            if (d.use_rgb && d.Th > 0) {
+                const float* uv = E.b.uv;
+                a0x = uv[(size_t)v0 * 2]; a0y = uv[(size_t)v0 * 2 + 1];
+                a1x = uv[(size_t)v1 * 2]; a1y = uv[(size_t)v1 * 2 + 1];
+                a2x = uv[(size_t)v2 * 2]; a2y = uv[(size_t)v2 * 2 + 1];
+            }
             DDX_PHASE(3);
             Bary bc;
             pixel_bary(p0, p1, p2, px, py, H, W, bc);
@@ -682,10 +698,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                 const float g0 = E.b.gt_rgb[pix * 3 + 0], g1 = E.b.gt_rgb[pix * 3 + 1], g2 = E.b.gt_rgb[pix * 3 + 2];
                 const float gt[3] = {g0, g1, g2}, sg[3] = {s0, s1, s2};
                 if (d.Th > 0) {
-                    const float* uv = E.b.uv;
-                    const float a0x = uv[(size_t)v0 * 2], a0y = uv[(size_t)v0 * 2 + 1];
-                    const float a1x = uv[(size_t)v1 * 2], a1y = uv[(size_t)v1 * 2 + 1];
-                    const float a2x = uv[(size_t)v2 * 2], a2y = uv[(size_t)v2 * 2 + 1];
                     const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x));
                     const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
                     TexelSetup ts;
@@ -966,7 +978,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
     else if (role == 1) shade_body<1, EDGE ? 3 : 2>(E);
     else if (EDGE) shade_body<2, 3>(E);
     DDX_TRACE_END(E.trace, 2, ((unsigned long long)role << 32) |
-                  (unsigned)max(0, (E.L.b_count[blockIdx.y] - (int)((blockIdx.x + 8u * (blockIdx.y >> 3)) % gridDim.x) + (int)gridDim.x - 1) / (int)gridDim.x));
+                  (unsigned)max(0, (E.L.b_count[blockIdx.x] - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1227,10 +1239,10 @@ static const char* const kKernelNames[K_COUNT] = {"scatter_kernel", "compact_big
 // shading grid (S, B): enough x-slices that a hypothesis' active tiles (a few dozen) get one workgroup each
 static dim3 shade_grid(const ddx_engine_desc& d)
 {
-    int S = RASTER_GRID / d.B;
+    int S = SHADE_GRID / d.B;
     if (S < 1) S = 1;
     if (S > 64) S = 64;
-    return dim3(S, d.B);
+    return dim3(d.B, S);
 }
 
 // first iteration of a run: pose -> clip/snap (later iterations inherit them from update_xfm_kernel)
