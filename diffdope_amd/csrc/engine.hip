@@ -633,7 +633,8 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
         const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
-        float* part = E.partials + (((size_t)flat * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
+        // stored by POSITION k in the hypothesis' ordered active list: update_xfm_kernel reads one contiguous run
+        float* part = E.partials + ((((size_t)b * L.NT + k) * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
         // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
         bool anycov = false;
 #pragma unroll
@@ -1003,10 +1004,17 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     __shared__ float snew[8];     // updated parameters
     __shared__ float sG[16];
     __shared__ float sgrad[8];
-    __shared__ int s_tiles[256], s_tidx[256];
+    __shared__ int s_tiles[256];
     const int it = E.st->it;
     const int NT = E.L.NT;
     DDX_TRACE_BEGIN();
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+    unsigned long long uph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define UPH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); uph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define UPH(i)
+#endif
+    UPH(0);
     // ---- parallel prefetch: params 0..6, lr_mult 7, lr 8, m23 9, proj 16..31, adam 32..45
     const int cur = it & 1;
     if (tid < 7) sc[tid] = E.params2[((size_t)cur * 7 + tid) * B + b];
@@ -1014,9 +1022,6 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     else if (tid == 8) sc[8] = E.b.lr_sched[it];
     else if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
     else if (tid >= 32 && tid < 46) sc[tid] = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
-    // ---- this hypothesis' active tiles come ordered by tile index (compact_big_kernel): sum their quadrant
-    // partials in that fixed order (bit-reproducible); re-arm what the iteration dirtied (zbuf of the active
-    // tiles, their flags) so that the next iteration needs no memset -- tile k is re-armed by slice k % UPD_SLICES.
     const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < NVALS of group g sums value j
     float acc = 0.f;
     const int n_act = E.L.b_count[b];
@@ -1025,6 +1030,16 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     // first chunk of the tile list (speculative: entries beyond n_act are stale and unused), the compact seg list
     // of the background depth term, and the first batch of vertex positions of the transform at the end.  The
     // kernel is a chain of dependent round trips; these three would otherwise each add one.
+    constexpr int PER = 4 * NR;  // partial slots per tile
+    const int rmask = E.role_mask;
+    const float* pbase = E.partials + (size_t)b * NT * PER * NPART + j;
+    float v0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s = grp + u * 8;
+        const bool ok = j < NVALS && s < NT * PER && ((rmask >> (s % NR)) & 1);
+        v0[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
+    }
     const int txy_first = tid < NT ? tiles[tid] : 0;
     const int ns = d.use_depth ? E.st->n_seg : 0;
     const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
@@ -1043,52 +1058,56 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
         px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
     }
+    // ---- partial sums.  The quadrant partials are stored by position in the hypothesis' ordered active list, so the
+    // slots (tile position, quadrant, role) of hypothesis b are ONE contiguous run: v0[] was requested before the
+    // count was known; fixed order => bit-reproducible
+    {
+        const int nslot = n_act * PER;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (grp + u * 8 < nslot) ? v0[u] : 0.f;
+        if (j < NVALS)
+            for (int s0 = grp + 64; s0 < nslot; s0 += 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per slot)
+                    const int s = s0 + u * 8;
+                    const bool ok = s < nslot && ((rmask >> (s % NR)) & 1);
+                    v[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+    }
+    // ---- re-arm what the iteration dirtied (zbuf of the active tiles, their flags) so that the next iteration needs
+    // no memset -- tile k is re-armed by slice k % UPD_SLICES.  Independent of the sums.
     for (int start = 0; start < n_act; start += 256) {
         __syncthreads();
         if (start + tid < n_act) {
             const int txy = start == 0 ? txy_first : tiles[start + tid];
-            const int tile = (txy >> 16) * E.L.ntx + (txy & 0xffff);
             s_tiles[tid] = txy;
-            s_tidx[tid] = tile;
             if (((start + tid) % UPD_SLICES) == slice) {
+                const int tile = (txy >> 16) * E.L.ntx + (txy & 0xffff);
                 E.L.tile_flag[(size_t)b * NT + tile] = 0;
                 E.L.tile_big[(size_t)b * NT + tile] = 0;
             }
         }
         __syncthreads();
         const int na = min(256, n_act - start);
-        if (j < NVALS) {
-            // slots = (tile, quadrant, role slot) in fixed order; loads are issued 8 at a time before they are
-            // consumed (a load-add-load-add chain would pay one L2 round trip per slot)
-            constexpr int PER = 4 * NR;  // slots per tile
-            const int nslot = na * PER;
-            const int rmask = E.role_mask;
-            for (int s0 = grp; s0 < nslot; s0 += 64) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int s = s0 + u * 8;
-                    const int ti = s / PER, within = s % PER;
-                    const bool ok = s < nslot && ((rmask >> (within % NR)) & 1);
-                    v[u] = ok ? E.partials[((size_t)(b * NT + s_tidx[ti]) * PER + within) * NPART + j] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
-            }
-        }
         const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
         for (int s = slice; s < na; s += UPD_SLICES) {  // (start is a multiple of 256, hence of UPD_SLICES)
             const int txy = s_tiles[s];
-            const int px = (txy & 0xffff) * DDX_TILE + lx, py = (txy >> 16) * DDX_TILE + ly;
-            if (px < d.W && py < d.H) E.L.zbuf[((size_t)b * d.H + py) * d.W + px] = ~0ull;
+            const int zx = (txy & 0xffff) * DDX_TILE + lx, zy = (txy >> 16) * DDX_TILE + ly;
+            if (zx < d.W && zy < d.H) E.L.zbuf[((size_t)b * d.H + zy) * d.W + zx] = ~0ull;
         }
     }
+    UPH(1);
     acc += __shfl_xor(acc, 32, 64);  // groups 2w and 2w+1 live in wave w
     __syncthreads();
     if (lane < NPART) red[wave][lane] = acc;
     __syncthreads();
     if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     __syncthreads();
+    UPH(2);
     // ---- whole-frame background depth term over the compact seg list
     float bgsum = 0.f, bgder = 0.f;
     if (d.use_depth) {
@@ -1112,6 +1131,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         bgsum = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         bgder = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
+    UPH(3);
     // ---- tail on wave 0, one lane per output where the work allows
     const bool writer = slice == 0;
     if (wave == 0) {
@@ -1192,7 +1212,9 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
             }
         }
     }
+    UPH(4);
     __syncthreads();
+    UPH(5);
     // ---- transform this slice of the vertices with the NEW pose (next iteration's pose_xfm)
     float q[4], t[3], M[16], F[16];
 #pragma unroll
@@ -1200,6 +1222,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = snew[4 + i];
     pose_matrices(q, t, sc + 16, M, F);
+    UPH(6);
     if (writer && tid == 0) {
         float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
         float* logm = (E.b.mtx_log && it + 1 < d.max_iters) ? E.b.mtx_log + ((size_t)(it + 1) * B + b) * 16 : nullptr;
@@ -1227,6 +1250,17 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
             if (n0 + u * 256 < n_end) xfm_vertex_regs(E, F, b, n, n < n_end, lane, px[u], py[u], pz[u]);
         }
     }
+    UPH(7);
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+    if (tid == 0) {
+        const size_t wg = blockIdx.x + gridDim.x * (size_t)blockIdx.y;
+        if (wg < 4096) {
+            unsigned long long* q = E.trace + ((size_t)1 * 8192) * 4 + wg * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = uph[i];
+        }
+    }
+#endif
     DDX_TRACE_END(E.trace, 3, 1ull);
 }
 
