@@ -205,29 +205,51 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
                                                       int T, int H, int W, RasterScratch L)
 {
     DDX_TRACE_BEGIN();
-    const int b = blockIdx.y;
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+    unsigned long long sph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SPH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SPH(i)
+#endif
+    SPH(0);
+    // (an XCD-aware mapping -- hypothesis b entirely on XCD b % 8 through a 1-D grid -- was measured: +-0 on cfg2,
+    // -8 % on cfg3/cfg4; the plain 2-D grid stays)
+    const int b = blockIdx.y, chunk = blockIdx.x;
     const int2* S = L.snap + (size_t)b * V;
     int t[SCATTER_TPL], i0[SCATTER_TPL], i1[SCATTER_TPL], i2[SCATTER_TPL];
     bool ok[SCATTER_TPL];
     int2 va[SCATTER_TPL], vb[SCATTER_TPL], vc[SCATTER_TPL];
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
-        t[k] = (blockIdx.x * SCATTER_TPL + k) * 256 + threadIdx.x;
+        t[k] = (chunk * SCATTER_TPL + k) * 256 + threadIdx.x;
         const int tt = min(t[k], T - 1);
         i0[k] = tri[tt * 3 + 0]; i1[k] = tri[tt * 3 + 1]; i2[k] = tri[tt * 3 + 2];
     }
+    SPH(1);
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
         ok[k] = t[k] < T && (unsigned)i0[k] < (unsigned)V && (unsigned)i1[k] < (unsigned)V && (unsigned)i2[k] < (unsigned)V;
         const int j0 = ok[k] ? i0[k] : 0, j1 = ok[k] ? i1[k] : 0, j2 = ok[k] ? i2[k] : 0;
         va[k] = S[j0]; vb[k] = S[j1]; vc[k] = S[j2];
     }
+    SPH(2);
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
         if (t[k] >= T) continue;
         if (!ok[k]) { L.trirange[(size_t)b * T + t[k]] = ~0u; continue; }
         scatter_one(pos, V, T, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k]);
+        SPH(3 + k);
     }
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+    if (threadIdx.x == 0 && L.trace) {
+        const size_t wg = blockIdx.x + gridDim.x * (size_t)blockIdx.y;
+        if (wg < 4096) {
+            unsigned long long* q = L.trace + ((size_t)1 * 8192) * 4 + wg * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = sph[i];
+        }
+    }
+#endif
     DDX_TRACE_END(L.trace, 0, 1ull);
 }
 
