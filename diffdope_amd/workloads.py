@@ -23,6 +23,11 @@ CONFIGS = {
     "cfg3ref": dict(rows=160, cols=160, B=128, H=480, W=640, textured=True, weights=dict(rgb=0.7, depth=1.0), tex=2048),
     # configs[3]: per-GPU share of the 512-hypothesis untextured job
     "cfg4": dict(rows=100, cols=150, B=64, H=480, W=640, textured=False, weights=dict(depth=1.0, mask=1.0), tex=0),
+    # configs[4]: one object of the BOP batch (32 objects x 64 hypotheses over 8 GPUs = 4 objects per GPU, run one
+    # after the other by bop.refine_frame): 1280x720, mixed losses incl. the edge extension
+    "cfg5": dict(rows=80, cols=128, B=64, H=720, W=1280, textured=True, weights=dict(rgb=0.7, depth=1.0, edge=1.0), tex=2048),
+    # north_star target sentence: 64 hypotheses of a 50k-triangle textured mesh at 640x480 (reference losses)
+    "cfg50k64": dict(rows=160, cols=160, B=64, H=480, W=640, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
     "tiny": dict(rows=16, cols=20, B=4, H=60, W=80, textured=True, weights=dict(rgb=0.7, depth=1.0, mask=1.0), tex=64),
 }
 
