@@ -1,0 +1,41 @@
+"""Op-by-op (materialising) path: render_texture_batch + torch L1 losses + autograd backward + SGD step on a BASELINE
+workload -- the compatibility path user loss functions take (every image materialised in HBM), next to the fused engine."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diffdope_amd as dd
+from diffdope_amd import workloads as wl
+from diffdope_amd.render import RasterizeContext, render_texture_batch
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+dev = torch.device('cuda:0')
+w = wl.build(cfg, dev)
+B, H, W = w['B'], w['H'], w['W']
+params = w['params0'].clone().requires_grad_(True)
+ctx = RasterizeContext()
+ex = lambda t: t[None].expand(B, *t.shape)
+kw = dict(uv=ex(w['uv']), uv_idx=ex(w['tri']), tex=ex(w['tex'])) if w['uv'] is not None else dict(vtx_color=ex(w['vtx_color']))
+gt = {k: v[None] for k, v in w['gt'].items()}
+lr_mult = w['lr_mult']
+wt = w['weights']
+
+def step():
+    q = params[:4].T / torch.norm(params[:4].T, dim=1, keepdim=True)
+    mtx = dd.matrix_batch_44_from_position_quat(q=q, p=params[4:].T)
+    r = render_texture_batch(ctx, ex(w['proj']), mtx, ex(w['pos']), ex(w['tri']), [H, W], **kw)
+    loss = 0
+    if wt.get('rgb') is not None:
+        loss = loss + (torch.abs((r['rgb'] - gt['rgb']) * gt['segmentation']).mean((1, 2, 3)) * lr_mult).mean() * wt['rgb']
+    if wt.get('depth') is not None:
+        loss = loss + (torch.abs((r['depth'] - gt['depth']) * gt['segmentation'][..., 0]).mean((1, 2)) * lr_mult).mean() * wt['depth']
+    if wt.get('mask') is not None:
+        loss = loss + (torch.abs(r['mask'] - gt['segmentation']).mean((1, 2, 3)) * lr_mult).mean() * wt['mask']
+    g, = torch.autograd.grad(loss, params)
+    with torch.no_grad():
+        params.sub_(1e-3 * g)
+
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = 20
+for _ in range(n): step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(f'{cfg}: op-by-op path {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s  (peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB)')
