@@ -226,3 +226,46 @@ def test_engine_with_edge_extension_tracks_oracle_over_iterations():
     np.testing.assert_allclose(lg[0, 3], logs_ref["edge"][0], rtol=1e-4)
     assert np.all(lg[:, 2] == 0)
     assert lg[-1, 3].min() < lg[0, 3].min()
+
+
+@pytest.mark.parametrize("rows,cols,H,W,weights", [(160, 160, 480, 640, dict(rgb=0.7, depth=1.0, edge=1.0)),   # BASELINE config 3
+                                                   (80, 128, 720, 1280, dict(rgb=0.7, depth=1.0, edge=1.0)),   # config 5 (one object)
+                                                   (100, 150, 480, 640, dict(depth=1.0, mask=1.0))])           # config 4 mesh size
+def test_engine_full_size_one_hypothesis_against_oracle_and_batch_properties(rows, cols, H, W, weights):
+    """Full BASELINE sizes.  The oracle renders ONE hypothesis (seconds); the batch of 16 is checked through
+    size-independent properties: hypotheses with identical parameters and multipliers give bit-identical losses and
+    updates, wherever they sit in the batch, and the per-hypothesis result does not depend on the batch around it
+    beyond the global 1/B factor."""
+    textured = "mask" not in weights or "rgb" in weights
+    sc = make_scene(rows, cols, H, W, B=16, dist=7.5, textured=textured, tex_size=256)
+    R = sc["oracle"]
+    R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
+    params = sc["params"].copy()
+    lrm = sc["lr_mult"].copy()
+    params[:, 9] = params[:, 2]
+    lrm[9] = lrm[2]
+    sc = dict(sc, params=params, lr_mult=lrm)
+    lr = 0.25
+    eng, p = _engine(sc, weights, [lr])
+    eng.run()
+    torch.cuda.synchronize()
+    eng.check()
+    lg = eng.losses()[0].cpu().numpy()
+    pn = p.cpu().numpy()
+    assert np.array_equal(lg[:, 2], lg[:, 9]) and np.array_equal(pn[:, 2], pn[:, 9])
+    # one hypothesis against the oracle (global_B keeps the 1/B factor of the batch mean)
+    total, logs, g_ref, _ = R.loss_and_grad(params[:, 2:3], lrm[2:3], global_B=16)
+    g_gpu = (params[:, 2] - pn[:, 2]) / lr
+    np.testing.assert_allclose(g_gpu, g_ref[:, 0], rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    for i, key in enumerate(KEYS):
+        if key in logs:
+            np.testing.assert_allclose(lg[i, 2], logs[key][0], rtol=5e-5, atol=1e-7)
+    # the same hypothesis alone in a batch of one: identical losses, gradient x16
+    sc1 = dict(sc, params=params[:, 2:3].copy(), lr_mult=lrm[2:3].copy(), B=1)
+    eng1, p1 = _engine(sc1, weights, [lr])
+    eng1.run()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(eng1.losses()[0].cpu().numpy()[:, 0], lg[:, 2], rtol=1e-6, atol=0)
+    g1 = (params[:, 2] - p1.cpu().numpy()[:, 0]) / lr
+    # (gradients are read back as parameter differences: resolution ulp(7.5) / lr = 2e-6, x16 for the batch of one)
+    np.testing.assert_allclose(g1, g_gpu * 16, rtol=2e-4, atol=4e-5)

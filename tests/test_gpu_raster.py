@@ -25,7 +25,10 @@ def _check_rast(rast_gpu, rast_ref):
     np.testing.assert_allclose(rast_gpu[..., :3], rast_ref[..., :3], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("rows,cols,H,W,dist", [(10, 14, 48, 64, 2.0), (40, 64, 120, 160, 7.5), (24, 30, 50, 70, 1.2), (80, 128, 480, 640, 7.5)])
+@pytest.mark.parametrize("rows,cols,H,W,dist", [(10, 14, 48, 64, 2.0), (40, 64, 120, 160, 7.5), (24, 30, 50, 70, 1.2), (80, 128, 480, 640, 7.5),
+                                                (160, 160, 480, 640, 7.5),    # BASELINE config 3 mesh: 51 200 triangles, sub-pixel
+                                                (80, 128, 720, 1280, 7.5),    # config 5 resolution
+                                                (16, 20, 720, 1280, 1.0)])    # few big triangles filling a 1280x720 frame (tile pass)
 def test_rasterize_ids_bit_identical(rows, cols, H, W, dist):
     import diffdope_amd as dd
     from oracle import oracle as orc
