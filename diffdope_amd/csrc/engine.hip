@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int it = E.st->it;
         if (b == 0) E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
+        E.L.bigcount[b] = 0;              // the hypothesis' list of large triangles, filled again by scatter_kernel
         float* dst = E.mats + ((size_t)(it & 1) * B + b) * 32;
         float* pp = E.params2 + (size_t)(it & 1) * 7 * B;
 #pragma unroll
@@ -1224,6 +1225,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     pose_matrices(q, t, sc + 16, M, F);
     UPH(6);
     if (writer && tid == 0) {
+        E.L.bigcount[b] = 0;  // re-arm the hypothesis' list of large triangles
         float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
         float* logm = (E.b.mtx_log && it + 1 < d.max_iters) ? E.b.mtx_log + ((size_t)(it + 1) * B + b) * 16 : nullptr;
 #pragma unroll

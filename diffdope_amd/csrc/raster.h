@@ -5,7 +5,7 @@
 
 #define RASTER_GRID 2048      // persistent workgroups striding over the active tiles
 #define RASTER_SMALL_PX 16    // triangles whose bbox holds at most this many pixel centres are resolved in scatter_kernel
-#define RASTER_BIG_GRID 256   // workgroups of the large-triangle pass
+#define RASTER_BIG_GRID 1024  // workgroups of the large-triangle pass
 
 struct RasterScratch {
     int* counters;            // [16]: 3 = large triangles of this pass
@@ -14,10 +14,11 @@ struct RasterScratch {
     int* active;              // [B,NT] per-hypothesis ordered list of active tiles, packed ty << 16 | tx (first b_count[b] entries)
     int* b_count;             // [B] active tiles of each hypothesis
     int2* snap;               // [B,V] window coordinates in 1/256 px (x = INT_MIN if w <= 0)
-    unsigned* trirange;       // [B,T] packed tile range of a LARGE triangle: tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24; ~0u otherwise
+    uint2* biglist;           // [B,T] the LARGE triangles of each hypothesis: (triangle id, packed tile range tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24)
+    int* bigcount;            // [B] entries of biglist (appended by scatter_kernel, one atomic per wave; re-armed by the consumer)
     unsigned long long* zbuf; // [B,H,W] (depth key << 32 | triangle id), all ones = background
     size_t zbuf_bytes;
-    size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big)
+    size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount)
     int ntx, nty, NT;
     PixNdc ndc;               // pixel index -> NDC centre constants for (H, W)
 #ifdef DDX_TRACE

@@ -43,11 +43,12 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     const size_t o_counters = carve(16 * sizeof(int));
     const size_t o_flag = carve((size_t)B * NT * sizeof(int));
     const size_t o_big = carve((size_t)B * NT * sizeof(int));
-    L.zero_bytes = off;  // [counters | tile_flag | tile_big] must be zero when a pass starts
+    const size_t o_bigcount = carve((size_t)B * sizeof(int));
+    L.zero_bytes = off;  // [counters | tile_flag | tile_big | bigcount] must be zero when a pass starts
     const size_t o_active = carve((size_t)B * NT * sizeof(int));
     const size_t o_bcount = carve((size_t)B * sizeof(int));
     const size_t o_snap = carve((size_t)B * V * sizeof(int2));
-    const size_t o_range = carve((size_t)B * T * sizeof(unsigned));
+    const size_t o_range = carve((size_t)B * T * sizeof(uint2));
     const size_t o_zbuf = carve((size_t)B * H * W * sizeof(unsigned long long));
     L.counters = (int*)(p + o_counters);
     L.tile_flag = (int*)(p + o_flag);
@@ -55,7 +56,8 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.active = (int*)(p + o_active);
     L.b_count = (int*)(p + o_bcount);
     L.snap = (int2*)(p + o_snap);
-    L.trirange = (unsigned*)(p + o_range);
+    L.biglist = (uint2*)(p + o_range);
+    L.bigcount = (int*)(p + o_bigcount);
     L.zbuf = (unsigned long long*)(p + o_zbuf);
     L.zbuf_bytes = (size_t)B * H * W * sizeof(unsigned long long);
     L.ntx = ntx; L.nty = nty; L.NT = (int)NT;
@@ -116,8 +118,9 @@ __device__ __forceinline__ Edge32 make_edge(int ax, int ay, int bx, int by, int 
 
 #define SCATTER_TPL 2  // triangles per lane: both index/vertex gathers are issued before either is consumed
 
-__device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V, int T, int H, int W, const RasterScratch& L,
-                                            int b, int t, int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c)
+// returns the packed tile range of a LARGE triangle (resolved later by the tile pass), ~0u otherwise
+__device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int T, int H, int W, const RasterScratch& L,
+                                                int b, int t, int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c)
 {
     unsigned range = ~0u;  // packed tile range of a LARGE triangle
     if (a.x != INT_MIN && bq.x != INT_MIN && c.x != INT_MIN) {
@@ -198,7 +201,7 @@ __device__ __forceinline__ void scatter_one(const float* __restrict__ pos, int V
             }
         }
     }
-    L.trirange[(size_t)b * T + t] = range;
+    return range;
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
@@ -233,12 +236,25 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
         va[k] = S[j0]; vb[k] = S[j1]; vc[k] = S[j2];
     }
     SPH(2);
+    unsigned range[SCATTER_TPL];
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
-        if (t[k] >= T) continue;
-        if (!ok[k]) { L.trirange[(size_t)b * T + t[k]] = ~0u; continue; }
-        scatter_one(pos, V, T, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k]);
+        range[k] = ~0u;
+        if (t[k] >= T || !ok[k]) continue;
+        range[k] = scatter_one(pos, V, T, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k]);
         SPH(3 + k);
+    }
+    // LARGE triangles go to the hypothesis' list for the tile pass: one atomic per WAVE that has any (none in the
+    // micro-polygon regime), the lanes take consecutive slots.  The order of the list does not matter (atomicMin).
+#pragma unroll
+    for (int k = 0; k < SCATTER_TPL; ++k) {
+        const unsigned long long m = __ballot(range[k] != ~0u);
+        if (m == 0ull) continue;
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(L.bigcount + b, __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (range[k] != ~0u) L.biglist[(size_t)b * T + base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)t[k], range[k]);
     }
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
     if (threadIdx.x == 0 && L.trace) {
@@ -260,15 +276,20 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
 //     otherwise stride over all (b, tile) with tile_big set: sweep the hypothesis' packed ranges,
 //     ballot-compact the triangles overlapping the tile into LDS, then lane = pixel (exact int64 coverage),
 //     merging into zbuf with atomicMin.
-#define BIG_LIST 512
+#define BIG_SCAN 1024  // (hypothesis, tile) flags scanned per step of the large-triangle pass
 
 __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int B,
                                                           int V, int T, int H, int W, RasterScratch L)
 {
-    __shared__ int list[BIG_LIST];
     __shared__ int wcnt[4];
-    __shared__ int n_list;
+    __shared__ int4 s_e0[256], s_e1[256], s_e2[256];  // staged LARGE triangles: per edge (e.lo, e.hi, step x, step y) at the tile origin
+    __shared__ int s_t[256];                          // ... their ids
+    __shared__ float4 s_p0[256], s_p1[256], s_p2[256];  // ... and their clip-space vertices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    DDX_TRACE_BEGIN();
+#ifdef DDX_TRACE
+    unsigned long long n_done = 0;
+#endif
     if ((int)blockIdx.x < B) {
         const int b = blockIdx.x;
         const int* flg = L.tile_flag + (size_t)b * L.NT;
@@ -290,58 +311,128 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
         return;
     }
     if (L.counters[3] == 0) return;  // no large triangle in the whole batch
-    const int total = B * L.NT;
-    for (int flat = blockIdx.x - B; flat < total; flat += gridDim.x - B) {
-        if (L.tile_big[flat] == 0) continue;
+    // workgroup g owns the pairs (b, tile) with tile = (g - 13 b) mod G (+ multiples of G): the large tiles of one object
+    // are neighbours, and the objects of all hypotheses sit at about the same place on screen -- both a contiguous and
+    // a plain strided split pile them up on a few workgroups (measured: 4 tiles on some, none on most).  The flags of
+    // BIG_SCAN pairs are read in parallel and compacted into LDS.
+    __shared__ int s_big[BIG_SCAN];
+    __shared__ int s_nbig;
+    const int G = gridDim.x - B, g = blockIdx.x - B;
+    const int per_b = (L.NT + G - 1) / G;          // candidate tiles per hypothesis for this workgroup
+    const int n_cand = B * per_b;
+    for (int base = 0; base < n_cand; base += BIG_SCAN) {
+    __syncthreads();
+    if (tid == 0) s_nbig = 0;
+    __syncthreads();
+    for (int j = base + tid; j < min(n_cand, base + BIG_SCAN); j += 256) {
+        const int bb = j / per_b, kk = j - bb * per_b;
+        int t0 = (g - 13 * bb) % G;
+        if (t0 < 0) t0 += G;
+        const int tile = t0 + kk * G;
+        if (tile < L.NT) {
+            const int i = bb * L.NT + tile;
+            if (L.tile_big[i] != 0) s_big[atomicAdd(&s_nbig, 1)] = i;  // LDS atomic; the order does not matter (atomicMin below)
+        }
+    }
+    __syncthreads();
+    const int nbig = s_nbig;
+    for (int e = 0; e < nbig; ++e) {
+        const int flat = s_big[e];
         const int b = flat / L.NT, tile = flat - b * L.NT;
         const int tcx = tile % L.ntx, tcy = tile / L.ntx;
         const float* P = pos + (size_t)b * V * 4;
         const int2* S = L.snap + (size_t)b * V;
-        const unsigned* R = L.trirange + (size_t)b * T;
+        const uint2* BL = L.biglist + (size_t)b * T;
+        const int n_big = min(L.bigcount[b], T);
         const int px = tcx * DDX_TILE + tid % DDX_TILE, py = tcy * DDX_TILE + tid / DDX_TILE;
         const bool inimg = px < W && py < H;
         unsigned long long best = ~0ull;
-        for (int t0 = 0; t0 < T; t0 += BIG_LIST) {
-            // ---- compact the triangles of [t0, t0+BIG_LIST) whose tile range contains this tile (ordered)
-            __syncthreads();
-            if (tid == 0) n_list = 0;
-            __syncthreads();
-            for (int sub = 0; sub < BIG_LIST; sub += 256) {
-                const int t = t0 + sub + tid;
-                bool hit = false;
-                if (t < T) {
-                    const unsigned r = R[t];
-                    if (r != ~0u) {
-                        const int x0 = r & 255, y0 = (r >> 8) & 255, nx = (r >> 16) & 255, ny = r >> 24;
-                        hit = tcx >= x0 && tcx <= x0 + nx && tcy >= y0 && tcy <= y0 + ny;
+        for (int r0 = 0; r0 < n_big; r0 += 256) {
+            // ---- the LARGE triangles of this hypothesis whose tile range contains this tile: ballot-compacted, and
+            // everything the pixel loop needs (snapped + clip-space vertices) is staged in LDS by the thread that found
+            // the hit -- 256 parallel gathers instead of one dependent gather chain per triangle and pixel loop step
+            const int idx = r0 + tid;
+            bool hit = false;
+            uint2 ent = make_uint2(0u, 0u);
+            if (idx < n_big) {
+                ent = BL[idx];
+                const unsigned r = ent.y;
+                const int x0 = r & 255, y0 = (r >> 8) & 255, nx = (r >> 16) & 255, ny = r >> 24;
+                hit = tcx >= x0 && tcx <= x0 + nx && tcy >= y0 && tcy <= y0 + ny;
+            }
+            // the packed range is the triangle's bbox in tiles: refine with the exact edge predicate at the four corner
+            // pixel centres of the tile -- all four outside one edge => no centre of the tile can be covered
+            int i0 = 0, i1 = 0, i2 = 0;
+            int4 es[3] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+            if (hit) {
+                const int t = (int)ent.x;
+                i0 = tri[t * 3 + 0]; i1 = tri[t * 3 + 1]; i2 = tri[t * 3 + 2];
+                const int2 sa = S[i0], sb = S[i1], sc = S[i2];
+                SnapTri st;
+                snap_from_vertices(sa, sb, sc, st);
+                hit = st.ok;
+                if (hit) {
+                    const int cx0 = (tcx * DDX_TILE) * DDX_SUBPIX + DDX_SUBPIX / 2, cy0 = (tcy * DDX_TILE) * DDX_SUBPIX + DDX_SUBPIX / 2;
+                    const int cx1 = (min(tcx * DDX_TILE + DDX_TILE, W) - 1) * DDX_SUBPIX + DDX_SUBPIX / 2;
+                    const int cy1 = (min(tcy * DDX_TILE + DDX_TILE, H) - 1) * DDX_SUBPIX + DDX_SUBPIX / 2;
+                    const bool flip = st.area < 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int ka = (k + 1) % 3, kb = (k + 2) % 3;
+                        const bool any_in = edge_inside(st.X[ka], st.Y[ka], st.X[kb], st.Y[kb], cx0, cy0, flip) ||
+                                            edge_inside(st.X[ka], st.Y[ka], st.X[kb], st.Y[kb], cx1, cy0, flip) ||
+                                            edge_inside(st.X[ka], st.Y[ka], st.X[kb], st.Y[kb], cx0, cy1, flip) ||
+                                            edge_inside(st.X[ka], st.Y[ka], st.X[kb], st.Y[kb], cx1, cy1, flip);
+                        hit = hit && any_in;
+                        // tile-local form of the same exact edge function for the pixel loop: value at the tile's first
+                        // pixel centre (int64) with the ownership rule folded in (e + own - 1 >= 0), and the 32-bit
+                        // steps per pixel in x and y
+                        int dx = st.X[kb] - st.X[ka], dy = st.Y[kb] - st.Y[ka];
+                        long long e = (long long)dx * (long long)(cy0 - st.Y[ka]) - (long long)dy * (long long)(cx0 - st.X[ka]);
+                        if (flip) { e = -e; dx = -dx; dy = -dy; }
+                        e += ((dy > 0) || (dy == 0 && dx < 0)) ? 0 : -1;
+                        es[k] = make_int4((int)(unsigned)(e & 0xffffffffll), (int)(e >> 32), -dy * DDX_SUBPIX, dx * DDX_SUBPIX);
                     }
                 }
-                const unsigned long long m = __ballot(hit);
-                if (lane == 0) wcnt[wave] = __popcll(m);
-                __syncthreads();
-                int off = n_list;
-                for (int w = 0; w < wave; ++w) off += wcnt[w];
-                if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = t;
-                __syncthreads();
-                if (tid == 0) n_list += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-                __syncthreads();
             }
-            // ---- lane = pixel over the compacted triangles (wave-uniform walk)
-            const int nl = n_list;
-            if (inimg)
-                for (int j = 0; j < nl; ++j) {
-                    const int t = list[j];
-                    const int i0 = tri[t * 3 + 0], i1 = tri[t * 3 + 1], i2 = tri[t * 3 + 2];
-                    SnapTri s;
-                    snap_from_vertices(S[i0], S[i1], S[i2], s);
-                    if (!tri_covers(s, px, py)) continue;
-                    const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
-                    const unsigned long long key = frag_key(p0, p1, p2, px, py, H, W, t);
+            const unsigned long long m = __ballot(hit);
+            __syncthreads();  // (the previous round's pixel loop is done with the staging arrays and wcnt)
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = 0;
+            for (int w = 0; w < wave; ++w) off += wcnt[w];
+            const int nh = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            if (hit) {
+                const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+                const int t = (int)ent.x;
+                s_e0[slot] = es[0]; s_e1[slot] = es[1]; s_e2[slot] = es[2];
+                s_t[slot] = t;
+                s_p0[slot] = ld4(P + (size_t)i0 * 4);
+                s_p1[slot] = ld4(P + (size_t)i1 * 4);
+                s_p2[slot] = ld4(P + (size_t)i2 * 4);
+            }
+            __syncthreads();
+            // ---- lane = pixel over the staged triangles (wave-uniform walk, LDS broadcast reads)
+            if (inimg) {
+                const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
+                for (int j = 0; j < nh; ++j) {
+                    const int4 q0 = s_e0[j], q1 = s_e1[j], q2 = s_e2[j];
+                    const long long v0 = (((long long)q0.y << 32) | (unsigned)q0.x) + (long long)lx * q0.z + (long long)ly * q0.w;
+                    const long long v1 = (((long long)q1.y << 32) | (unsigned)q1.x) + (long long)lx * q1.z + (long long)ly * q1.w;
+                    const long long v2 = (((long long)q2.y << 32) | (unsigned)q2.x) + (long long)lx * q2.z + (long long)ly * q2.w;
+                    if ((v0 | v1 | v2) < 0) continue;
+                    const unsigned long long key = frag_key(s_p0[j], s_p1[j], s_p2[j], px, py, H, W, s_t[j]);
                     best = key < best ? key : best;
                 }
+            }
         }
         if (best != ~0ull) atomicMin(L.zbuf + ((size_t)b * H + py) * W + px, best);
+#ifdef DDX_TRACE
+        n_done += 1 + ((unsigned long long)n_big << 32);
+#endif
     }
+    }
+    DDX_TRACE_END(L.trace, 1, n_done);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -28,6 +28,8 @@ CONFIGS = {
     "cfg5": dict(rows=80, cols=128, B=64, H=720, W=1280, textured=True, weights=dict(rgb=0.7, depth=1.0, edge=1.0), tex=2048),
     # north_star target sentence: 64 hypotheses of a 50k-triangle textured mesh at 640x480 (reference losses)
     "cfg50k64": dict(rows=160, cols=160, B=64, H=480, W=640, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
+    # low-polygon CAD-like mesh (T-LESS CAD models have large flat faces): every triangle takes the tile pass
+    "lowpoly": dict(rows=12, cols=16, B=64, H=480, W=640, textured=False, weights=dict(depth=1.0, mask=1.0), tex=0),
     "tiny": dict(rows=16, cols=20, B=4, H=60, W=80, textured=True, weights=dict(rgb=0.7, depth=1.0, mask=1.0), tex=64),
 }
 

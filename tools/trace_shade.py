@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffdope_amd as dd
 from diffdope_amd import workloads as wl, _lib
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
-KIDX = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # 0 scatter, 2 shade, 3 update
+KIDX = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # 0 scatter, 1 compact/big-tile pass, 2 shade, 3 update
 w = wl.build(cfg, torch.device('cuda:0'))
 eng = dd.RefineEngine(w['pos'], w['tri'], w['proj'], [w['H'], w['W']], w['gt'], w['params0'].clone(), w['lr_mult'], [0.0] * 60, w['weights'], uv=w['uv'], tex=w['tex'], vtx_color=w['vtx_color'])
 eng.run(20)
