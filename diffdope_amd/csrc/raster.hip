@@ -116,6 +116,11 @@ __device__ __forceinline__ Edge32 make_edge(int ax, int ay, int bx, int by, int 
     return e;
 }
 
+#if RASTER_SMALL_PX > 32
+typedef unsigned long long scatter_mask_t;
+#else
+typedef unsigned scatter_mask_t;
+#endif
 #define SCATTER_TPL 2  // triangles per lane: both index/vertex gathers are issued before either is consumed
 
 // returns the packed tile range of a LARGE triangle (resolved later by the tile pass), ~0u otherwise
@@ -144,16 +149,16 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                     const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
                     const Edge32 e1 = make_edge(c.x, c.y, a.x, a.y, X0, Y0, flip);
                     const Edge32 e2 = make_edge(a.x, a.y, bq.x, bq.y, X0, Y0, flip);
-                    // pass 1: coverage of the <= 16 bbox centres as a bit mask -- integer only; the ownership rule
+                    // pass 1: coverage of the <= RASTER_SMALL_PX bbox centres as a bit mask -- integer only; the ownership rule
                     // (v > 0 || (v == 0 && own)) is folded into the start value: v + own - 1 >= 0
                     const int b0 = e0.e00 + (int)e0.own - 1, b1 = e1.e00 + (int)e1.own - 1, b2 = e2.e00 + (int)e2.own - 1;
-                    unsigned mask = 0;
+                    scatter_mask_t mask = 0;
                     int idx = 0;
                     int r0 = b0, r1 = b1, r2 = b2;
                     for (int j = 0; j < nyp; ++j, r0 += e0.sy, r1 += e1.sy, r2 += e2.sy) {
                         int v0 = r0, v1 = r1, v2 = r2;
                         for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
-                            mask |= (unsigned)((v0 | v1 | v2) >= 0) << idx;
+                            mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
                     }
                     // pass 2: one depth evaluation + one atomic per covered centre: the wave walks max(popcount)
                     // rounds instead of max(bbox area), and the clip-space vertices are loaded once, up front
@@ -164,7 +169,7 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                         const PixNdc ndc = L.ndc;  // host-computed (IEEE divisions, same values as make_pixndc)
                         const float rn = __frcp_rn((float)nxp);
                         while (mask) {
-                            const int k = __ffs(mask) - 1;
+                            const int k = RASTER_SMALL_PX > 32 ? __ffsll((long long)mask) - 1 : __ffs((unsigned)mask) - 1;
                             mask &= mask - 1;
                             const int j = (int)(((float)k + 0.5f) * rn), i = k - __mul24(j, nxp);  // k = j * nxp + i, exact for k < 16
                             float zw;

@@ -30,6 +30,8 @@ CONFIGS = {
     "cfg50k64": dict(rows=160, cols=160, B=64, H=480, W=640, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
     # low-polygon CAD-like mesh (T-LESS CAD models have large flat faces): every triangle takes the tile pass
     "lowpoly": dict(rows=12, cols=16, B=64, H=480, W=640, textured=False, weights=dict(depth=1.0, mask=1.0), tex=0),
+    # in between: 5120 triangles at 1280x720, a mix of small (scatter) and large (tile pass) triangles
+    "midpoly": dict(rows=40, cols=64, B=64, H=720, W=1280, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
     "tiny": dict(rows=16, cols=20, B=4, H=60, W=80, textured=True, weights=dict(rgb=0.7, depth=1.0, mask=1.0), tex=64),
 }
 
