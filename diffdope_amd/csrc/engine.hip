@@ -613,8 +613,8 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     const float* __restrict__ pos = E.b.pos;
     const int* __restrict__ tri = E.b.tri;
     int* ids = s_ids[wave];
-    // grid (S, B): workgroup (s, b) takes tiles s, s+S, ... of hypothesis b's ordered active list -- no
-    // prefix over hypotheses, no global list, workgroups beyond the count leave after one scalar load
+    // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's ordered active list -- no prefix over hypotheses,
+    // no global list, workgroups beyond the count leave after one scalar load
     // grid (B, S, roles): x = hypothesis, y = slice.  Workgroups are dispatched in linear-id order and land on CUs
     // in a fixed pattern of that id (XCD = id % 8, CU = f(id/8 % 32), measured): slice-major order sends the
     // working slices of every hypothesis first and the idle ones (slice >= n_tiles) last, so the tail of the launch
@@ -1272,7 +1272,7 @@ __global__ void set_it_kernel(EngineState* st, int it) { st->it = it; st->it_nex
 enum { K_SCATTER, K_COMPACT_BIG, K_SHADE, K_UPDATE, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"scatter_kernel", "compact_big_kernel", "shade_kernel", "update_xfm_kernel"};
 
-// shading grid (S, B): enough x-slices that a hypothesis' active tiles (a few dozen) get one workgroup each
+// shading grid (B, S): S slices per hypothesis, SHADE_GRID workgroups per role in total (all resident at 4 waves/SIMD)
 static dim3 shade_grid(const ddx_engine_desc& d)
 {
     int S = SHADE_GRID / d.B;

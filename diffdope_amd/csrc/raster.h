@@ -3,7 +3,6 @@
 #pragma once
 #include "raster_math.h"
 
-#define RASTER_GRID 2048      // persistent workgroups striding over the active tiles
 #define RASTER_SMALL_PX 64    // bbox of at most this many pixel centres => resolved in scatter_kernel (16 / 32 / 64: midpoly 4.7k / 7.5k / 7.6k it/s, lowpoly 10.7k / 9.8k / 11.2k, cfg2 unchanged)
 #define RASTER_BIG_GRID 1024  // workgroups of the large-triangle pass
 

@@ -4,22 +4,22 @@
 // Meshes on this path are 20k-50k triangles landing on a few thousand pixels: most triangles own zero or
 // one pixel centre.  The rasteriser is therefore split by triangle size:
 //
-//   scatter_kernel   one lane per (hypothesis, triangle).  Three 8-byte gathers of the per-vertex snapped
-//                    window coordinates (1/256 px, produced once per vertex by the transform kernel), exact
-//                    integer setup, pixel-centre bbox.  No centre inside -> dead.  Up to RASTER_SMALL_PX
-//                    centres -> resolved right here: edge functions evaluated incrementally in 32-bit
-//                    integers relative to the bbox corner (exact: a small triangle spans < 2^13 sub-pixels),
-//                    fp32 z/w for the covered centres, one non-returning 64-bit atomicMin of
-//                    (depth key, id) per fragment into the depth/visibility buffer zbuf[b,y,x].
-//                    Larger -> its packed tile range is stored for raster_big_kernel.
-//                    Either way the 16x16 tiles under bbox + 1 px (antialias apron) are flagged active
-//                    with plain stores (no atomic on a hot word).
-//   compact_big_kernel  workgroups [0,B): ordered per-hypothesis compaction of the flags (active lists);
-//                    the other workgroups: tiles flagged in tile_big only (none in the micro-polygon regime:
-//                    they exit on one scalar load).  Such a workgroup sweeps the hypothesis' packed
-//                    ranges, ballot-compacts the triangles overlapping its tile into LDS, then the 256
-//                    lanes are the 256 pixels (exact int64 coverage), merging into zbuf with atomicMin.
-//                    No per-tile lists in memory, so nothing can overflow.
+//   scatter_kernel   one lane per (hypothesis, triangle), two triangles per lane.  Three 8-byte gathers of the
+//                    per-vertex snapped window coordinates (1/256 px, produced once per vertex by the transform
+//                    kernel), exact integer setup, pixel-centre bbox.  No centre inside -> dead.  Up to
+//                    RASTER_SMALL_PX centres -> resolved right here in two passes: the coverage of the bbox centres
+//                    as a bit mask (edge functions stepped in 32-bit integers relative to the bbox corner -- exact:
+//                    a small triangle spans < 2^13 sub-pixels), then per set bit fp32 z/w and one non-returning
+//                    64-bit atomicMin of (depth key, id) into the depth/visibility buffer zbuf[b,y,x].
+//                    Larger -> appended (id, packed tile range) to the hypothesis' list of LARGE triangles, one
+//                    atomic per wave that has any.  Either way the 16x16 tiles under bbox + 1 px (antialias apron)
+//                    are flagged active with plain stores (no atomic on a hot word).
+//   compact_big_kernel  workgroups [0,B): ordered per-hypothesis compaction of the flags (active lists); the other
+//                    workgroups are the tile pass for LARGE triangles (none in the micro-polygon regime: they exit
+//                    on one scalar load): per flagged tile, the hypothesis' list is range-tested in rounds of 256,
+//                    refined with the exact edge predicate at the tile corners, and the survivors are staged in LDS
+//                    (tile-local edge values + steps, clip vertices); then the 256 lanes are the 256 pixels,
+//                    merging into zbuf with atomicMin.  No per-tile lists in memory, so nothing can overflow.
 //   emit_kernel      (op-level API only) expands zbuf into nvdiffrast's rast tensor (u, v, z/w, id+1).
 //
 // zbuf invariant: all ones between passes.  The op-level entry memsets it; the fused engine re-arms only
