@@ -72,6 +72,8 @@ struct EngineDev {
     int n_roles;      // enabled shade roles (grid z of shade_kernel): 0 colour+depth, 1 antialiased mask, 2 edge
     int roles[MAX_ROLES];    // grid z -> role
     int role_mask;           // bit r set = role r runs
+    float* eval_grad;        // [7,B] or null.  Non-null = evaluation pass (ddx_engine_eval): d loss / d params and the
+    float* eval_loss;        // [4,B] losses are written here, no optimiser step, no transform for a next iteration
 #ifdef DDX_TRACE
     unsigned long long* trace;  // [4 kernels][8192 workgroups][4]: start, end (s_memtime), hw id, work units
 #endif
@@ -1139,13 +1141,14 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         const float npx = (float)d.H * (float)d.W;
         const float lrb = sc[7];
         // loss log: weighted, not LR-scaled (diffdope.py:558-560,576-578,604-608)
-        if (writer && lane < 4 && E.b.loss_log) {
+        if (writer && lane < 4 && (E.eval_grad ? E.eval_loss != nullptr : E.b.loss_log != nullptr)) {
             float v = 0.f;
             if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
             if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
             if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
             if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
-            E.b.loss_log[((size_t)it * 4 + lane) * B + b] = v;
+            if (E.eval_grad) E.eval_loss[(size_t)lane * B + b] = v;
+            else E.b.loss_log[((size_t)it * 4 + lane) * B + b] = v;
         }
         // d loss / d mtx = proj^T . dFinal (+ direct depth row): lane = k*4 + j
         if (lane < 16) {
@@ -1176,7 +1179,10 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         }
         wave_lds_sync();
         // optimiser step: lane = parameter
-        if (lane < 7) {
+        if (lane < 7 && E.eval_grad) {  // evaluation pass: hand out the gradient, leave every state as it is
+            if (writer) E.eval_grad[(size_t)lane * B + b] = sgrad[lane];
+            snew[lane] = sc[lane];
+        } else if (lane < 7) {
             const float g = sgrad[lane], lr = sc[8];
             float pnew;
             if (d.optimizer == 0) {
@@ -1209,13 +1215,17 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
                 E.st->last_active = tot;
                 E.st->last_pairs = E.L.counters[3];
                 E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
-                E.st->it_next = it + 1;
+                E.st->it_next = E.eval_grad ? it : it + 1;
             }
         }
     }
     UPH(4);
     __syncthreads();
     UPH(5);
+    if (E.eval_grad) {  // the next pass starts from pose_xfm_kernel with whatever the caller put into params
+        if (writer && tid == 0) E.L.bigcount[b] = 0;
+        return;
+    }
     // ---- transform this slice of the vertices with the NEW pose (next iteration's pose_xfm)
     float q[4], t[3], M[16], F[16];
 #pragma unroll
@@ -1351,6 +1361,8 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     DDX_REQUIRE(e, DDX_E_NULL, "engine_create: out of host memory");
     e->dev.d = *desc;
     e->dev.b = *bufs;
+    e->dev.eval_grad = nullptr;
+    e->dev.eval_loss = nullptr;
     {
         EngineDev& E = e->dev;
         const bool on[MAX_ROLES] = {desc->use_rgb || desc->use_depth, desc->use_mask != 0, desc->use_edge != 0};
@@ -1460,6 +1472,22 @@ extern "C" int ddx_engine_trace_dump(ddx_engine* e, const char* path)
     return 0;
 }
 #endif
+
+extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* loss_out, void* stream)
+{
+    DDX_REQUIRE(e && grad_out, DDX_E_NULL, "engine_eval: NULL pointer");
+    DDX_REQUIRE(it >= 0 && it < e->dev.d.max_iters, DDX_E_SHAPE, "engine_eval: iteration %d outside [0,%d)", it, e->dev.d.max_iters);
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->setup_done)
+        if (int err = engine_setup(e, s)) return err;
+    if (int err = run_prologue(e, it, s)) return err;
+    e->dev.eval_grad = grad_out;
+    e->dev.eval_loss = loss_out;
+    const int err = run_iteration(e, s, nullptr);
+    e->dev.eval_grad = nullptr;
+    e->dev.eval_loss = nullptr;
+    return err;
+}
 
 extern "C" const int32_t* ddx_engine_status_ptr(ddx_engine* e) { return e ? &e->dev.st->overflow : nullptr; }
 

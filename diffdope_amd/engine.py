@@ -14,6 +14,21 @@ from .render import build_topology
 KERNEL_NAMES_MAX = 16
 
 
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, eng):
+        if params.data_ptr() != eng.params.data_ptr():
+            eng.params.copy_(params.detach())
+        losses, grad = eng.loss_and_grad()
+        ctx.save_for_backward(grad)
+        return (losses * eng.lr_mult[None]).sum() / float(eng.desc.B_global)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
 class RefineEngine:
     """
     Args (torch tensors on one ROCm device, fp32 / int32):
@@ -95,6 +110,23 @@ class RefineEngine:
         n = self.max_iters - self.it if n is None else n
         _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
         self.it += n
+
+    def loss_and_grad(self):
+        """One evaluation pass at the CURRENT contents of `params`, no optimiser step: returns (losses [4,B] weighted,
+        un-LR'd per hypothesis (rgb, depth, mask, edge), grad [7,B] = d loss / d params with
+        loss = sum_k sum_b lr_mult[b] * losses[k,b] / global_batch).  For callers that bring their own optimiser."""
+        B = self.B
+        grad = torch.empty((7, B), dtype=torch.float32, device=self.params.device)
+        losses = torch.empty((4, B), dtype=torch.float32, device=self.params.device)
+        it = min(self.it, self.max_iters - 1)
+        _lib.check(self.lib.ddx_engine_eval(self.handle, it, grad.data_ptr(), losses.data_ptr(), _lib.stream_ptr()), "ddx_engine_eval")
+        return losses, grad
+
+    def loss(self, params=None):
+        """Scalar total loss with autograd through the fused engine: `params` [7,B] (default: the engine's own tensor)
+        gets its gradient from the analytic backward of the kernels, so any torch optimiser can drive the fused path:
+            opt = torch.optim.Adam([p], lr=1e-2);  loss = eng.loss(p);  loss.backward();  opt.step()"""
+        return _FusedLoss.apply(self.params if params is None else params, self)
 
     def rewind(self, it=0):
         self.it = it

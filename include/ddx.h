@@ -169,6 +169,12 @@ int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* buf
 /* Run iterations [it0, it0+n) (rows of lr_sched / loss_log / mtx_log).  use_graph != 0 replays a
  * captured hipGraph of one iteration. */
 int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
+/* Evaluation pass without an optimiser step (for callers that bring their own optimiser): renders the hypotheses
+ * at the CURRENT contents of `params`, writes d loss / d params to grad_out [7,B] and the weighted, un-LR'd
+ * per-hypothesis losses (rgb, depth, mask, edge) to loss_out [4,B] (may be NULL); parameters, optimiser state and logs
+ * are left untouched.  loss = sum_k sum_b lr_mult[b] * loss_out[k,b] / B_global  (diffdope.py:534-613);
+ * `it` only selects the mtx_log row the pose matrices are logged to. */
+int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* loss_out, void* stream);
 /* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
  * iteration, [2] active tiles of the last iteration, [3] next iteration index, [4] pixels with seg != 0 */
 const int32_t* ddx_engine_status_ptr(ddx_engine* e);

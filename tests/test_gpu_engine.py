@@ -269,3 +269,46 @@ def test_engine_full_size_one_hypothesis_against_oracle_and_batch_properties(row
     g1 = (params[:, 2] - p1.cpu().numpy()[:, 0]) / lr
     # (gradients are read back as parameter differences: resolution ulp(7.5) / lr = 2e-6, x16 for the batch of one)
     np.testing.assert_allclose(g1, g_gpu * 16, rtol=2e-4, atol=4e-5)
+
+
+@pytest.mark.parametrize("weights", [dict(rgb=0.7, depth=1.0, mask=1.0), dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8)])
+def test_engine_eval_pass_gradient_against_oracle_and_torch_optimizer(weights):
+    """ddx_engine_eval: loss and d loss / d params handed out directly (no optimiser step, nothing mutated) --
+    compared with the oracle without going through parameter differences -- and a torch optimiser driving the fused
+    path through RefineEngine.loss()."""
+    sc = make_scene(16, 20, 60, 80, B=3, dist=1.8)
+    R = sc["oracle"]
+    R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
+    total, logs, g_ref, _ = R.loss_and_grad(sc["params"], sc["lr_mult"])
+    eng, params = _engine(sc, weights, [0.1] * 30)
+    before = params.clone()
+    losses, grad = eng.loss_and_grad()
+    torch.cuda.synchronize()
+    assert torch.equal(params, before) and eng.it == 0
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-3, atol=1e-4 * np.abs(g_ref).max())
+    for i, key in enumerate(KEYS):
+        if key in logs:
+            np.testing.assert_allclose(losses[i].cpu().numpy(), logs[key], rtol=2e-5, atol=1e-7)
+    p = params.clone().requires_grad_(True)
+    val = eng.loss(p)
+    assert abs(float(val.detach()) - total) < 1e-5 * max(1.0, abs(total))
+    val.backward()
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g_ref, rtol=1e-3, atol=1e-4 * np.abs(g_ref).max())
+    # the evaluation pass leaves the engine usable: a normal run afterwards equals a run on a fresh engine
+    eng.run(3)
+    eng2, params2 = _engine(sc, weights, [0.1] * 30)
+    eng2.run(3)
+    torch.cuda.synchronize()
+    assert torch.equal(params, params2) and torch.equal(eng.losses(), eng2.losses())
+    # torch.optim on the fused path
+    p = torch.tensor(sc["params"], device="cuda", requires_grad=True)
+    eng3, _ = _engine(sc, weights, [0.1] * 30)
+    opt = torch.optim.Adam([p], lr=5e-3)
+    first = None
+    for _ in range(25):
+        opt.zero_grad()
+        val = eng3.loss(p)
+        val.backward()
+        opt.step()
+        first = float(val.detach()) if first is None else first
+    assert float(val.detach()) < 0.7 * first
