@@ -74,6 +74,55 @@ def test_rasterize_edge_cases():
     assert float((rast[..., 3] == 2).sum()) > 0 and float((rast[..., 3] == 1).sum()) == 0
 
 
+@pytest.mark.parametrize("seed,H,W,n_tri", [(0, 37, 53, 60), (1, 64, 64, 400), (2, 120, 160, 1500), (3, 97, 211, 300), (4, 480, 640, 2500),
+                                            (5, 16, 16, 40), (6, 1, 1, 10), (7, 720, 1280, 900)])
+def test_rasterize_random_triangle_soup_bit_identical(seed, H, W, n_tri):
+    """Seeded random soups: sizes from sub-pixel to frame-filling (log-uniform), random depths incl. exact ties,
+    some vertices behind the camera (w <= 0) or beyond the far plane, shared vertices, duplicates and degenerate
+    triangles, centres landing exactly on pixel-centre lattice points -- every size class of the rasteriser
+    (dead / mask path / tile pass) in one batch; ids bit-identical, u, v, z/w within 2e-6."""
+    import diffdope_amd as dd
+    from oracle import oracle as orc
+
+    rng = np.random.RandomState(100 + seed)
+    B = 2
+    nv = n_tri * 3
+    cx, cy = rng.uniform(-0.2 * W, 1.2 * W, n_tri), rng.uniform(-0.2 * H, 1.2 * H, n_tri)
+    size = np.exp(rng.uniform(np.log(0.3), np.log(1.5 * max(H, W)), n_tri))
+    ang = rng.uniform(0, 2 * np.pi, (n_tri, 3))
+    rad = size[:, None] * rng.uniform(0.2, 1.0, (n_tri, 3))
+    px = cx[:, None] + rad * np.cos(ang)
+    py = cy[:, None] + rad * np.sin(ang)
+    snap = rng.rand(n_tri) < 0.15  # vertices exactly on pixel centres / edges
+    px[snap] = np.round(px[snap] * 2) / 2
+    py[snap] = np.round(py[snap] * 2) / 2
+    z = np.round(rng.uniform(-0.9, 0.9, (n_tri, 1)) * 8) / 8 + rng.uniform(-0.05, 0.05, (n_tri, 3)) * (rng.rand(n_tri, 1) < 0.7)
+    w = np.exp(rng.uniform(np.log(0.5), np.log(4.0), (n_tri, 3)))
+    pos = np.zeros((B, nv, 4), np.float32)
+    for b in range(B):
+        sh = 0.37 * b
+        x_ndc = ((px + sh) / W * 2 - 1).reshape(-1)
+        y_ndc = ((py - sh) / H * 2 - 1).reshape(-1)
+        ww = w.reshape(-1).copy()
+        pos[b, :, 0], pos[b, :, 1], pos[b, :, 2], pos[b, :, 3] = x_ndc * ww, y_ndc * ww, z.reshape(-1) * ww, ww
+    bad = rng.rand(nv) < 0.02
+    pos[:, bad, 3] *= -1.0                       # behind the camera
+    far = rng.rand(nv) < 0.02
+    pos[:, far, 2] = 1.7 * pos[:, far, 3]        # beyond the far plane
+    tri = np.arange(nv, dtype=np.int32).reshape(n_tri, 3)
+    share = rng.rand(n_tri) < 0.3                # shared vertices / edges, duplicates, degenerate triangles
+    tri[share, 0] = tri[rng.randint(0, n_tri, share.sum()), 1]
+    dup = rng.rand(n_tri) < 0.05
+    tri[dup] = tri[rng.randint(0, n_tri, dup.sum())]
+    deg = rng.rand(n_tri) < 0.03
+    tri[deg, 2] = tri[deg, 1]
+    ref = orc.rasterize_fwd(pos, tri, H, W)
+    rast, _ = dd.rasterize(dd.RasterizeGLContext(), T(pos), T(tri), [H, W])
+    _check_rast(rast.cpu().numpy(), ref)
+    if H * W > 256:
+        assert (ref[..., 3] > 0).mean() > 0.05
+
+
 def test_rasterize_full_size_properties():
     """640x480, 64 hypotheses, 20480 triangles (BASELINE config 2): properties that need no oracle pass
     over the full batch -- hypotheses with identical poses give identical images, u,v in [0,1],
