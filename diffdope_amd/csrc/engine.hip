@@ -607,6 +607,8 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
     __shared__ float s_gm[WAVES_PER_TILE][64];          // d loss / d mask of each pixel
     __shared__ unsigned short s_pairs[WAVES_PER_TILE][ROLE == 1 ? PAIR_CAP : 4];
+    __shared__ float s_C[WAVES_PER_TILE][ROLE == 1 ? 12 : 1][ROLE == 1 ? 64 : 1];  // unit contributions of the first 64 pairs, parked
+                                                                               // in LDS between the forward and backward halves
     __shared__ float s_lum[WAVES_PER_TILE][ROLE == 2 ? QH * QH + 4 : 4];
     const ddx_engine_desc& d = E.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -793,9 +795,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
             if (c3) s_pairs[wave][n0 + n1 + n2 + __popcll(m3 & lt)] = (unsigned short)(lane | (3 << 6));
             wave_lds_sync();
             // forward: each lane owns pair `lane` (+64, ... in the rare quadrant with more than 64 pairs)
-            float C0[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) C0[i] = 0.f;
             int tl0 = -1;
             float cd0 = 0.f;
             for (int j0 = 0; j0 < np; j0 += 64) {
@@ -823,7 +822,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                     tl0 = (pr.valid && !pr.clamped) ? tl : -1;
                     cd0 = cd;
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) C0[i] = pr.C[i];
+                    for (int i = 0; i < 12; ++i) s_C[wave][i][lane] = pr.C[i];  // 12 VGPRs less across the pixel phase
                 }
             }
             wave_lds_sync();
@@ -844,7 +843,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                 float cd = cd0;
                 float C[12];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) C[i] = C0[i];
+                for (int i = 0; i < 12; ++i) C[i] = j0 == 0 ? s_C[wave][i][lane] : 0.f;
                 if (j0 > 0) {  // rare: re-evaluate the overflow pairs
                     const int j = j0 + lane;
                     tl = -1;
