@@ -597,8 +597,10 @@ __device__ __forceinline__ float lum_unit(const EngineDev& E, const float* __res
 #define DDX_PHASE(i)
 #endif
 
+// `pool`: per-wave LDS scratch owned by the kernel (one allocation shared by the roles, which are different
+// workgroups): 12 x 64 floats for the mask role, 24 x 64 for the edge role.
 template <int ROLE, int NR>
-__device__ __forceinline__ void shade_body(const EngineDev& E)
+__device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict__ pool)
 {
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -607,8 +609,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
     __shared__ float s_gm[WAVES_PER_TILE][64];          // d loss / d mask of each pixel
     __shared__ unsigned short s_pairs[WAVES_PER_TILE][ROLE == 1 ? PAIR_CAP : 4];
-    __shared__ float s_C[WAVES_PER_TILE][ROLE == 1 ? 12 : 1][ROLE == 1 ? 64 : 1];  // unit contributions of the first 64 pairs, parked
-                                                                               // in LDS between the forward and backward halves
     __shared__ float s_lum[WAVES_PER_TILE][ROLE == 2 ? QH * QH + 4 : 4];
     const ddx_engine_desc& d = E.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -822,7 +822,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                     tl0 = (pr.valid && !pr.clamped) ? tl : -1;
                     cd0 = cd;
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) s_C[wave][i][lane] = pr.C[i];  // 12 VGPRs less across the pixel phase
+                    for (int i = 0; i < 12; ++i) pool[i * 64 + lane] = pr.C[i];  // parked in LDS: 12 VGPRs less across the pixel phase
                 }
             }
             wave_lds_sync();
@@ -843,7 +843,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                 float cd = cd0;
                 float C[12];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) C[i] = j0 == 0 ? s_C[wave][i][lane] : 0.f;
+                for (int i = 0; i < 12; ++i) C[i] = j0 == 0 ? pool[i * 64 + lane] : 0.f;
                 if (j0 > 0) {  // rare: re-evaluate the overflow pairs
                     const int j = j0 + lane;
                     tl = -1;
@@ -873,18 +873,27 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
         }
         if (ROLE == 2) {
             // ---- A: luminance + unit gradient of the 100 halo pixels, two rounds of lanes (halo index e, 64 + e)
-            float U0[12], U1[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) { U0[i] = 0.f; U1[i] = 0.f; }
+            // the unit gradients are parked in LDS (pool rows 0..11: first round, 12..23: second) so that neither
+            // is live in registers during the other round and the Sobel stage
             float l0 = 0.f, l1 = 0.f;
             {
+                float U[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) U[i] = 0.f;
                 const int t = ids[lane] - 1;
-                if (t >= 0) l0 = lum_unit(E, P, t, qx - 1 + lane % QH, qy - 1 + lane / QH, U0);
+                if (t >= 0) l0 = lum_unit(E, P, t, qx - 1 + lane % QH, qy - 1 + lane / QH, U);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) pool[i * 64 + lane] = U[i];
             }
             const int e1 = 64 + lane;
             if (e1 < QH * QH) {
+                float U[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) U[i] = 0.f;
                 const int t = ids[e1] - 1;
-                if (t >= 0) l1 = lum_unit(E, P, t, qx - 1 + e1 % QH, qy - 1 + e1 / QH, U1);
+                if (t >= 0) l1 = lum_unit(E, P, t, qx - 1 + e1 % QH, qy - 1 + e1 / QH, U);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) pool[(12 + i) * 64 + lane] = U[i];
                 s_lum[wave][e1] = l1;
             }
             s_lum[wave][lane] = l0;
@@ -929,7 +938,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E)
                             }
                         }
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) A.dF[i] = __fmaf_rn(g, r == 0 ? U0[i] : U1[i], A.dF[i]);
+                    for (int i = 0; i < 12; ++i) A.dF[i] = __fmaf_rn(g, pool[(r * 12 + i) * 64 + lane], A.dF[i]);
                 }
             }
             wave_lds_sync();
@@ -977,9 +986,11 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
     DDX_TRACE_BEGIN();
     const int z = blockIdx.z;
     const int role = EDGE ? (z == 0 ? E.roles[0] : (z == 1 ? E.roles[1] : E.roles[2])) : (E.n_roles == 2 ? z : E.st_role);
-    if (role == 0) shade_body<0, EDGE ? 3 : 2>(E);
-    else if (role == 1) shade_body<1, EDGE ? 3 : 2>(E);
-    else if (EDGE) shade_body<2, 3>(E);
+    __shared__ float s_pool[WAVES_PER_TILE][(EDGE ? 24 : 12) * 64];
+    float* pool = s_pool[threadIdx.x >> 6];
+    if (role == 0) shade_body<0, EDGE ? 3 : 2>(E, pool);
+    else if (role == 1) shade_body<1, EDGE ? 3 : 2>(E, pool);
+    else if (EDGE) shade_body<2, 3>(E, pool);
     DDX_TRACE_END(E.trace, 2, ((unsigned long long)role << 32) |
                   (unsigned)max(0, (E.L.b_count[blockIdx.x] - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y));
 }
