@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
 // rasteriser.  Slice 0 also writes parameters, optimiser state and logs; the zbuf / tile-flag re-arm is split
 // over the slices.
 #define UPD_SLICES 8
+#define UPD_SPEC 24  // partial slots per thread requested before the tile count is known
 #define SEG_PRE 16  // seg-list entries per thread requested up front (covers 4096 masked pixels; the rest loops)
 
 template <int NR>
@@ -1023,18 +1024,16 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     DDX_TRACE_BEGIN();
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
     unsigned long long uph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef DDX_PHASES_NOWAIT  // stamp when the wave gets here (its own waits included), without draining loads/stores first
+#define UPH(i) do { asm volatile("" ::: "memory"); uph[i] = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
 #define UPH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); uph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #else
 #define UPH(i)
 #endif
     UPH(0);
-    // ---- parallel prefetch: params 0..6, lr_mult 7, lr 8, m23 9, proj 16..31, adam 32..45
     const int cur = it & 1;
-    if (tid < 7) sc[tid] = E.params2[((size_t)cur * 7 + tid) * B + b];
-    else if (tid == 7) sc[7] = E.b.lr_mult[b];
-    else if (tid == 8) sc[8] = E.b.lr_sched[it];
-    else if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
-    else if (tid >= 32 && tid < 46) sc[tid] = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
     const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < NVALS of group g sums value j
     float acc = 0.f;
     const int n_act = E.L.b_count[b];
@@ -1046,16 +1045,15 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     constexpr int PER = 4 * NR;  // partial slots per tile
     const int rmask = E.role_mask;
     const float* pbase = E.partials + (size_t)b * NT * PER * NPART + j;
-    float v0[8];
+    float v0[UPD_SPEC];  // slots grp, grp + 8, ...: the first UPD_SPEC x 8 slots (24 tiles with two roles) in ONE round trip
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UPD_SPEC; ++u) {
         const int s = grp + u * 8;
         const bool ok = j < NVALS && s < NT * PER && ((rmask >> (s % NR)) & 1);
         v0[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
     }
     const int txy_first = tid < NT ? tiles[tid] : 0;
     const int ns = d.use_depth ? E.st->n_seg : 0;
-    const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
     float2 sg[SEG_PRE];
 #pragma unroll
     for (int k = 0; k < SEG_PRE; ++k) {
@@ -1071,15 +1069,25 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
         px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
     }
+    // ---- the scalars of the tail, one per thread, into LDS: params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45.
+    // Requested AFTER the loads above (their addresses need the iteration index, itself a load: ahead of the others
+    // they delayed everything by two round trips), consumed after the partial sums.
+    float sc_val = 0.f;
+    if (tid < 7) sc_val = E.params2[((size_t)cur * 7 + tid) * B + b];
+    else if (tid == 7) sc_val = E.b.lr_mult[b];
+    else if (tid == 8) sc_val = E.b.lr_sched[it];
+    else if (tid >= 16 && tid < 32) sc_val = E.b.proj[tid - 16];
+    else if (tid >= 32 && tid < 46) sc_val = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
+    const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
     // ---- partial sums.  The quadrant partials are stored by position in the hypothesis' ordered active list, so the
     // slots (tile position, quadrant, role) of hypothesis b are ONE contiguous run: v0[] was requested before the
     // count was known; fixed order => bit-reproducible
     {
         const int nslot = n_act * PER;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (grp + u * 8 < nslot) ? v0[u] : 0.f;
+        for (int u = 0; u < UPD_SPEC; ++u) acc += (grp + u * 8 < nslot) ? v0[u] : 0.f;
         if (j < NVALS)
-            for (int s0 = grp + 64; s0 < nslot; s0 += 64) {
+            for (int s0 = grp + UPD_SPEC * 8; s0 < nslot; s0 += 64) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per slot)
@@ -1091,6 +1099,8 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
                 for (int u = 0; u < 8; ++u) acc += v[u];
             }
     }
+    if (tid < 46) sc[tid] = sc_val;
+    UPH(1);
     // ---- re-arm what the iteration dirtied (zbuf of the active tiles, their flags) so that the next iteration needs
     // no memset -- tile k is re-armed by slice k % UPD_SLICES.  Independent of the sums.
     for (int start = 0; start < n_act; start += 256) {
@@ -1113,7 +1123,6 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
             if (zx < d.W && zy < d.H) E.L.zbuf[((size_t)b * d.H + zy) * d.W + zx] = ~0ull;
         }
     }
-    UPH(1);
     acc += __shfl_xor(acc, 32, 64);  // groups 2w and 2w+1 live in wave w
     __syncthreads();
     if (lane < NPART) red[wave][lane] = acc;

@@ -12,7 +12,7 @@ lib = _lib.load(); lib.ddx_engine_trace_dump.argtypes = [ctypes.c_void_p, ctypes
 assert lib.ddx_engine_trace_dump(eng.handle, b'/tmp/trace.bin') == 0
 t = np.fromfile('/tmp/trace.bin', dtype=np.uint64).reshape(4, 8192 * 4)[1].reshape(4096, 8).astype(np.int64)
 t = t[(t[:, 0] > 0) & (t[:, 7] > 0)]
-names = ['prefetch+tiles+partials loop', 'lds sums', 'seg list term', 'tail (wave 0)', 'barrier', 'matrices', 'transform+stores']
+names = ['prefetch + partial sums', 're-arm loop + lds sums', 'seg list term', 'tail (wave 0)', 'barrier', 'matrices', 'transform+stores']
 print('workgroups:', len(t))
 for i, n in enumerate(names):
     d = (t[:, i + 1] - t[:, i]) * 10
