@@ -230,7 +230,9 @@ def test_engine_with_edge_extension_tracks_oracle_over_iterations():
 
 @pytest.mark.parametrize("rows,cols,H,W,weights", [(160, 160, 480, 640, dict(rgb=0.7, depth=1.0, edge=1.0)),   # BASELINE config 3
                                                    (80, 128, 720, 1280, dict(rgb=0.7, depth=1.0, edge=1.0)),   # config 5 (one object)
-                                                   (100, 150, 480, 640, dict(depth=1.0, mask=1.0))])           # config 4 mesh size
+                                                   (100, 150, 480, 640, dict(depth=1.0, mask=1.0)),            # config 4 mesh size
+                                                   (12, 16, 480, 640, dict(depth=1.0, mask=1.0)),              # low-poly: every triangle takes the tile pass
+                                                   (40, 64, 720, 1280, dict(rgb=0.7, mask=1.0))])              # 10-60 px triangles: both paths
 def test_engine_full_size_one_hypothesis_against_oracle_and_batch_properties(rows, cols, H, W, weights):
     """Full BASELINE sizes.  The oracle renders ONE hypothesis (seconds); the batch of 16 is checked through
     size-independent properties: hypotheses with identical parameters and multipliers give bit-identical losses and
