@@ -30,6 +30,8 @@ CONFIGS = {
     "cfg50k64": dict(rows=160, cols=160, B=64, H=480, W=640, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
     # low-polygon CAD-like mesh (T-LESS CAD models have large flat faces): every triangle takes the tile pass
     "lowpoly": dict(rows=12, cols=16, B=64, H=480, W=640, textured=False, weights=dict(depth=1.0, mask=1.0), tex=0),
+    # a handful of huge triangles close to the camera (a box-like CAD part): hundreds of large tiles per hypothesis
+    "hugetri": dict(rows=3, cols=4, B=64, H=480, W=640, textured=False, weights=dict(depth=1.0, mask=1.0), tex=0, distance=2.2),
     # in between: 5120 triangles at 1280x720, a mix of small (scatter) and large (tile pass) triangles
     "midpoly": dict(rows=40, cols=64, B=64, H=720, W=1280, textured=True, weights=dict(rgb=0.7, mask=1.0), tex=2048),
     "tiny": dict(rows=16, cols=20, B=4, H=60, W=80, textured=True, weights=dict(rgb=0.7, depth=1.0, mask=1.0), tex=64),
@@ -51,10 +53,11 @@ def lr_schedule(nb_iterations, base_lr, lr_decay):
     return [base_lr * lr_decay ** (it / nb_iterations + 1) for it in range(nb_iterations + 1)]
 
 
-def build(name, device, B=None, seed=0, global_lo=0, global_B=None, rot_deg=10.0, trans_frac=0.04, distance=7.5):
+def build(name, device, B=None, seed=0, global_lo=0, global_B=None, rot_deg=10.0, trans_frac=0.04, distance=None):
     """Returns a dict of device tensors describing the workload.  Hypothesis b of the GLOBAL batch gets
     initial pose / multiplier number (global_lo + b), so shards of one job are consistent."""
     cfg = dict(CONFIGS[name])
+    distance = cfg.get("distance", 7.5) if distance is None else distance
     B = cfg["B"] if B is None else B
     global_B = B if global_B is None else global_B
     H, W = cfg["H"], cfg["W"]
