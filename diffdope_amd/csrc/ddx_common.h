@@ -46,6 +46,31 @@ static inline int ddx_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 // ds_bpermute_b32, i.e. every step goes through the LDS crossbar: 19 sums x 6 steps per wave made the shading
 // kernel's epilogue LDS-throughput bound (9 us of a 25 us kernel, measured by ablation).  Fixed association
 // order => bit-reproducible.
+// One DPP step of the wave reduction applied to N independent values back to back: written value-by-value the compiler
+// emits each 4-step chain on its own with an s_nop between dependent DPP ops; step-by-step the next op of a chain is
+// N instructions away and needs none.
+#define DDX_DPP_STEP(v, ctrl) (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0xB1);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0x4E);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0x141);  // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0x140);  // row_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 48));
+        v[i] = (r0 + r1) + (r2 + r3);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

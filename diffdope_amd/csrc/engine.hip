@@ -957,11 +957,10 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 #pragma unroll
         for (int i = 0; i < NV; ++i) nz |= vals[i] != 0.f;
         if (__ballot(nz) != 0ull) {  // e.g. mask role on an interior quadrant: every term is exactly zero
+            wave_sum_n(vals);  // same association as wave_sum per value: bit-identical results
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const float s = wave_sum(vals[i]);
-                if (lane == i) mine = s;
-            }
+            for (int i = 0; i < NV; ++i)
+                if (lane == i) mine = vals[i];
         }
         if (lane < NPART) part[lane] = mine;
         DDX_PHASE(6);
