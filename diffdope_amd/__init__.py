@@ -32,3 +32,11 @@ from .api import (  # noqa: F401
     load_config,
     opencv_2_opengl,
 )
+from .viz import (  # noqa: F401  (the reference's module-level presentation helpers, diffdope.py:243-528)
+    find_crop,
+    getimg_stack,
+    im_resize,
+    make_grid_image,
+    make_grid_overlay_batch,
+)
+from .viz import make_grid_tensor as make_grid  # noqa: F401

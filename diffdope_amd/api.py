@@ -550,7 +550,7 @@ class DiffDope:
         """Overlay of the render of iteration `index` (default: last) on the observed image, as an upright uint8
         RGB numpy image: one hypothesis (`batch_index`) or, with batch_index=None, a grid of all of them.
         Honours cfg.render_images.{nrow, add_background, alpha_overlay, flip_result, crop_around_mask} when the
-        config has them (diffdope.py:1377-1486; contours are not drawn)."""
+        config has them, plus add_countour / color_countour (sic) for the silhouette contour (diffdope.py:1377-1486)."""
         from . import viz
 
         ri = self.cfg.get("render_images", {}) if isinstance(self.cfg, dict) else {}
@@ -572,6 +572,9 @@ class DiffDope:
                 fg = fg[r0:r0 + sz + 1, c0:c0 + sz + 1]
                 bg = None if bg is None else bg[r0:r0 + sz + 1, c0:c0 + sz + 1]
             im = viz.overlay(bg, fg, alpha=ri.get("alpha_overlay", 0.7), add_background=ri.get("add_background", True))
+            if ri.get("add_countour", False) and fg.ndim == 3:  # (sic: the reference's config key, configs/diffdope.yaml:40)
+                im = im.copy()
+                im[viz.contour(fg.sum(-1) > 0)] = np.asarray(ri.get("color_countour", [0.46, 0.73, 0]), np.float32)
             tiles.append(im[::-1] if ri.get("flip_result", True) else im)
         img = tiles[0] if len(tiles) == 1 else viz.make_grid(tiles, nrow=ri.get("nrow", 4))
         return viz.to_uint8(img)

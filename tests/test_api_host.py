@@ -148,7 +148,8 @@ def test_alias_package_exposes_reference_names():
 
     for name in ("xfm_points", "xfm_vectors", "DiffDope", "Object3D", "Mesh", "Scene", "Image", "Camera", "render_texture_batch",
                  "l1_rgb_with_mask", "l1_depth_with_mask", "l1_mask", "dist_batch_lr", "matrix_batch_44_from_position_quat",
-                 "opencv_2_opengl"):
+                 "opencv_2_opengl", "find_crop", "getimg_stack", "im_resize", "make_grid", "make_grid_image", "make_grid_overlay_batch",
+                 "interpolate"):
         assert hasattr(diffdope, name), name
     assert diffdope.__all__ == ["xfm_points", "xfm_vectors"]
 
@@ -218,3 +219,26 @@ def test_l1_edge_extension_matches_oracle_and_logs():
     assert np.isclose(float(loss.detach()), (per * lr).sum() / B * 0.8, rtol=1e-12)
     assert np.allclose(t_rgb.grad.numpy(), d, rtol=1e-10, atol=1e-15)
     assert "l1_edge" in dir(dd)
+
+
+def test_reference_named_viz_helpers():
+    import diffdope_amd as dd
+    from diffdope_amd import viz
+
+    fg = np.zeros((3, 20, 30, 3), np.float32)
+    fg[:, 5:15, 8:20] = 0.5
+    bg = np.full((3, 20, 30, 3), 0.2, np.float32)
+    grid = dd.make_grid_overlay_batch(torch.tensor(fg), torch.tensor(bg), alpha=0.5, row=2, final_width=200)
+    assert grid.dtype == np.uint8 and grid.shape[1] == 200 and grid.ndim == 3
+    assert (grid[..., 0] > 250).any() and (grid[..., 1] < 5).any()        # the red contour is there
+    c = viz.contour(fg[0].sum(-1) > 0)
+    assert c.sum() == 2 * (10 + 12) - 4 and c[5, 8] and not c[10, 12]       # boundary ring of a 10 x 12 box
+    img = dd.make_grid_image(torch.tensor(fg), 3, 120)
+    assert img.shape[1] == 120 and img.dtype == np.uint8
+    assert dd.im_resize(np.zeros((10, 20, 3), np.uint8), height=5).shape[:2] == (5, 10)
+    g = dd.make_grid(torch.rand(5, 3, 8, 6), nrow=4, padding=1)
+    assert tuple(g.shape) == (3, 2 * 9 + 1, 4 * 7 + 1)
+    st = dd.getimg_stack([torch.rand(4, 5, 3) for _ in range(4)], w=2, h=2)
+    assert st.shape == (8, 10, 3) and st.dtype == np.uint8
+    r0, c0, size = dd.find_crop(fg[0])
+    assert r0 <= 5 and c0 <= 8 and size >= 12
