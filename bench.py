@@ -117,10 +117,12 @@ def main():
 
     used = [i for i, k in enumerate(("rgb", "depth", "mask", "edge")) if w["weights"].get(k) is not None]
 
+    row_mask = sum(1 << i for i in used)
+
     def select_best(it):
-        # the one collective of the job: global arg-min hypothesis + its pose (diffdope.py:1488-1513,1618-1632)
-        per_hyp = eng.loss_log[it][used].mean(0)
-        return per_hyp, ddist.global_argmin(per_hyp, eng.mtx_log[it].reshape(Bl, 4, 4), lo=rank * Bl)
+        # the one collective of the job: global arg-min hypothesis + its pose (diffdope.py:1488-1513,1618-1632);
+        # local selection by one device kernel, one all_reduce of the [world,18] table, one host synchronisation
+        return ddist.global_argmin_fused(eng.loss_log[it], row_mask, eng.mtx_log[it], lo=rank * Bl)
 
     eng.run(args.warmup, use_graph=args.graph)
     if args.warmup > 0:
@@ -128,7 +130,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     eng.run(args.steps, use_graph=args.graph)
-    per_hyp, (gidx, gloss, gpose) = select_best(n_it - 1)
+    gidx, gloss, gpose = select_best(n_it - 1)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -140,6 +142,7 @@ def main():
     if rank == 0:
         rot, tr = wl.pose_errors(params, w["q_gt"], w["t_gt"])
         add = wl.add_error(params, w["pos"], w["q_gt"], w["t_gt"])
+        per_hyp = eng.loss_log[n_it - 1][used].mean(0)
         lbest = int(np.argmin(per_hyp.cpu().numpy()))
         V, T, HW = w["V"], w["T"], w["H"] * w["W"]
         alg = algorithmic_bytes(V, T, HW, Bl)

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "ddx_engine_create": (_I, [ctypes.POINTER(EngineDesc), ctypes.POINTER(EngineBuffers), ctypes.POINTER(_P)]),
     "ddx_engine_run": (_I, [_P, _I, _I, _I, _P]),
     "ddx_engine_eval": (_I, [_P, _I, _P, _P, _P]),
+    "ddx_select_best": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "ddx_engine_status_ptr": (_P, [_P]),
     "ddx_engine_profile": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I, _P]),
     "ddx_engine_destroy": (None, [_P]),

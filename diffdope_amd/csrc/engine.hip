@@ -1491,6 +1491,52 @@ extern "C" int ddx_engine_trace_dump(ddx_engine* e, const char* path)
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// get_argmin / get_pose (diffdope.py:1488-1513,1618-1632) for the local hypotheses, on the device: mean over the used
+// loss rows of iteration `it`, arg-min (ties -> lowest index), and the winner's row for the [world,18] exchange table:
+// (loss, global index, 4x4 pose).  One workgroup; replaces ~15 tiny framework launches and 3 host syncs.
+__global__ __launch_bounds__(256) void select_best_kernel(const float* __restrict__ loss_rows, int row_mask, int B,
+                                                          const float* __restrict__ mtx, int lo, float* __restrict__ out18)
+{
+    __shared__ float s_v[256];
+    __shared__ int s_i[256];
+    const int tid = threadIdx.x;
+    const int n_used = __popc(row_mask & 15);
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int b = tid; b < B; b += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((row_mask >> r) & 1) a += loss_rows[(size_t)r * B + b];
+        a = __fdiv_rn(a, (float)max(n_used, 1));
+        if (a < best || (a == best && b < bi)) { best = a; bi = b; }
+    }
+    s_v[tid] = best;
+    s_i[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v = s_v[tid + o];
+            const int i = s_i[tid + o];
+            if (v < s_v[tid] || (v == s_v[tid] && i < s_i[tid])) { s_v[tid] = v; s_i[tid] = i; }
+        }
+        __syncthreads();
+    }
+    const int w = s_i[0] < B ? s_i[0] : 0;  // (all-NaN losses: index 0, as torch.argmin would not help either)
+    if (tid == 0) { out18[0] = s_v[0]; out18[1] = (float)(w + lo); }
+    if (tid < 16) out18[2 + tid] = mtx[(size_t)w * 16 + tid];
+}
+
+extern "C" int ddx_select_best(const float* loss_rows, int row_mask, int B, const float* mtx, int lo, float* out18, void* stream)
+{
+    DDX_REQUIRE(loss_rows && mtx && out18, DDX_E_NULL, "select_best: NULL pointer");
+    DDX_REQUIRE(B >= 1 && (row_mask & 15) != 0, DDX_E_SHAPE, "select_best: B=%d row_mask=%d", B, row_mask);
+    select_best_kernel<<<1, 256, 0, (hipStream_t)stream>>>(loss_rows, row_mask, B, mtx, lo, out18);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* loss_out, void* stream)
 {
     DDX_REQUIRE(e && grad_out, DDX_E_NULL, "engine_eval: NULL pointer");

@@ -51,6 +51,31 @@ def global_argmin(per_hyp_loss, mtx, lo=0, group=None):
     return int(table[row, 1].item()), float(table[row, 0].item()), table[row, 2:].reshape(4, 4).to(mtx.dtype)
 
 
+def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
+    """global_argmin with the local selection done by one device kernel (ddx_select_best) and ONE host
+    synchronisation: loss_rows [4,B] (one iteration's row block of RefineEngine.loss_log), row_mask = bit r set when
+    loss row r takes part in the mean, mtx [B,16] or [B,4,4].  Same result as
+    global_argmin(loss_rows[used].mean(0), mtx, lo)."""
+    import torch.distributed as dist
+
+    from . import _lib
+
+    lib = _lib.load()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = loss_rows.shape[1]
+    table = torch.zeros((world, 18), dtype=torch.float32, device=loss_rows.device)
+    _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table[rank].data_ptr(),
+                                   _lib.stream_ptr()), "ddx_select_best")
+    if world > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    t = table.cpu()  # the one synchronisation
+    losses, gidx = t[:, 0], t[:, 1]
+    cand = torch.where(losses == losses.min(), gidx, torch.full_like(gidx, float("inf")))
+    row = int(torch.argmin(cand))
+    return int(t[row, 1]), float(t[row, 0]), t[row, 2:].reshape(4, 4).to(mtx.device)
+
+
 def merge_object_tables(table, group=None):
     """Multi-object jobs (bop.refine_frame): row i of `table` [n_obj, 18] is filled by the one rank that owns
     object i and zero elsewhere, so a single all_reduce(SUM) gives every rank the complete table."""

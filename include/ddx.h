@@ -175,6 +175,11 @@ int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
  * are left untouched.  loss = sum_k sum_b lr_mult[b] * loss_out[k,b] / B_global  (diffdope.py:534-613);
  * `it` only selects the mtx_log row the pose matrices are logged to. */
 int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* loss_out, void* stream);
+/* get_argmin / get_pose (diffdope.py:1488-1513,1618-1632) for the local hypotheses, on the device:
+ * loss_rows [4,B] (one row of loss_log), row_mask bit r = loss row r takes part in the mean, mtx [B,16],
+ * lo = global index of the first local hypothesis; out18 = (mean loss of the winner, its global index, its 4x4
+ * pose row-major): this rank's row of the [world,18] table that ONE all_reduce(SUM) exchanges. */
+int ddx_select_best(const float* loss_rows, int row_mask, int B, const float* mtx, int lo, float* out18, void* stream);
 /* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
  * iteration, [2] active tiles of the last iteration, [3] next iteration index, [4] pixels with seg != 0 */
 const int32_t* ddx_engine_status_ptr(ddx_engine* e);

@@ -314,3 +314,21 @@ def test_engine_eval_pass_gradient_against_oracle_and_torch_optimizer(weights):
         opt.step()
         first = float(val.detach()) if first is None else first
     assert float(val.detach()) < 0.7 * first
+
+
+def test_device_side_selection_matches_torch_argmin():
+    """ddx_select_best / dist.global_argmin_fused == dist.global_argmin(loss_rows[used].mean(0), ...), ties -> lowest index."""
+    from diffdope_amd import dist as ddist
+
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for B, mask in ((1, 0b0001), (7, 0b0101), (64, 0b0101), (300, 0b1111), (513, 0b0010)):
+        rows = torch.rand(4, B, generator=g).cuda()
+        if B > 4:
+            rows[:, B - 2] = rows[:, 1] = rows.min(1).values - 0.25   # an exact tie between two hypotheses: index 1 must win
+        mtx = torch.rand(B, 16, generator=g).cuda()
+        used = [r for r in range(4) if (mask >> r) & 1]
+        ref = ddist.global_argmin(rows[used].mean(0), mtx.reshape(B, 4, 4), lo=10)
+        got = ddist.global_argmin_fused(rows, mask, mtx, lo=10)
+        assert got[0] == ref[0], (B, mask, got[0], ref[0])
+        assert abs(got[1] - ref[1]) <= 1e-6 * max(1.0, abs(ref[1]))
+        assert torch.equal(got[2].cpu(), ref[2].cpu())
