@@ -640,29 +640,43 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
         // stored by POSITION k in the hypothesis' ordered active list: update_xfm_kernel reads one contiguous run
         float* part = E.partials + ((((size_t)b * L.NT + k) * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
-        // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
-        bool anycov = false;
-#pragma unroll
-        for (int e = lane; e < QH * QH; e += 64) {
-            const int gx = qx - 1 + e % QH, gy = qy - 1 + e / QH;
-            int v = -1;
-            if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
-                const unsigned long long key = zb[(size_t)gy * W + gx];
-                v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
-            }
-            ids[e] = v;
-            anycov |= v > 0;
-        }
-        s_m[wave][lane] = 0.f;
-        if (__ballot(anycov) == 0ull) {  // nothing drawn in or next to this quadrant: only background terms
-            if (lane < NPART) part[lane] = 0.f;
-            continue;
-        }
-        wave_lds_sync();
         const int lx = lane % QUAD, ly = lane / QUAD;
         const int px = qx + lx, py = qy + ly;
         const int hidx = (ly + 1) * QH + lx + 1;
-        const int id = ids[hidx];
+        int id;
+        if (ROLE == 0) {
+            // the colour / depth role only needs its own pixel: one zbuf entry per lane, no LDS staging
+            id = -1;
+            if (px < W && py < H) {
+                const unsigned long long key = zb[(size_t)py * W + px];
+                id = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
+            }
+            if (__ballot(id > 0) == 0ull) {  // nothing drawn in this quadrant: only background terms
+                if (lane < NPART) part[lane] = 0.f;
+                continue;
+            }
+        } else {
+            // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
+            bool anycov = false;
+#pragma unroll
+            for (int e = lane; e < QH * QH; e += 64) {
+                const int gx = qx - 1 + e % QH, gy = qy - 1 + e / QH;
+                int v = -1;
+                if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
+                    const unsigned long long key = zb[(size_t)gy * W + gx];
+                    v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
+                }
+                ids[e] = v;
+                anycov |= v > 0;
+            }
+            s_m[wave][lane] = 0.f;
+            if (__ballot(anycov) == 0ull) {  // nothing drawn in or next to this quadrant: only background terms
+                if (lane < NPART) part[lane] = 0.f;
+                continue;
+            }
+            wave_lds_sync();
+            id = ids[hidx];
+        }
         DDX_PHASE(1);
         PixAcc A;
 #pragma unroll
