@@ -64,6 +64,8 @@ struct EngineDev {
     float* params2;   // [2][7,B]: the parameters, by iteration parity (b.params is the user-visible copy)
     float* partials;  // [B*NT*4*NR, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*NR + role, NR = 2 (3 with the edge role)
     float2* gtedge;   // [H*W] Sobel gradients of lum(gt_rgb * seg) (edge extension), or null
+    float* lumbuf;    // [B,H*W] luminance of the rendered colour at covered pixels (written by the colour role, read by
+    float* ubuf;      // [B,H*W,12] edge_kernel; garbage where zbuf says "background") and U = d lum / d final per pixel
     float* adam;      // [2][2,7,B]: first and second moments, by iteration parity
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
@@ -112,6 +114,8 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
     const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * MAX_ROLES * NPART * sizeof(float));  // per 8x8 quadrant and shade role
     const size_t o_edge = carve(d.use_edge ? (size_t)d.H * d.W * sizeof(float2) : 0);
+    const size_t o_lum = carve(d.use_edge ? (size_t)d.B * d.H * d.W * sizeof(float) : 0);
+    const size_t o_ubuf = carve(d.use_edge ? (size_t)d.B * d.H * d.W * 12 * sizeof(float) : 0);
     const size_t o_rast = carve(0);
     const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W);
     off += rast_bytes;
@@ -124,6 +128,8 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.trirec = (int4*)(p + o_rec);
     E.partials = (float*)(p + o_part);
     E.gtedge = d.use_edge ? (float2*)(p + o_edge) : nullptr;
+    E.lumbuf = d.use_edge ? (float*)(p + o_lum) : nullptr;
+    E.ubuf = d.use_edge ? (float*)(p + o_ubuf) : nullptr;
     return off;
 }
 
@@ -362,6 +368,9 @@ __device__ __forceinline__ void acc_vertex_regs(PixAcc& A, float x, float y, flo
 #ifndef SHADE_GRID
 #define SHADE_GRID 1024  // shade workgroups per role (slices x hypotheses): measured flat 512..1536, worse above
 #endif
+#ifndef EDGE_GRID
+#define EDGE_GRID 1792  // edge_kernel workgroups (hypotheses x slices)
+#endif
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4  // waves per SIMD the shade kernel is compiled for (128 VGPRs)
 #endif
@@ -508,83 +517,12 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     }
 }
 
-// Edge role: luminance of the rendered colour at pixel (px,py), covered by triangle t, and U = d lum / d final (rows
-// x,y,w), i.e. the whole chain lum -> colour -> (texture ->) uv -> barycentrics -> clip vertices -> final, per unit
-// d loss / d lum.  The backward of the edge term is linear in d loss / d lum, so the pixel keeps 12 numbers and
-// the pass after the Sobel stage is 12 FMAs with no memory access (same trick as AAUnit).
-__device__ __forceinline__ float lum_unit(const EngineDev& E, const float* __restrict__ P, int t, int px, int py, float U[12])
-{
-    const ddx_engine_desc& d = E.d;
-    const float* __restrict__ pos = E.b.pos;
-    const int* __restrict__ tri = E.b.tri;
-    const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
-    const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
-    float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f;
-    if (d.Th > 0) {  // requested with the clip vertices, not after them
-        const float* uv = E.b.uv;
-        a0x = uv[(size_t)v0 * 2]; a0y = uv[(size_t)v0 * 2 + 1];
-        a1x = uv[(size_t)v1 * 2]; a1y = uv[(size_t)v1 * 2 + 1];
-        a2x = uv[(size_t)v2 * 2]; a2y = uv[(size_t)v2 * 2 + 1];
-    }
-    Bary bc;
-    pixel_bary(p0, p1, p2, px, py, d.H, d.W, bc);
-    const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
-    const float third = 1.0f / 3.0f;
-    float gu = 0.f, gv = 0.f, col[3];
-    if (d.Th > 0) {
-        const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x));
-        const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
-        TexelSetup ts;
-        tex_setup(tu, tv, d.Th, d.Tw, ts);
-        const float* TX = E.b.tex;
-        const float *t00 = TX + ((size_t)ts.y0 * d.Tw + ts.x0) * 3, *t10 = TX + ((size_t)ts.y0 * d.Tw + ts.x1) * 3,
-                    *t01 = TX + ((size_t)ts.y1 * d.Tw + ts.x0) * 3, *t11 = TX + ((size_t)ts.y1 * d.Tw + ts.x1) * 3;
-        float gU = 0.f, gV = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
-            const float a = __fmaf_rn(ts.fx, c10 - c00, c00);
-            const float bq = __fmaf_rn(ts.fx, c11 - c01, c01);
-            col[c] = __fmaf_rn(ts.fy, bq - a, a);
-            gU = __fmaf_rn(third, __fmaf_rn(ts.fy, (c11 - c01) - (c10 - c00), c10 - c00), gU);
-            gV = __fmaf_rn(third, __fmaf_rn(ts.fx, (c11 - c10) - (c01 - c00), c01 - c00), gV);
-        }
-        gU *= (float)d.Tw;
-        gV *= (float)d.Th;
-        gu = gU * (a0x - a2x) + gV * (a0y - a2y);
-        gv = gU * (a1x - a2x) + gV * (a1y - a2y);
-    } else {
-        const float* vc = E.b.vtx_color;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float c0 = vc[(size_t)v0 * 3 + c], c1 = vc[(size_t)v1 * 3 + c], c2 = vc[(size_t)v2 * 3 + c];
-            col[c] = __fmaf_rn(w2, c2, __fmaf_rn(v, c1, u * c0));
-            gu = __fmaf_rn(third, c0 - c2, gu);
-            gv = __fmaf_rn(third, c1 - c2, gv);
-        }
-    }
-    if (gu != 0.f || gv != 0.f) {
-        float gx[3], gy[3], gw[3];
-        bary_backward(bc, gu, gv, gx, gy, gw);
-        PixAcc T;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) T.dF[i] = 0.f;
-        acc_vertex(T, pos, v0, gx[0], gy[0], gw[0]);
-        acc_vertex(T, pos, v1, gx[1], gy[1], gw[1]);
-        acc_vertex(T, pos, v2, gx[2], gy[2], gw[2]);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) U[i] = T.dF[i];
-    }
-    return lum3(col[0], col[1], col[2]);
-}
-
 // ROLE 0: colour + depth terms (per covered pixel).  ROLE 1: antialiased-coverage (mask) term (silhouette
 // pairs).  The two roles only share the zbuf they read, so they are separate workgroups of ONE launch
 // (blockIdx.z picks the role): they overlap on the chip, and each body keeps its own, smaller register
 // footprint instead of the union of both.  Each role writes its own partial per quadrant.
-// ROLE 2: edge term (extension): the wave owns the Sobel loss terms of its 8x8 quadrant, shades the luminance of
-// the 10x10 halo those terms read, and backpropagates into all 100 halo pixels (the neighbouring quadrants add
-// their own terms' share for the same pixels -- the chain is linear).
+// The edge term (extension) is a separate, texture-free kernel (edge_kernel below): in the edge build the colour role
+// also writes the luminance and U = d lum / d final of every covered pixel.
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
 #define DDX_PHASE(i)                                                           \
     do {                                                                       \
@@ -609,7 +547,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
     __shared__ float s_gm[WAVES_PER_TILE][64];          // d loss / d mask of each pixel
     __shared__ unsigned short s_pairs[WAVES_PER_TILE][ROLE == 1 ? PAIR_CAP : 4];
-    __shared__ float s_lum[WAVES_PER_TILE][ROLE == 2 ? QH * QH + 4 : 4];
     const ddx_engine_desc& d = E.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W, V = d.V;
@@ -702,7 +639,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             // ... and the texture coordinates: behind `if (use_rgb && textured)` below they would only be requested
             // after the clip vertices have arrived (the compiler does not speculate loads across the branch)
             float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f;
-            if (d.use_rgb && d.Th > 0) {
+            if ((d.use_rgb || NR == 3) && d.Th > 0) {
                 const float* uv = E.b.uv;
                 a0x = uv[(size_t)v0 * 2]; a0y = uv[(size_t)v0 * 2 + 1];
                 a1x = uv[(size_t)v1 * 2]; a1y = uv[(size_t)v1 * 2 + 1];
@@ -713,10 +650,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             pixel_bary(p0, p1, p2, px, py, H, W, bc);
             const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
             float gu = 0.f, gv = 0.f;
-            if (d.use_rgb) {
-                const float k = d.w_rgb * lrb * inv_b / (3.0f * (float)H * (float)W);
-                const float g0 = E.b.gt_rgb[pix * 3 + 0], g1 = E.b.gt_rgb[pix * 3 + 1], g2 = E.b.gt_rgb[pix * 3 + 2];
-                const float gt[3] = {g0, g1, g2}, sg[3] = {s0, s1, s2};
+            // colour of the pixel and its derivatives w.r.t. the barycentrics (u, v), per channel; used by the rgb term
+            // and -- in the edge build -- written out as luminance + unit gradient for edge_kernel
+            constexpr bool WLUM = NR == 3;  // edge build: this role also feeds the edge term
+            if (d.use_rgb || WLUM) {
+                float col[3], dcu[3], dcv[3];
                 if (d.Th > 0) {
                     const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x));
                     const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
@@ -725,36 +663,61 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     const float* TX = E.b.tex;
                     const float *t00 = TX + ((size_t)ts.y0 * d.Tw + ts.x0) * 3, *t10 = TX + ((size_t)ts.y0 * d.Tw + ts.x1) * 3,
                                 *t01 = TX + ((size_t)ts.y1 * d.Tw + ts.x0) * 3, *t11 = TX + ((size_t)ts.y1 * d.Tw + ts.x1) * 3;
-                    float gU = 0.f, gV = 0.f;
+                    const float ux = (a0x - a2x) * (float)d.Tw, uy = (a0y - a2y) * (float)d.Th;  // d(texel x, y) / du
+                    const float vx = (a1x - a2x) * (float)d.Tw, vy = (a1y - a2y) * (float)d.Th;  // d(texel x, y) / dv
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
                         const float a = __fmaf_rn(ts.fx, c10 - c00, c00);
                         const float bq = __fmaf_rn(ts.fx, c11 - c01, c01);
-                        const float col = __fmaf_rn(ts.fy, bq - a, a);
-                        const float diff = (col - gt[c]) * sg[c];
-                        A.L[0] += fabsf(diff) - fabsf(gt[c] * sg[c]);
-                        const float g = k * sgnf(diff) * sg[c];
-                        gU = __fmaf_rn(g, __fmaf_rn(ts.fy, (c11 - c01) - (c10 - c00), c10 - c00), gU);
-                        gV = __fmaf_rn(g, __fmaf_rn(ts.fx, (c11 - c10) - (c01 - c00), c01 - c00), gV);
+                        col[c] = __fmaf_rn(ts.fy, bq - a, a);
+                        const float dX = __fmaf_rn(ts.fy, (c11 - c01) - (c10 - c00), c10 - c00);  // d col / d texel x
+                        const float dY = __fmaf_rn(ts.fx, (c11 - c10) - (c01 - c00), c01 - c00);  // d col / d texel y
+                        dcu[c] = dX * ux + dY * uy;
+                        dcv[c] = dX * vx + dY * vy;
                     }
-                    gU *= (float)d.Tw;
-                    gV *= (float)d.Th;
-                    gu += gU * (a0x - a2x) + gV * (a0y - a2y);
-                    gv += gU * (a1x - a2x) + gV * (a1y - a2y);
                     DDX_PHASE(4);
                 } else {
                     const float* vc = E.b.vtx_color;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float c0 = vc[(size_t)v0 * 3 + c], c1 = vc[(size_t)v1 * 3 + c], c2 = vc[(size_t)v2 * 3 + c];
-                        const float col = __fmaf_rn(w2, c2, __fmaf_rn(v, c1, u * c0));
-                        const float diff = (col - gt[c]) * sg[c];
+                        col[c] = __fmaf_rn(w2, c2, __fmaf_rn(v, c1, u * c0));
+                        dcu[c] = c0 - c2;
+                        dcv[c] = c1 - c2;
+                    }
+                }
+                if (d.use_rgb) {
+                    const float k = d.w_rgb * lrb * inv_b / (3.0f * (float)H * (float)W);
+                    const float gt[3] = {E.b.gt_rgb[pix * 3 + 0], E.b.gt_rgb[pix * 3 + 1], E.b.gt_rgb[pix * 3 + 2]}, sg[3] = {s0, s1, s2};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float diff = (col[c] - gt[c]) * sg[c];
                         A.L[0] += fabsf(diff) - fabsf(gt[c] * sg[c]);
                         const float g = k * sgnf(diff) * sg[c];
-                        gu = __fmaf_rn(g, c0 - c2, gu);
-                        gv = __fmaf_rn(g, c1 - c2, gv);
+                        gu = __fmaf_rn(g, dcu[c], gu);
+                        gv = __fmaf_rn(g, dcv[c], gv);
                     }
+                }
+                if (WLUM && E.lumbuf) {
+                    // luminance and U = d lum / d final (rows x, y, w) per unit d loss / d lum: the backward of the edge
+                    // term is linear in d loss / d lum, so edge_kernel only multiplies
+                    const float third = 1.0f / 3.0f;
+                    const float gu2 = third * ((dcu[0] + dcu[1]) + dcu[2]), gv2 = third * ((dcv[0] + dcv[1]) + dcv[2]);
+                    float gx[3], gy[3], gw[3];
+                    bary_backward(bc, gu2, gv2, gx, gy, gw);
+                    PixAcc T;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) T.dF[i] = 0.f;
+                    acc_vertex_regs(T, x0, y0, z0, gx[0], gy[0], gw[0]);
+                    acc_vertex_regs(T, x1, y1, z1, gx[1], gy[1], gw[1]);
+                    acc_vertex_regs(T, x2, y2, z2, gx[2], gy[2], gw[2]);
+                    const size_t gp = (size_t)b * H * W + pix;
+                    E.lumbuf[gp] = lum3(col[0], col[1], col[2]);
+                    float4* ub = reinterpret_cast<float4*>(E.ubuf + gp * 12);
+                    ub[0] = make_float4(T.dF[0], T.dF[1], T.dF[2], T.dF[3]);
+                    ub[1] = make_float4(T.dF[4], T.dF[5], T.dF[6], T.dF[7]);
+                    ub[2] = make_float4(T.dF[8], T.dF[9], T.dF[10], T.dF[11]);
                 }
             }
             if (d.use_depth) {
@@ -885,81 +848,8 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             }
             wave_lds_sync();
         }
-        if (ROLE == 2) {
-            // ---- A: luminance + unit gradient of the 100 halo pixels, two rounds of lanes (halo index e, 64 + e)
-            // the unit gradients are parked in LDS (pool rows 0..11: first round, 12..23: second) so that neither
-            // is live in registers during the other round and the Sobel stage
-            float l0 = 0.f, l1 = 0.f;
-            {
-                float U[12];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) U[i] = 0.f;
-                const int t = ids[lane] - 1;
-                if (t >= 0) l0 = lum_unit(E, P, t, qx - 1 + lane % QH, qy - 1 + lane / QH, U);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) pool[i * 64 + lane] = U[i];
-            }
-            const int e1 = 64 + lane;
-            if (e1 < QH * QH) {
-                float U[12];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) U[i] = 0.f;
-                const int t = ids[e1] - 1;
-                if (t >= 0) l1 = lum_unit(E, P, t, qx - 1 + e1 % QH, qy - 1 + e1 / QH, U);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) pool[(12 + i) * 64 + lane] = U[i];
-                s_lum[wave][e1] = l1;
-            }
-            s_lum[wave][lane] = l0;
-            wave_lds_sync();
-            // ---- B: the quadrant's Sobel terms (zero padding = the halo's zeros outside the image)
-            float cx = 0.f, cy = 0.f;
-            if (id >= 0) {
-                const float* Lm = s_lum[wave];
-                float v[3][3];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) v[dy][dx] = Lm[hidx + (dy - 1) * QH + (dx - 1)];
-                float gx, gy;
-                sobel3(v, gx, gy);
-                const float2 g = E.gtedge[pix];
-                const float ex = gx - g.x, ey = gy - g.y;
-                A.L[3] += (fabsf(ex) + fabsf(ey)) - (fabsf(g.x) + fabsf(g.y));
-                const float k = d.w_edge * lrb * inv_b / (2.0f * (float)H * (float)W) * 0.125f;
-                cx = k * sgnf(ex);
-                cy = k * sgnf(ey);
-            }
-            s_m[wave][lane] = cx;
-            s_gm[wave][lane] = cy;
-            wave_lds_sync();
-            // ---- C: d loss / d lum of every halo pixel from the quadrant's terms, times the unit gradient
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int e = r * 64 + lane;
-                if (e < QH * QH) {
-                    const int ex = e % QH - 1, ey = e / QH - 1;
-                    float g = 0.f;
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int nx = ex - dx, ny = ey - dy;  // loss pixel whose (dy,dx) neighbour is e
-                            if (nx >= 0 && nx < QUAD && ny >= 0 && ny < QUAD) {
-                                const int n = ny * QUAD + nx;
-                                g = __fmaf_rn(s_m[wave][n], (float)(dx * (2 - (dy < 0 ? -dy : dy))), g);
-                                g = __fmaf_rn(s_gm[wave][n], (float)(dy * (2 - (dx < 0 ? -dx : dx))), g);
-                            }
-                        }
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) A.dF[i] = __fmaf_rn(g, pool[(r * 12 + i) * 64 + lane], A.dF[i]);
-                }
-            }
-            wave_lds_sync();
-            s_m[wave][lane] = 0.f;
-        }
         // ---- wave reduction -> one partial per quadrant (fixed order: bit-reproducible)
-        constexpr int NV = NR == 3 ? NVALS : NVALS - 1;  // the edge loss slot only exists in the edge build
+        constexpr int NV = NVALS - 1;  // (the 20th value, the edge loss, belongs to edge_kernel)
         float vals[NVALS];
 #pragma unroll
         for (int i = 0; i < 12; ++i) vals[i] = A.dF[i];
@@ -999,13 +889,151 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
     DDX_TRACE_BEGIN();
     const int z = blockIdx.z;
     const int role = EDGE ? (z == 0 ? E.roles[0] : (z == 1 ? E.roles[1] : E.roles[2])) : (E.n_roles == 2 ? z : E.st_role);
-    __shared__ float s_pool[WAVES_PER_TILE][(EDGE ? 24 : 12) * 64];
+    __shared__ float s_pool[WAVES_PER_TILE][12 * 64];
     float* pool = s_pool[threadIdx.x >> 6];
     if (role == 0) shade_body<0, EDGE ? 3 : 2>(E, pool);
-    else if (role == 1) shade_body<1, EDGE ? 3 : 2>(E, pool);
-    else if (EDGE) shade_body<2, 3>(E, pool);
+    else shade_body<1, EDGE ? 3 : 2>(E, pool);
     DDX_TRACE_END(E.trace, 2, ((unsigned long long)role << 32) |
                   (unsigned)max(0, (E.L.b_count[blockIdx.x] - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Edge term (extension, no reference counterpart; definition: oracle/ddx_oracle.c orc_loss_edge), after shade_kernel.
+// Owner computes: the wave of an 8x8 quadrant owns the loss terms AND the gradient of its 64 pixels.  d loss / d lum of
+// pixel p needs the Sobel coefficients of the 3x3 loss terms around p, which need the luminance of THEIR 3x3: a 12x12
+// luminance halo (from lumbuf where zbuf says covered, 0 elsewhere), a 10x10 block of loss terms, 64 owned pixels.
+// Everything comes from buffers the colour role wrote (lum, U = d lum / d final): one level of independent loads, no
+// texture fetch, no barycentrics -- the old edge role re-shaded the 100 halo pixels of every quadrant in two rounds.
+#define EH (QUAD + 4)  // 12: luminance halo
+#define ET (QUAD + 2)  // 10: loss terms
+__global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
+{
+    __shared__ float s_l[WAVES_PER_TILE][EH * EH];
+    __shared__ float s_cx[WAVES_PER_TILE][ET * ET + 4], s_cy[WAVES_PER_TILE][ET * ET + 4];
+    const ddx_engine_desc& d = E.d;
+    const RasterScratch& L = E.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = d.H, W = d.W;
+    const int b = blockIdx.x;
+    const int n_tiles = L.b_count[b];
+    const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
+    const float* __restrict__ lumb = E.lumbuf + (size_t)b * H * W;
+    const float lrb = E.b.lr_mult[b];
+    const float kc = d.w_edge * lrb * __fdiv_rn(1.0f, (float)d.B_global) / (2.0f * (float)H * (float)W) * 0.125f;
+    for (int k = blockIdx.y; k < n_tiles; k += gridDim.y) {
+        const int txy = L.active[(size_t)b * L.NT + k];
+        const int qx = (txy & 0xffff) * DDX_TILE + (wave & 1) * QUAD, qy = (txy >> 16) * DDX_TILE + (wave >> 1) * QUAD;
+        float* part = E.partials + ((((size_t)b * L.NT + k) * WAVES_PER_TILE + wave) * 3 + 2) * NPART;
+        // ---- everything this quadrant needs is requested up front: the 12x12 (zbuf, lum) halo in 3 rounds of lanes, the
+        // observed-image gradients of the 10x10 loss terms in 2, U of the owned pixel
+        const int lx = lane % QUAD, ly = lane / QUAD;
+        const int px = qx + lx, py = qy + ly;
+        const bool inimg = px < W && py < H;
+        const size_t pix = (size_t)py * W + px;
+        bool cov[3];
+        float lm[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = r * 64 + lane;
+            const int gx = qx - 2 + e % EH, gy = qy - 2 + e / EH;
+            cov[r] = false; lm[r] = 0.f;
+            if (e < EH * EH && gx >= 0 && gy >= 0 && gx < W && gy < H) {
+                const size_t g = (size_t)gy * W + gx;
+                cov[r] = zb[g] != ~0ull;
+                lm[r] = lumb[g];  // garbage where nothing is drawn: masked below
+            }
+        }
+        float2 ge[2];
+        bool term[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = r * 64 + lane;
+            const int gx = qx - 1 + e % ET, gy = qy - 1 + e / ET;
+            term[r] = e < ET * ET && gx >= 0 && gy >= 0 && gx < W && gy < H;
+            ge[r] = term[r] ? E.gtedge[(size_t)gy * W + gx] : make_float2(0.f, 0.f);
+        }
+        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, u2 = u0;
+        const bool own_cov = inimg && zb[pix] != ~0ull;
+        if (inimg) {  // (read unconditionally inside the image: masked by own_cov below -- keeps the loads independent of zbuf)
+            const float4* ub = reinterpret_cast<const float4*>(E.ubuf + ((size_t)b * H * W + pix) * 12);
+            u0 = ub[0]; u1 = ub[1]; u2 = ub[2];
+        }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = r * 64 + lane;
+            if (e < EH * EH) s_l[wave][e] = cov[r] ? lm[r] : 0.f;
+            any |= cov[r];
+        }
+        if (__ballot(any) == 0ull) {  // nothing drawn in or around this quadrant: only background terms
+            if (lane < NPART) part[lane] = 0.f;
+            continue;
+        }
+        wave_lds_sync();
+        // ---- the 10x10 loss terms: Sobel of the rendered luminance against the observed image's gradients
+        float own_loss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = r * 64 + lane;
+            float cx = 0.f, cy = 0.f;
+            if (term[r]) {
+                const int tx = e % ET, ty = e / ET;           // term coordinates in the 10x10 block
+                const float* c = &s_l[wave][(ty + 1) * EH + (tx + 1)];  // its centre in the 12x12 halo
+                float v[3][3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) v[dy][dx] = c[(dy - 1) * EH + (dx - 1)];
+                float gx, gy;
+                sobel3(v, gx, gy);
+                const float ex = gx - ge[r].x, ey = gy - ge[r].y;
+                cx = kc * sgnf(ex);
+                cy = kc * sgnf(ey);
+                // the loss itself is counted by the owner of the pixel only (terms of the outer ring belong to neighbours)
+                if (tx >= 1 && tx <= QUAD && ty >= 1 && ty <= QUAD) own_loss += (fabsf(ex) + fabsf(ey)) - (fabsf(ge[r].x) + fabsf(ge[r].y));
+            }
+            if (e < ET * ET) { s_cx[wave][e] = cx; s_cy[wave][e] = cy; }
+        }
+        wave_lds_sync();
+        // ---- owned pixel: d loss / d lum from the 3x3 terms around it, times U
+        float vals[NVALS];
+#pragma unroll
+        for (int i = 0; i < NVALS; ++i) vals[i] = 0.f;
+        if (own_cov) {
+            float g = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    // term n = p - (dy, dx): p is its (dy, dx) neighbour, coefficient kx[dy][dx] = dx (2 - |dy|), ky = dy (2 - |dx|)
+                    const int n = (ly + 1 - dy) * ET + (lx + 1 - dx);
+                    g = __fmaf_rn(s_cx[wave][n], (float)(dx * (2 - (dy < 0 ? -dy : dy))), g);
+                    g = __fmaf_rn(s_cy[wave][n], (float)(dy * (2 - (dx < 0 ? -dx : dx))), g);
+                }
+            vals[0] = g * u0.x; vals[1] = g * u0.y; vals[2] = g * u0.z; vals[3] = g * u0.w;
+            vals[4] = g * u1.x; vals[5] = g * u1.y; vals[6] = g * u1.z; vals[7] = g * u1.w;
+            vals[8] = g * u2.x; vals[9] = g * u2.y; vals[10] = g * u2.z; vals[11] = g * u2.w;
+        }
+        // the quadrant's loss terms: lanes hold up to 2 terms each (own_loss already restricted to owned pixels)
+        vals[19] = own_loss;
+        float mine = 0.f;
+        bool nz = false;
+#pragma unroll
+        for (int i = 0; i < NVALS; ++i) nz |= vals[i] != 0.f;
+        if (__ballot(nz) != 0ull) {
+            float red[13];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) red[i] = vals[i];
+            red[12] = vals[19];
+            wave_sum_n(red);
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (lane == i) mine = red[i];
+            if (lane == 19) mine = red[12];
+        }
+        if (lane < NPART) part[lane] = mine;
+        wave_lds_sync();  // (the LDS arrays are reused by the next tile)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1311,8 +1339,8 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 __global__ void set_it_kernel(EngineState* st, int it) { st->it = it; st->it_next = it; }
 
 // ---------------------------------------------------------------------------------------------
-enum { K_SCATTER, K_COMPACT_BIG, K_SHADE, K_UPDATE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"scatter_kernel", "compact_big_kernel", "shade_kernel", "update_xfm_kernel"};
+enum { K_SCATTER, K_COMPACT_BIG, K_SHADE, K_EDGE, K_UPDATE, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"scatter_kernel", "compact_big_kernel", "shade_kernel", "edge_kernel", "update_xfm_kernel"};
 
 // shading grid (B, S): S slices per hypothesis, SHADE_GRID workgroups per role in total (all resident at 4 waves/SIMD)
 static dim3 shade_grid(const ddx_engine_desc& d)
@@ -1350,6 +1378,12 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
         g.z = E.n_roles;
         if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E);
         else shade_kernel<false><<<g, 256, 0, s>>>(E);
+    }
+    if (d.use_edge) {
+        if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
+        dim3 ge = shade_grid(d);  // 66 VGPRs: 7 waves/SIMD, so more resident workgroups than the shade kernel has
+        ge.y = (unsigned)((EDGE_GRID / d.B) < 1 ? 1 : ((EDGE_GRID / d.B) > 64 ? 64 : (EDGE_GRID / d.B)));
+        edge_kernel<<<ge, 256, 0, s>>>(E);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
     if (d.use_edge) update_xfm_kernel<3><<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
@@ -1397,7 +1431,9 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     e->dev.eval_loss = nullptr;
     {
         EngineDev& E = e->dev;
-        const bool on[MAX_ROLES] = {desc->use_rgb || desc->use_depth, desc->use_mask != 0, desc->use_edge != 0};
+        // shade roles: 0 colour/depth (also runs for the edge term: it produces the luminance + unit gradients that
+        // edge_kernel consumes), 1 mask.  Partial slot 2 belongs to edge_kernel.
+        const bool on[MAX_ROLES] = {desc->use_rgb || desc->use_depth || desc->use_edge, desc->use_mask != 0, false};
         E.n_roles = 0;
         E.role_mask = 0;
         for (int r = 0; r < MAX_ROLES; ++r) E.roles[r] = 0;
@@ -1411,6 +1447,7 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
             E.roles[0] = 1;
             E.role_mask = 2;
         }
+        if (desc->use_edge) E.role_mask |= 4;  // slot 2
         E.st_role = E.roles[0];
     }
     const size_t need = engine_layout(e->dev, *desc, b.scratch);
@@ -1584,8 +1621,10 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
         if (int err = run_iteration(e, s, ev)) return err;
         DDX_HIP(hipEventSynchronize(ev[K_COUNT]));
         for (int k = 0; k < K_COUNT; ++k) {
+            if (k == K_EDGE && !e->dev.d.use_edge) continue;  // not launched, no event recorded: 0
+            const int k_end = (k + 1 == K_EDGE && !e->dev.d.use_edge) ? K_UPDATE : k + 1;
             float ms = 0.f;
-            DDX_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            DDX_HIP(hipEventElapsedTime(&ms, ev[k], ev[k_end]));
             ms_out[k] += ms;
         }
     }
