@@ -19,6 +19,8 @@
 //                  contracted with [pos;1] in registers (the xfm_bwd_mtx product, mesh.cu:165-214),
 //                  reduced per workgroup and written as one 24-float partial per tile: no atomics,
 //                  bit-reproducible.
+//   edge_kernel    (edge extension only) Sobel-gradient L1 of the rendered luminance against the observed image, from the
+//                  luminance + unit gradients the colour role of shade_kernel wrote; owner-computes, texture-free
 //   update_xfm_kernel  per hypothesis: fixed-order sum of its quadrant partials, whole-frame constants for the
 //                  pixels outside the active tiles, proj^T chain, quaternion chain, SGD/Adam step,
 //                  loss log (diffdope.py:558,576,604) -- and, with the new pose, the NEXT iteration's
