@@ -526,9 +526,12 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
 // The edge term (extension) is a separate, texture-free kernel (edge_kernel below): in the edge build the colour role
 // also writes the luminance and U = d lum / d final of every covered pixel.
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
+#ifndef DDX_PHASE_ROLE
+#define DDX_PHASE_ROLE 0
+#endif
 #define DDX_PHASE(i)                                                           \
     do {                                                                       \
-        if (ROLE == 0) {                                                       \
+        if (ROLE == DDX_PHASE_ROLE) {                                          \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
             ph[i] = __builtin_amdgcn_s_memrealtime();                          \
         }                                                                      \
@@ -582,6 +585,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         const int lx = lane % QUAD, ly = lane / QUAD;
         const int px = qx + lx, py = qy + ly;
         const int hidx = (ly + 1) * QH + lx + 1;
+        // the observed segmentation of the own pixel only depends on the pixel: requested WITH the zbuf entries, not after
+        // them (for a quadrant without silhouette pairs the chain was zbuf -> seg -> loss)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        const size_t pix = (size_t)py * W + px;
+        if (px < W && py < H) { s0 = E.b.gt_seg[pix * 3 + 0]; s1 = E.b.gt_seg[pix * 3 + 1]; s2 = E.b.gt_seg[pix * 3 + 2]; }
         int id;
         if (ROLE == 0) {
             // the colour / depth role only needs its own pixel: one zbuf entry per lane, no LDS staging
@@ -625,9 +633,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         A.L[0] = A.L[1] = A.L[2] = A.L[3] = 0.f;
         const float lrb = E.b.lr_mult[b];
         const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        const size_t pix = (size_t)py * W + px;
-        if (id >= 0) { s0 = E.b.gt_seg[pix * 3 + 0]; s1 = E.b.gt_seg[pix * 3 + 1]; s2 = E.b.gt_seg[pix * 3 + 2]; }
         if (ROLE == 0 && id > 0) {
             const int t = id - 1;
             const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
@@ -773,6 +778,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             if (c2) s_pairs[wave][n0 + n1 + __popcll(m2 & lt)] = (unsigned short)(lane | (2 << 6));
             if (c3) s_pairs[wave][n0 + n1 + n2 + __popcll(m3 & lt)] = (unsigned short)(lane | (3 << 6));
             wave_lds_sync();
+            DDX_PHASE(2);
             // forward: each lane owns pair `lane` (+64, ... in the rare quadrant with more than 64 pairs)
             int tl0 = -1;
             float cd0 = 0.f;
@@ -805,6 +811,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 }
             }
             wave_lds_sync();
+            DDX_PHASE(3);
             // pixel: mask value, loss term, d loss / d mask
             float gm = 0.f;
             if (inimg) {
@@ -816,6 +823,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             s_gm[wave][lane] = gm;
             s_m[wave][lane] = 0.f;  // re-arm for the next tile
             wave_lds_sync();
+            DDX_PHASE(4);
             // backward: a pair whose target pixel is ours scales its unit contribution by d loss / d alpha
             for (int j0 = 0; j0 < np; j0 += 64) {
                 int tl = tl0;
@@ -871,7 +879,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         if (lane < NPART) part[lane] = mine;
         DDX_PHASE(6);
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
-        if (ROLE == 0 && tid == 0 && k == k_first) {
+        if (ROLE == DDX_PHASE_ROLE && tid == 0 && k == k_first) {
             const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
             if (wg < 4096) {
                 unsigned long long* q = E.trace + ((size_t)1 * 8192) * 4 + wg * 8;  // kernel slot 1 (unused), 8 stamps per workgroup
