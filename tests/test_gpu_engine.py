@@ -53,9 +53,9 @@ def test_engine_one_iteration_losses_and_gradients(weights, textured):
     np.testing.assert_allclose(eng.mtx_log[0].cpu().numpy().reshape(-1, 4, 4), orc.pose_fwd(sc["params"]), rtol=1e-5, atol=1e-6)
 
 
-def test_engine_graph_replay_equals_stream_launches_and_is_deterministic():
+@pytest.mark.parametrize("w", [dict(rgb=0.7, depth=1.0, mask=1.0), dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8)])
+def test_engine_graph_replay_equals_stream_launches_and_is_deterministic(w):
     sc = make_scene(16, 20, 60, 80, B=4, dist=1.8)
-    w = dict(rgb=0.7, depth=1.0, mask=1.0)
     lrs = [0.05] * 6
     outs = []
     for use_graph in (False, True, True):
