@@ -579,7 +579,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         const int flat = b * L.NT + tcy * L.ntx + tcx;
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
-        const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
+        const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * L.zper;
         // stored by POSITION k in the hypothesis' ordered active list: update_xfm_kernel reads one contiguous run
         float* part = E.partials + ((((size_t)b * L.NT + k) * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
         const int lx = lane % QUAD, ly = lane / QUAD;
@@ -595,7 +595,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             // the colour / depth role only needs its own pixel: one zbuf entry per lane, no LDS staging
             id = -1;
             if (px < W && py < H) {
-                const unsigned long long key = zb[(size_t)py * W + px];
+                const unsigned long long key = zb[zaddr(px, py, L.zwb)];
                 id = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
             }
             if (__ballot(id > 0) == 0ull) {  // nothing drawn in this quadrant: only background terms
@@ -610,7 +610,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 const int gx = qx - 1 + e % QH, gy = qy - 1 + e / QH;
                 int v = -1;
                 if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
-                    const unsigned long long key = zb[(size_t)gy * W + gx];
+                    const unsigned long long key = zb[zaddr(gx, gy, L.zwb)];
                     v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
                 }
                 ids[e] = v;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
     const int H = d.H, W = d.W;
     const int b = blockIdx.x;
     const int n_tiles = L.b_count[b];
-    const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * H * W;
+    const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * L.zper;
     const float* __restrict__ lumb = E.lumbuf + (size_t)b * H * W;
     const float lrb = E.b.lr_mult[b];
     const float kc = d.w_edge * lrb * __fdiv_rn(1.0f, (float)d.B_global) / (2.0f * (float)H * (float)W) * 0.125f;
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
             cov[r] = false; lm[r] = 0.f;
             if (e < EH * EH && gx >= 0 && gy >= 0 && gx < W && gy < H) {
                 const size_t g = (size_t)gy * W + gx;
-                cov[r] = zb[g] != ~0ull;
+                cov[r] = zb[zaddr(gx, gy, L.zwb)] != ~0ull;
                 lm[r] = lumb[g];  // garbage where nothing is drawn: masked below
             }
         }
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
             ge[r] = term[r] ? E.gtedge[(size_t)gy * W + gx] : make_float2(0.f, 0.f);
         }
         float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, u2 = u0;
-        const bool own_cov = inimg && zb[pix] != ~0ull;
+        const bool own_cov = inimg && zb[zaddr(px, py, L.zwb)] != ~0ull;
         if (inimg) {  // (read unconditionally inside the image: masked by own_cov below -- keeps the loads independent of zbuf)
             const float4* ub = reinterpret_cast<const float4*>(E.ubuf + ((size_t)b * H * W + pix) * 12);
             u0 = ub[0]; u1 = ub[1]; u2 = ub[2];
@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         for (int s = slice; s < na; s += UPD_SLICES) {  // (start is a multiple of 256, hence of UPD_SLICES)
             const int txy = s_tiles[s];
             const int zx = (txy & 0xffff) * DDX_TILE + lx, zy = (txy >> 16) * DDX_TILE + ly;
-            if (zx < d.W && zy < d.H) E.L.zbuf[((size_t)b * d.H + zy) * d.W + zx] = ~0ull;
+            if (zx < d.W && zy < d.H) E.L.zbuf[(size_t)b * E.L.zper + zaddr(zx, zy, E.L.zwb)] = ~0ull;
         }
     }
     acc += __shfl_xor(acc, 32, 64);  // groups 2w and 2w+1 live in wave w

@@ -15,8 +15,11 @@ struct RasterScratch {
     int2* snap;               // [B,V] window coordinates in 1/256 px (x = INT_MIN if w <= 0)
     uint2* biglist;           // [B,T] the LARGE triangles of each hypothesis: (triangle id, packed tile range tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24)
     int* bigcount;            // [B] entries of biglist (appended by scatter_kernel, one atomic per wave; re-armed by the consumer)
-    unsigned long long* zbuf; // [B,H,W] (depth key << 32 | triangle id), all ones = background
+    unsigned long long* zbuf; // [B, zper] (depth key << 32 | triangle id), all ones = background; per hypothesis the frame is
+                              // stored in 4x4-pixel blocks (16 entries = one 128-byte line), see zaddr()
     size_t zbuf_bytes;
+    size_t zper;              // entries per hypothesis = zwb * ceil(H/4) * 16
+    int zwb;                  // 4x4 blocks per row = ceil(W/4)
     size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount)
     int ntx, nty, NT;
     PixNdc ndc;               // pixel index -> NDC centre constants for (H, W)
@@ -47,6 +50,15 @@ struct RasterScratch {
 #endif
 
 size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, int W);
+
+// zbuf address of pixel (px, py) inside one hypothesis' frame.  4x4 blocks instead of rows: the 64-bit atomicMin stream of
+// the rasteriser is bound by the number of distinct 128-byte lines an instruction touches (tools/ubench/atomic_density.hip:
+// 48 ps per lane-atomic on random lines, 9 ps on one line), and the fragments of a small triangle and of its neighbours in
+// the mesh form a compact 2-D patch -- 16x1 row segments cut it into twice as many lines as 4x4 blocks do.
+__device__ __forceinline__ unsigned zaddr(int px, int py, int zwb)
+{
+    return (unsigned)(((__mul24(py >> 2, zwb) + (px >> 2)) << 4) | ((py & 3) << 2) | (px & 3));
+}
 // window-coordinate snap of clip positions (the fused engine does this inside its transform kernel)
 int raster_snap(const float* pos, int B, int V, int H, int W, const RasterScratch& L, hipStream_t s);
 // scatter + (compaction | large-triangle raster) (no emit); asynchronous on s.  Needs L.snap filled.

@@ -49,7 +49,9 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     const size_t o_bcount = carve((size_t)B * sizeof(int));
     const size_t o_snap = carve((size_t)B * V * sizeof(int2));
     const size_t o_range = carve((size_t)B * T * sizeof(uint2));
-    const size_t o_zbuf = carve((size_t)B * H * W * sizeof(unsigned long long));
+    const int zwb = (W + 3) / 4, zhb = (H + 3) / 4;
+    const size_t zper = (size_t)zwb * zhb * 16;
+    const size_t o_zbuf = carve((size_t)B * zper * sizeof(unsigned long long));
     L.counters = (int*)(p + o_counters);
     L.tile_flag = (int*)(p + o_flag);
     L.tile_big = (int*)(p + o_big);
@@ -59,7 +61,9 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.biglist = (uint2*)(p + o_range);
     L.bigcount = (int*)(p + o_bigcount);
     L.zbuf = (unsigned long long*)(p + o_zbuf);
-    L.zbuf_bytes = (size_t)B * H * W * sizeof(unsigned long long);
+    L.zbuf_bytes = (size_t)B * zper * sizeof(unsigned long long);
+    L.zper = zper;
+    L.zwb = zwb;
     L.ntx = ntx; L.nty = nty; L.NT = (int)NT;
     L.ndc.xs = 2.0f / (float)W; L.ndc.xo = 1.0f / (float)W - 1.0f;  // as make_pixndc (host float division is IEEE too)
     L.ndc.ys = 2.0f / (float)H; L.ndc.yo = 1.0f / (float)H - 1.0f;
@@ -165,7 +169,7 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                     if (mask) {
                         const float* P = pos + (size_t)b * V * 4;
                         const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
-                        unsigned long long* Z = L.zbuf + (size_t)b * H * W;
+                        unsigned long long* Z = L.zbuf + (size_t)b * L.zper;
                         const PixNdc ndc = L.ndc;  // host-computed (IEEE divisions, same values as make_pixndc)
                         const float rn = __frcp_rn((float)nxp);
                         while (mask) {
@@ -175,7 +179,7 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                             float zw;
                             const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
                             if (pixel_depth(p0, p1, p2, fx, fy, zw))
-                                atomicMin(Z + (unsigned)(__mul24(py0 + j, W) + px0 + i), ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
+                                atomicMin(Z + zaddr(px0 + i, py0 + j, L.zwb), ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
                         }
                     }
                 }
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
                 }
             }
         }
-        if (best != ~0ull) atomicMin(L.zbuf + ((size_t)b * H + py) * W + px, best);
+        if (best != ~0ull) atomicMin(L.zbuf + (size_t)b * L.zper + zaddr(px, py, L.zwb), best);
 #ifdef DDX_TRACE
         n_done += 1 + ((unsigned long long)n_big << 32);
 #endif
@@ -447,12 +451,12 @@ __global__ __launch_bounds__(256) void emit_kernel(const float* __restrict__ pos
 {
     const long long n = (long long)B * H * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const unsigned long long key = L.zbuf[i];
+        const int px = (int)(i % W);
+        const int py = (int)((i / W) % H);
+        const int b = (int)(i / ((long long)W * H));
+        const unsigned long long key = L.zbuf[(size_t)b * L.zper + zaddr(px, py, L.zwb)];
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (key != ~0ull) {
-            const int px = (int)(i % W);
-            const int py = (int)((i / W) % H);
-            const int b = (int)(i / ((long long)W * H));
             const int t = (int)(unsigned)(key & 0xffffffffull);
             const float* P = pos + (size_t)b * V * 4;
             const float4 p0 = ld4(P + (size_t)tri[t * 3 + 0] * 4), p1 = ld4(P + (size_t)tri[t * 3 + 1] * 4),
