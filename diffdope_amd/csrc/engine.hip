@@ -32,7 +32,9 @@
 // |gt*seg|, |seg| and |(-t_z - gt_d) seg0|.  The first two are constants of the observed images
 // (summed once at engine creation); the third is evaluated per hypothesis and iteration over the
 // compacted list of pixels with seg0 != 0.  Pixels of active tiles add (actual - background) terms.
+#include <algorithm>
 #include <new>
+#include <vector>
 #ifdef DDX_TRACE
 #include <cstdio>
 #include <vector>
@@ -70,6 +72,7 @@ struct EngineDev {
     float* ubuf;      // [B,H*W,12] edge_kernel; garbage where zbuf says "background") and U = d lum / d final per pixel
     float* adam;      // [2][2,7,B]: first and second moments, by iteration parity
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
+    int4* trisort;    // [T] {v0,v1,v2,id}: triangles in Morton order of their object-space centroids (scatter_kernel's processing order)
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     EngineState* st;
     int st_role;      // shade role that advances the iteration counter (= roles[0])
@@ -113,6 +116,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
+    const size_t o_perm = carve((size_t)d.T * sizeof(int4));
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
     const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * MAX_ROLES * NPART * sizeof(float));  // per 8x8 quadrant and shade role
     const size_t o_edge = carve(d.use_edge ? (size_t)d.H * d.W * sizeof(float2) : 0);
@@ -128,6 +132,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.trirec = (int4*)(p + o_rec);
+    E.trisort = (int4*)(p + o_perm);
     E.partials = (float*)(p + o_part);
     E.gtedge = d.use_edge ? (float2*)(p + o_edge) : nullptr;
     E.lumbuf = d.use_edge ? (float*)(p + o_lum) : nullptr;
@@ -1499,6 +1504,56 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     trirec_kernel<<<ddx_cdiv(E.d.T, 256), 256, 0, s>>>(E);
     if (E.d.use_edge) edge_setup_kernel<<<1, 1024, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
+    // ---- processing order of the rasteriser: triangles sorted by the Morton code of their object-space centroid (host,
+    // once per engine).  The 64-bit atomicMin stream is bound by distinct zbuf lines per instruction; in mesh-file order the
+    // 128 triangles of a wave may be a long thin strip (or anything), in Morton order they are a compact patch.
+    {
+        const int V = E.d.V, T = E.d.T;
+        std::vector<float> hpos((size_t)V * 3);
+        std::vector<int> htri((size_t)T * 3);
+        DDX_HIP(hipMemcpyAsync(hpos.data(), E.b.pos, hpos.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        DDX_HIP(hipMemcpyAsync(htri.data(), E.b.tri, htri.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        DDX_HIP(hipStreamSynchronize(s));
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int v = 0; v < V; ++v)
+            for (int c = 0; c < 3; ++c) {
+                const float x = hpos[(size_t)v * 3 + c];
+                if (x == x) { lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c]; }
+            }
+        auto spread = [](unsigned x) {  // 10 bits -> every third bit
+            x &= 1023u;
+            x = (x | (x << 16)) & 0x030000FFu;
+            x = (x | (x << 8)) & 0x0300F00Fu;
+            x = (x | (x << 4)) & 0x030C30C3u;
+            x = (x | (x << 2)) & 0x09249249u;
+            return x;
+        };
+        std::vector<unsigned long long> keys((size_t)T);
+        for (int t = 0; t < T; ++t) {
+            unsigned q[3];
+            for (int c = 0; c < 3; ++c) {
+                float m = 0.f;
+                for (int k = 0; k < 3; ++k) {
+                    const int v = htri[(size_t)t * 3 + k];
+                    m += (v >= 0 && v < V) ? hpos[(size_t)v * 3 + c] : 0.f;
+                }
+                const float ext = hi[c] - lo[c];
+                const float u = ext > 0.f ? (m / 3.0f - lo[c]) / ext : 0.f;
+                q[c] = (unsigned)(u < 0.f ? 0.f : (u > 1.f ? 1023.f : u * 1023.f));
+            }
+            const unsigned code = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+            keys[(size_t)t] = ((unsigned long long)code << 32) | (unsigned)t;
+        }
+        std::sort(keys.begin(), keys.end());
+        std::vector<int4> hrec((size_t)T);
+        for (int i = 0; i < T; ++i) {
+            const int t = (int)(unsigned)(keys[(size_t)i] & 0xffffffffull);
+            hrec[(size_t)i] = make_int4(htri[(size_t)t * 3 + 0], htri[(size_t)t * 3 + 1], htri[(size_t)t * 3 + 2], t);
+        }
+        DDX_HIP(hipMemcpyAsync(E.trisort, hrec.data(), hrec.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        DDX_HIP(hipStreamSynchronize(s));
+        E.L.trisort = E.trisort;
+    }
     e->setup_done = true;
     return 0;
 }

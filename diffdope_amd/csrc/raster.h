@@ -20,6 +20,8 @@ struct RasterScratch {
     size_t zbuf_bytes;
     size_t zper;              // entries per hypothesis = zwb * ceil(H/4) * 16
     int zwb;                  // 4x4 blocks per row = ceil(W/4)
+    const int4* trisort;      // [T] or null: the triangles in the processing order of scatter_kernel, {v0, v1, v2, original id}
+                              // (lane j takes record j; ids in zbuf stay the original ones, so the result does not depend on it)
     size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount)
     int ntx, nty, NT;
     PixNdc ndc;               // pixel index -> NDC centre constants for (H, W)

@@ -64,6 +64,7 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.zbuf_bytes = (size_t)B * zper * sizeof(unsigned long long);
     L.zper = zper;
     L.zwb = zwb;
+    L.trisort = nullptr;
     L.ntx = ntx; L.nty = nty; L.NT = (int)NT;
     L.ndc.xs = 2.0f / (float)W; L.ndc.xo = 1.0f / (float)W - 1.0f;  // as make_pixndc (host float division is IEEE too)
     L.ndc.ys = 2.0f / (float)H; L.ndc.yo = 1.0f / (float)H - 1.0f;
@@ -233,9 +234,19 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
     int2 va[SCATTER_TPL], vb[SCATTER_TPL], vc[SCATTER_TPL];
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
-        t[k] = (chunk * SCATTER_TPL + k) * 256 + threadIdx.x;
-        const int tt = min(t[k], T - 1);
-        i0[k] = tri[tt * 3 + 0]; i1[k] = tri[tt * 3 + 1]; i2[k] = tri[tt * 3 + 2];
+        const int slot = (chunk * SCATTER_TPL + k) * 256 + threadIdx.x;
+        // engine: spatially sorted records {v0, v1, v2, original id} -- the lanes of a wave take triangles that are
+        // neighbours in space, so their fragments share zbuf lines; one coalesced 16-byte load per triangle.
+        // t[k] is the ORIGINAL triangle id (T marks a lane past the end)
+        if (L.trisort) {
+            const int4 rec = L.trisort[min(slot, T - 1)];
+            i0[k] = rec.x; i1[k] = rec.y; i2[k] = rec.z;
+            t[k] = slot < T ? rec.w : T;
+        } else {
+            const int tt = min(slot, T - 1);
+            i0[k] = tri[tt * 3 + 0]; i1[k] = tri[tt * 3 + 1]; i2[k] = tri[tt * 3 + 2];
+            t[k] = slot < T ? slot : T;
+        }
     }
     SPH(1);
 #pragma unroll
