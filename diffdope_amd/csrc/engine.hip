@@ -72,6 +72,15 @@ struct EngineDev {
     float* ubuf;      // [B,H*W,12] edge_kernel; garbage where zbuf says "background") and U = d lum / d final per pixel
     float* adam;      // [2][2,7,B]: first and second moments, by iteration parity
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
+    // Internal, spatially sorted copy of the mesh (built once per engine): vertices renumbered in Morton order of their
+    // object-space position, so that the vertex data of neighbouring triangles / pixels are neighbours in memory whatever
+    // order the mesh file had (a randomly ordered vertex list cost 15-20 % otherwise); triangle ids are NOT renumbered.
+    float* spos;      // [V,3] positions, sorted vertex order
+    float* suv;       // [V,2] or null
+    float* scol;      // [V,3] or null
+    int* stri;        // [T,3] triangles (original triangle order) with sorted vertex ids
+    int* vnew;        // [V] old vertex id -> sorted id
+    int* vold;        // [V] sorted id -> old vertex id
     int4* trisort;    // [T] {v0,v1,v2,id}: triangles in Morton order of their object-space centroids (scatter_kernel's processing order)
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     EngineState* st;
@@ -117,6 +126,12 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
     const size_t o_perm = carve((size_t)d.T * sizeof(int4));
+    const size_t o_spos = carve((size_t)d.V * 3 * sizeof(float));
+    const size_t o_suv = carve((size_t)d.V * 2 * sizeof(float));
+    const size_t o_scol = carve((size_t)d.V * 3 * sizeof(float));
+    const size_t o_stri = carve((size_t)d.T * 3 * sizeof(int));
+    const size_t o_vnew = carve((size_t)d.V * sizeof(int));
+    const size_t o_vold = carve((size_t)d.V * sizeof(int));
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
     const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * MAX_ROLES * NPART * sizeof(float));  // per 8x8 quadrant and shade role
     const size_t o_edge = carve(d.use_edge ? (size_t)d.H * d.W * sizeof(float2) : 0);
@@ -133,6 +148,12 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.seglist = (float2*)(p + o_seg);
     E.trirec = (int4*)(p + o_rec);
     E.trisort = (int4*)(p + o_perm);
+    E.spos = (float*)(p + o_spos);
+    E.suv = (float*)(p + o_suv);
+    E.scol = (float*)(p + o_scol);
+    E.stri = (int*)(p + o_stri);
+    E.vnew = (int*)(p + o_vnew);
+    E.vold = (int*)(p + o_vold);
     E.partials = (float*)(p + o_part);
     E.gtedge = d.use_edge ? (float2*)(p + o_edge) : nullptr;
     E.lumbuf = d.use_edge ? (float*)(p + o_lum) : nullptr;
@@ -302,7 +323,7 @@ __device__ __forceinline__ void xfm_vertex(const EngineDev& E, const float F[16]
     const float a2 = r == 0 ? F[2] : (r == 1 ? F[6] : (r == 2 ? F[10] : F[14]));
     const float a3 = r == 0 ? F[3] : (r == 1 ? F[7] : (r == 2 ? F[11] : F[15]));
     const bool live = n < n_end;
-    const float* p = E.b.pos + (size_t)(live ? n : 0) * 3;
+    const float* p = E.spos + (size_t)(live ? n : 0) * 3;
     const float px = p[0], py = p[1], pz = p[2];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, px, acc, 0, 0, 0);
@@ -561,8 +582,8 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W, V = d.V;
     const RasterScratch& L = E.L;
-    const float* __restrict__ pos = E.b.pos;
-    const int* __restrict__ tri = E.b.tri;
+    const float* __restrict__ pos = E.spos;
+    const int* __restrict__ tri = E.stri;
     int* ids = s_ids[wave];
     // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's ordered active list -- no prefix over hypotheses,
     // no global list, workgroups beyond the count leave after one scalar load
@@ -652,7 +673,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             // after the clip vertices have arrived (the compiler does not speculate loads across the branch)
             float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f;
             if ((d.use_rgb || NR == 3) && d.Th > 0) {
-                const float* uv = E.b.uv;
+                const float* uv = E.suv;
                 a0x = uv[(size_t)v0 * 2]; a0y = uv[(size_t)v0 * 2 + 1];
                 a1x = uv[(size_t)v1 * 2]; a1y = uv[(size_t)v1 * 2 + 1];
                 a2x = uv[(size_t)v2 * 2]; a2y = uv[(size_t)v2 * 2 + 1];
@@ -690,7 +711,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     }
                     DDX_PHASE(4);
                 } else {
-                    const float* vc = E.b.vtx_color;
+                    const float* vc = E.scol;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float c0 = vc[(size_t)v0 * 3 + c], c1 = vc[(size_t)v1 * 3 + c], c2 = vc[(size_t)v2 * 3 + c];
@@ -1122,7 +1143,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int n = n_begin + u * 256 + tid;
-        const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
+        const float* p = E.spos + (size_t)(n < n_end ? n : 0) * 3;
         px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
     }
     // ---- the scalars of the tail, one per thread, into LDS: params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45.
@@ -1327,7 +1348,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int n = n0 + u * 256 + tid;
-                const float* p = E.b.pos + (size_t)(n < n_end ? n : 0) * 3;
+                const float* p = E.spos + (size_t)(n < n_end ? n : 0) * 3;
                 px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
             }
         }
@@ -1386,7 +1407,7 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
 {
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
-    if (int err = raster_run(E.clip, E.b.tri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_SCATTER : nullptr)) return err;
+    if (int err = raster_run(E.clip, E.stri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_SCATTER : nullptr)) return err;
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
     {
         dim3 g = shade_grid(d);
@@ -1485,12 +1506,30 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     return 0;
 }
 
-__global__ void trirec_kernel(EngineDev E)
+// sorted internal mesh: vertex attributes gathered into sorted order, triangle / opposite-vertex ids renumbered
+__global__ void remap_vertices_kernel(EngineDev E)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= E.d.V) return;
+    const int o = E.vold[n];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) E.spos[(size_t)n * 3 + c] = E.b.pos[(size_t)o * 3 + c];
+    if (E.b.uv) { E.suv[(size_t)n * 2 + 0] = E.b.uv[(size_t)o * 2 + 0]; E.suv[(size_t)n * 2 + 1] = E.b.uv[(size_t)o * 2 + 1]; }
+    if (E.b.vtx_color)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) E.scol[(size_t)n * 3 + c] = E.b.vtx_color[(size_t)o * 3 + c];
+}
+
+__global__ void remap_triangles_kernel(EngineDev E)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= E.d.T) return;
-    E.trirec[t * 2 + 0] = make_int4(E.b.tri[t * 3 + 0], E.b.tri[t * 3 + 1], E.b.tri[t * 3 + 2], E.b.opp[t * 3 + 0]);
-    E.trirec[t * 2 + 1] = make_int4(E.b.opp[t * 3 + 1], E.b.opp[t * 3 + 2], 0, 0);
+    const int V = E.d.V;
+    auto rm = [&](int i) { return (i >= 0 && i < V) ? E.vnew[i] : i; };  // (out-of-range ids stay out of range: the triangle is ignored)
+    const int v0 = rm(E.b.tri[t * 3 + 0]), v1 = rm(E.b.tri[t * 3 + 1]), v2 = rm(E.b.tri[t * 3 + 2]);
+    E.stri[t * 3 + 0] = v0; E.stri[t * 3 + 1] = v1; E.stri[t * 3 + 2] = v2;
+    E.trirec[t * 2 + 0] = make_int4(v0, v1, v2, rm(E.b.opp[t * 3 + 0]));
+    E.trirec[t * 2 + 1] = make_int4(rm(E.b.opp[t * 3 + 1]), rm(E.b.opp[t * 3 + 2]), 0, 0);
 }
 
 static int engine_setup(ddx_engine* e, hipStream_t s)
@@ -1501,12 +1540,13 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // kept zero by update_xfm_kernel afterwards
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
-    trirec_kernel<<<ddx_cdiv(E.d.T, 256), 256, 0, s>>>(E);
     if (E.d.use_edge) edge_setup_kernel<<<1, 1024, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
-    // ---- processing order of the rasteriser: triangles sorted by the Morton code of their object-space centroid (host,
-    // once per engine).  The 64-bit atomicMin stream is bound by distinct zbuf lines per instruction; in mesh-file order the
-    // 128 triangles of a wave may be a long thin strip (or anything), in Morton order they are a compact patch.
+    // ---- internal sorted mesh (host, once per engine).  (1) Vertices renumbered in Morton order of their object-space
+    // position: the vertex data of neighbouring triangles and pixels become neighbours in memory whatever order the mesh
+    // file had.  (2) Processing order of the rasteriser: triangles sorted by the Morton code of their centroid -- the 64-bit
+    // atomicMin stream is bound by distinct zbuf lines per instruction; in file order the 128 triangles of a wave may be a
+    // long thin strip (or anything), in Morton order they are a compact patch.  Triangle ids are not renumbered.
     {
         const int V = E.d.V, T = E.d.T;
         std::vector<float> hpos((size_t)V * 3);
@@ -1528,30 +1568,45 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             x = (x | (x << 2)) & 0x09249249u;
             return x;
         };
-        std::vector<unsigned long long> keys((size_t)T);
-        for (int t = 0; t < T; ++t) {
+        auto morton = [&](const float m[3]) {
             unsigned q[3];
             for (int c = 0; c < 3; ++c) {
-                float m = 0.f;
-                for (int k = 0; k < 3; ++k) {
-                    const int v = htri[(size_t)t * 3 + k];
-                    m += (v >= 0 && v < V) ? hpos[(size_t)v * 3 + c] : 0.f;
-                }
                 const float ext = hi[c] - lo[c];
-                const float u = ext > 0.f ? (m / 3.0f - lo[c]) / ext : 0.f;
+                const float u = (ext > 0.f && m[c] == m[c]) ? (m[c] - lo[c]) / ext : 0.f;
                 q[c] = (unsigned)(u < 0.f ? 0.f : (u > 1.f ? 1023.f : u * 1023.f));
             }
-            const unsigned code = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
-            keys[(size_t)t] = ((unsigned long long)code << 32) | (unsigned)t;
+            return spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        };
+        std::vector<unsigned long long> keys((size_t)(V > T ? V : T));
+        std::vector<int> vold((size_t)V), vnew((size_t)V);
+        for (int v = 0; v < V; ++v) keys[(size_t)v] = ((unsigned long long)morton(&hpos[(size_t)v * 3]) << 32) | (unsigned)v;
+        std::sort(keys.begin(), keys.begin() + V);
+        for (int n = 0; n < V; ++n) {
+            vold[(size_t)n] = (int)(unsigned)(keys[(size_t)n] & 0xffffffffull);
+            vnew[(size_t)vold[(size_t)n]] = n;
         }
-        std::sort(keys.begin(), keys.end());
+        for (int t = 0; t < T; ++t) {
+            float m[3] = {0.f, 0.f, 0.f};
+            for (int k = 0; k < 3; ++k) {
+                const int v = htri[(size_t)t * 3 + k];
+                for (int c = 0; c < 3; ++c) m[c] += (v >= 0 && v < V) ? hpos[(size_t)v * 3 + c] * (1.0f / 3.0f) : 0.f;
+            }
+            keys[(size_t)t] = ((unsigned long long)morton(m) << 32) | (unsigned)t;
+        }
+        std::sort(keys.begin(), keys.begin() + T);
         std::vector<int4> hrec((size_t)T);
+        auto rm = [&](int i) { return (i >= 0 && i < V) ? vnew[(size_t)i] : i; };
         for (int i = 0; i < T; ++i) {
             const int t = (int)(unsigned)(keys[(size_t)i] & 0xffffffffull);
-            hrec[(size_t)i] = make_int4(htri[(size_t)t * 3 + 0], htri[(size_t)t * 3 + 1], htri[(size_t)t * 3 + 2], t);
+            hrec[(size_t)i] = make_int4(rm(htri[(size_t)t * 3 + 0]), rm(htri[(size_t)t * 3 + 1]), rm(htri[(size_t)t * 3 + 2]), t);
         }
         DDX_HIP(hipMemcpyAsync(E.trisort, hrec.data(), hrec.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        DDX_HIP(hipStreamSynchronize(s));
+        DDX_HIP(hipMemcpyAsync(E.vold, vold.data(), vold.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        DDX_HIP(hipMemcpyAsync(E.vnew, vnew.data(), vnew.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        remap_vertices_kernel<<<ddx_cdiv(V, 256), 256, 0, s>>>(E);
+        remap_triangles_kernel<<<ddx_cdiv(T, 256), 256, 0, s>>>(E);
+        DDX_LAUNCH_CHECK();
+        DDX_HIP(hipStreamSynchronize(s));  // (the host vectors above are the copy sources)
         E.L.trisort = E.trisort;
     }
     e->setup_done = true;

@@ -332,3 +332,24 @@ def test_device_side_selection_matches_torch_argmin():
         assert got[0] == ref[0], (B, mask, got[0], ref[0])
         assert abs(got[1] - ref[1]) <= 1e-6 * max(1.0, abs(ref[1]))
         assert torch.equal(got[2].cpu(), ref[2].cpu())
+
+
+def test_engine_result_does_not_depend_on_the_order_of_the_mesh_file():
+    """The engine works on an internal copy with vertices renumbered and triangles processed in Morton order; shuffling the
+    vertex list and the triangle list of the input must not change losses or gradients (beyond which of two coincident
+    triangles wins an exact depth tie at the mesh seam)."""
+    sc = make_scene(16, 20, 60, 80, B=3, dist=1.8)
+    w = dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8)
+    eng, params = _engine(sc, w, [0.1])
+    l0, g0 = eng.loss_and_grad()
+    rng = np.random.RandomState(1)
+    V, T_ = sc["pos"].shape[0], sc["tri"].shape[0]
+    pv = rng.permutation(V)                      # new position of old vertex v
+    inv = np.empty(V, np.int64)
+    inv[pv] = np.arange(V)
+    sc2 = dict(sc, pos=sc["pos"][inv], uv=sc["uv"][inv], vtx_color=sc["vtx_color"][inv], tri=pv[sc["tri"]][rng.permutation(T_)].astype(np.int32))
+    eng2, _ = _engine(sc2, w, [0.1])
+    l1, g1 = eng2.loss_and_grad()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(g0.abs().max()))
