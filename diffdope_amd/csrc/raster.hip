@@ -126,7 +126,6 @@ typedef unsigned long long scatter_mask_t;
 #else
 typedef unsigned scatter_mask_t;
 #endif
-#define SCATTER_TPL 2  // triangles per lane: both index/vertex gathers are issued before either is consumed
 
 // returns the packed tile range of a LARGE triangle (resolved later by the tile pass), ~0u otherwise
 __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int T, int H, int W, const RasterScratch& L,
@@ -214,7 +213,10 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
     return range;
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
+// TPL triangles per lane, NT threads per workgroup: (2, 256) normally; (1, 64) for small meshes, where 512-triangle chunks
+// would leave most of the chip without a workgroup (a 384-triangle CAD model x 64 hypotheses = 64 workgroups).
+template <int SCATTER_TPL, int SCATTER_NT>
+__global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
                                                       int T, int H, int W, RasterScratch L)
 {
     DDX_TRACE_BEGIN();
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ 
     int2 va[SCATTER_TPL], vb[SCATTER_TPL], vc[SCATTER_TPL];
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
-        const int slot = (chunk * SCATTER_TPL + k) * 256 + threadIdx.x;
+        const int slot = (chunk * SCATTER_TPL + k) * SCATTER_NT + threadIdx.x;
         // engine: spatially sorted records {v0, v1, v2, original id} -- the lanes of a wave take triangles that are
         // neighbours in space, so their fragments share zbuf lines; one coalesced 16-byte load per triangle.
         // t[k] is the ORIGINAL triangle id (T marks a lane past the end)
@@ -489,7 +491,8 @@ int raster_run(const float* pos, const int* tri, int B, int V, int T, int H, int
         DDX_HIP(hipMemsetAsync(L.counters, 0, L.zero_bytes, s));
         DDX_HIP(hipMemsetAsync(L.zbuf, 0xFF, L.zbuf_bytes, s));
     }
-    scatter_kernel<<<dim3(ddx_cdiv(T, 256 * SCATTER_TPL), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+    if ((long long)ddx_cdiv(T, 512) * B >= 1024) scatter_kernel<2, 256><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+    else scatter_kernel<1, 64><<<dim3(ddx_cdiv(T, 64), B), 64, 0, s>>>(pos, tri, V, T, H, W, L);
     if (ev) DDX_HIP(hipEventRecord(ev[1], s));
     compact_big_kernel<<<B + RASTER_BIG_GRID, 256, 0, s>>>(pos, tri, B, V, T, H, W, L);
     DDX_LAUNCH_CHECK();
