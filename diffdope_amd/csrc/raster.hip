@@ -127,10 +127,18 @@ typedef unsigned long long scatter_mask_t;
 typedef unsigned scatter_mask_t;
 #endif
 
-// returns the packed tile range of a LARGE triangle (resolved later by the tile pass), ~0u otherwise
-__device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int T, int H, int W, const RasterScratch& L,
-                                                int b, int t, int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c)
+// Coverage of one triangle (integer only, no memory reads): flags its tiles; for a SMALL triangle the bit mask of the covered
+// pixel centres of its bbox (bit k = j * nxp + i  <=>  pixel (px0 + i, py0 + j)) goes to `cv`; returns the packed tile range
+// of a LARGE triangle (resolved later by the tile pass), ~0u otherwise.
+struct ScatterCov { scatter_mask_t mask; int px0, py0, nxp; };
+
+// WALK: the lane resolves its covered centres itself, right here (the plain variant of the kernel; kept inside this function,
+// in the scope that computed the mask, because hoisting it out costs 2-3 % of the kernel in the compiler's schedule).
+template <bool WALK>
+__device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int H, int W, const RasterScratch& L, int b, int t,
+                                                int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c, ScatterCov& cv)
 {
+    cv.mask = 0; cv.px0 = 0; cv.py0 = 0; cv.nxp = 1;
     unsigned range = ~0u;  // packed tile range of a LARGE triangle
     if (a.x != INT_MIN && bq.x != INT_MIN && c.x != INT_MIN) {
         const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
@@ -164,23 +172,27 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                         for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
                             mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
                     }
-                    // pass 2: one depth evaluation + one atomic per covered centre: the wave walks max(popcount)
-                    // rounds instead of max(bbox area), and the clip-space vertices are loaded once, up front
-                    if (mask) {
-                        const float* P = pos + (size_t)b * V * 4;
-                        const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
-                        unsigned long long* Z = L.zbuf + (size_t)b * L.zper;
-                        const PixNdc ndc = L.ndc;  // host-computed (IEEE divisions, same values as make_pixndc)
-                        const float rn = __frcp_rn((float)nxp);
-                        while (mask) {
-                            const int k = RASTER_SMALL_PX > 32 ? __ffsll((long long)mask) - 1 : __ffs((unsigned)mask) - 1;
-                            mask &= mask - 1;
-                            const int j = (int)(((float)k + 0.5f) * rn), i = k - __mul24(j, nxp);  // k = j * nxp + i, exact for k < 16
-                            float zw;
-                            const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
-                            if (pixel_depth(p0, p1, p2, fx, fy, zw))
-                                atomicMin(Z + zaddr(px0 + i, py0 + j, L.zwb), ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
+                    if (WALK) {
+                        // one depth evaluation + one atomic per covered centre: the wave walks max(popcount) rounds instead
+                        // of max(bbox area), and the clip-space vertices are loaded once, up front
+                        if (mask) {
+                            const float* P = pos + (size_t)b * V * 4;
+                            const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
+                            unsigned long long* Z = L.zbuf + (size_t)b * L.zper;
+                            const PixNdc ndc = L.ndc;  // host-computed (IEEE divisions, same values as make_pixndc)
+                            const float rn = __frcp_rn((float)nxp);
+                            while (mask) {
+                                const int k = RASTER_SMALL_PX > 32 ? __ffsll((long long)mask) - 1 : __ffs((unsigned)mask) - 1;
+                                mask &= mask - 1;
+                                const int j = (int)(((float)k + 0.5f) * rn), i = k - __mul24(j, nxp);  // k = j * nxp + i, exact for k < 64
+                                float zw;
+                                const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
+                                if (pixel_depth(p0, p1, p2, fx, fy, zw))
+                                    atomicMin(Z + zaddr(px0 + i, py0 + j, L.zwb), ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
+                            }
                         }
+                    } else {
+                        cv.mask = mask; cv.px0 = px0; cv.py0 = py0; cv.nxp = nxp;
                     }
                 }
             } else {
@@ -213,12 +225,59 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
     return range;
 }
 
+// every lane walks the fragments of its own triangle (clip-space vertices loaded only when it owns a centre)
+__device__ __forceinline__ void scatter_walk(const ScatterCov& cv, const float* __restrict__ P, int i0, int i1, int i2, int t,
+                                             unsigned long long* __restrict__ Z, const PixNdc& ndc, int zwb)
+{
+    if (!cv.mask) return;
+    const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
+    scatter_mask_t m = cv.mask;
+    const float rn = __frcp_rn((float)cv.nxp);
+    while (m) {
+        const int kb = RASTER_SMALL_PX > 32 ? __ffsll((long long)m) - 1 : __ffs((unsigned)m) - 1;
+        m &= m - 1;
+        const int j = (int)(((float)kb + 0.5f) * rn), i = kb - __mul24(j, cv.nxp);  // kb = j * nxp + i, exact for kb < 64
+        float zw;
+        const float fx = __fmaf_rn((float)(cv.px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(cv.py0 + j), ndc.ys, ndc.yo);
+        if (pixel_depth(p0, p1, p2, fx, fy, zw))
+            atomicMin(Z + zaddr(cv.px0 + i, cv.py0 + j, zwb), ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
+    }
+}
+
+#ifndef SCATTER_DIRECT_MAX
+#define SCATTER_DIRECT_MAX 3  // waves in which no lane owns more fragments than this resolve them lane by lane
+#endif
+// j-th (0-based) set bit of m; j < popcount(m)
+__device__ __forceinline__ int select_bit(scatter_mask_t m, int j)
+{
+    int pos = 0;
+    unsigned w = (unsigned)m;
+#if RASTER_SMALL_PX > 32
+    {
+        const int c = __popc(w);
+        if (j >= c) { j -= c; w = (unsigned)(m >> 32); pos = 32; }
+    }
+#endif
+    int c = __popc(w & 0xFFFFu); if (j >= c) { j -= c; w >>= 16; pos += 16; } w &= 0xFFFFu;
+    c = __popc(w & 0xFFu); if (j >= c) { j -= c; w >>= 8; pos += 8; } w &= 0xFFu;
+    c = __popc(w & 0xFu); if (j >= c) { j -= c; w >>= 4; pos += 4; } w &= 0xFu;
+    c = __popc(w & 3u); if (j >= c) { j -= c; w >>= 2; pos += 2; } w &= 3u;
+    if (j >= (int)(w & 1u)) pos += 1;
+    return pos;
+}
+
 // TPL triangles per lane, NT threads per workgroup: (2, 256) normally; (1, 64) for small meshes, where 512-triangle chunks
 // would leave most of the chip without a workgroup (a 384-triangle CAD model x 64 hypotheses = 64 workgroups).
-template <int SCATTER_TPL, int SCATTER_NT>
+// EXCHANGE: redistribute the fragments over the lanes of the wave (see below) -- pays when triangles own many centres
+// (the small-mesh variant); in the micro-polygon regime of the dense meshes the plain per-lane walk is ~10 % faster.
+template <int SCATTER_TPL, int SCATTER_NT, bool EXCHANGE>
 __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
                                                       int T, int H, int W, RasterScratch L)
 {
+    // fragment exchange of one wave: exclusive prefix of the lanes' fragment counts, their coverage masks and triangle records
+    __shared__ int s_pref[EXCHANGE ? SCATTER_NT / 64 : 1][EXCHANGE ? 64 : 1];
+    __shared__ scatter_mask_t s_mask[EXCHANGE ? SCATTER_NT / 64 : 1][EXCHANGE ? 64 : 1];
+    __shared__ float4 s_rec[EXCHANGE ? SCATTER_NT / 64 : 1][EXCHANGE ? 64 : 1][4];  // p0, p1, p2, (px0, py0, nxp, id) as bits
     DDX_TRACE_BEGIN();
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
     unsigned long long sph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -259,13 +318,75 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
     }
     SPH(2);
     unsigned range[SCATTER_TPL];
+    ScatterCov cv[SCATTER_TPL];
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
         range[k] = ~0u;
+        cv[k].mask = 0; cv[k].px0 = 0; cv[k].py0 = 0; cv[k].nxp = 1;
         if (t[k] >= T || !ok[k]) continue;
-        range[k] = scatter_one(pos, V, T, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k]);
-        SPH(3 + k);
+        // (plain variant: triangle by triangle -- coverage of both triangles first and all fragments afterwards measured
+        // 2 us slower on cfg2: more atomics in flight at once make the atomicMin stream slower)
+        range[k] = scatter_one<!EXCHANGE>(pos, V, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k]);
     }
+    SPH(3);
+    // ---- fragments.  A lane owns 0..64 covered centres of its triangle, most lanes none: walked lane by lane the wave runs
+    // max(count) rounds at ~15 % lane utilisation, and one atomic instruction touches one pixel of up to 64 different
+    // triangles.  Instead the wave's fragments are numbered consecutively (prefix sum of the counts) and fragment f goes to
+    // lane f % 64: every lane works, and consecutive lanes take consecutive pixels of the same triangle -- the same zbuf
+    // line, which is what the atomicMin stream is bound by.
+    if (EXCHANGE) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned long long* Z = L.zbuf + (size_t)b * L.zper;
+        const float* P = pos + (size_t)b * V * 4;
+        const PixNdc ndc = L.ndc;  // host-computed (IEEE divisions, same values as make_pixndc)
+#pragma unroll
+        for (int k = 0; k < SCATTER_TPL; ++k) {
+            const int cnt = RASTER_SMALL_PX > 32 ? __popcll(cv[k].mask) : __popc((unsigned)cv[k].mask);
+            if (__ballot(cnt > SCATTER_DIRECT_MAX) == 0ull) {
+                // nobody owns more than a few centres: the exchange would cost more than the idle lanes do
+                scatter_walk(cv[k], P, i0[k], i1[k], i2[k], t[k], Z, ndc, L.zwb);
+                continue;
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const int F = __shfl(incl, 63, 64);
+            if (F == 0) continue;  // (wave-uniform)
+            if (cnt) {  // clip-space vertices only for triangles that own a pixel centre
+                s_rec[wv][lane][0] = ld4(P + (size_t)i0[k] * 4);
+                s_rec[wv][lane][1] = ld4(P + (size_t)i1[k] * 4);
+                s_rec[wv][lane][2] = ld4(P + (size_t)i2[k] * 4);
+                s_rec[wv][lane][3] = make_float4(__int_as_float(cv[k].px0), __int_as_float(cv[k].py0), __int_as_float(cv[k].nxp), __int_as_float(t[k]));
+            }
+            s_pref[wv][lane] = incl - cnt;
+            s_mask[wv][lane] = cv[k].mask;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int base = 0; base < F; base += 64) {
+                const int f = base + lane;
+                if (f < F) {
+                    int Lo = 0;  // largest lane whose exclusive prefix is <= f: the owner of fragment f
+#pragma unroll
+                    for (int st = 32; st > 0; st >>= 1)
+                        if (s_pref[wv][Lo + st] <= f) Lo += st;
+                    const int kb = select_bit(s_mask[wv][Lo], f - s_pref[wv][Lo]);
+                    const float4 p0 = s_rec[wv][Lo][0], p1 = s_rec[wv][Lo][1], p2 = s_rec[wv][Lo][2], q = s_rec[wv][Lo][3];
+                    const int px0 = __float_as_int(q.x), py0 = __float_as_int(q.y), nxp = __float_as_int(q.z), tid_ = __float_as_int(q.w);
+                    const int j = (int)(((float)kb + 0.5f) * __frcp_rn((float)nxp)), i = kb - __mul24(j, nxp);  // kb = j * nxp + i, exact for kb < 64
+                    float zw;
+                    const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
+                    if (pixel_depth(p0, p1, p2, fx, fy, zw))
+                        atomicMin(Z + zaddr(px0 + i, py0 + j, L.zwb), ((unsigned long long)depth_key(zw) << 32) | (unsigned)tid_);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the LDS arrays are reused by the next k)
+        }
+    }
+    SPH(4);
     // LARGE triangles go to the hypothesis' list for the tile pass: one atomic per WAVE that has any (none in the
     // micro-polygon regime), the lanes take consecutive slots.  The order of the list does not matter (atomicMin).
 #pragma unroll
@@ -491,8 +612,8 @@ int raster_run(const float* pos, const int* tri, int B, int V, int T, int H, int
         DDX_HIP(hipMemsetAsync(L.counters, 0, L.zero_bytes, s));
         DDX_HIP(hipMemsetAsync(L.zbuf, 0xFF, L.zbuf_bytes, s));
     }
-    if ((long long)ddx_cdiv(T, 512) * B >= 1024) scatter_kernel<2, 256><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
-    else scatter_kernel<1, 64><<<dim3(ddx_cdiv(T, 64), B), 64, 0, s>>>(pos, tri, V, T, H, W, L);
+    if ((long long)ddx_cdiv(T, 512) * B >= 1024) scatter_kernel<2, 256, false><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+    else scatter_kernel<1, 64, true><<<dim3(ddx_cdiv(T, 64), B), 64, 0, s>>>(pos, tri, V, T, H, W, L);
     if (ev) DDX_HIP(hipEventRecord(ev[1], s));
     compact_big_kernel<<<B + RASTER_BIG_GRID, 256, 0, s>>>(pos, tri, B, V, T, H, W, L);
     DDX_LAUNCH_CHECK();
