@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd"])
+    ap.add_argument("--distance", type=float, default=None, help="camera distance in scene units (default: the config's, 7.5 = the example's 747 mm); "
+                    "smaller = larger object in the frame -- for coverage-sensitivity sweeps, not the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph per iteration (measured ~5 %% slower than plain stream launches here)")
     args = ap.parse_args()
@@ -102,7 +104,7 @@ def main():
     from diffdope_amd import workloads as wl
 
     Bl = wl.CONFIGS[args.config]["B"]  # hypotheses per GPU (weak scaling)
-    w = wl.build(args.config, dev, B=Bl, global_lo=rank * Bl, global_B=Bl * world)
+    w = wl.build(args.config, dev, B=Bl, global_lo=rank * Bl, global_B=Bl * world, distance=args.distance)
     n_it = args.warmup + args.steps
     base = 0.005 if args.optimizer == "adam" else 1.0
     lrs = [base * l / 2.0 for l in wl.lr_schedule(max(n_it - 1, 1), 20, 0.1)][:n_it]

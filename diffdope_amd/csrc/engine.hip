@@ -33,6 +33,7 @@
 // (summed once at engine creation); the third is evaluated per hypothesis and iteration over the
 // compacted list of pixels with seg0 != 0.  Pixels of active tiles add (actual - background) terms.
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <vector>
 #ifdef DDX_TRACE
@@ -45,6 +46,10 @@
 #define NPART 24  // floats per tile partial: 12 dFinal(x,y,w rows) | 4 dMtx row 2 | 4 losses (rgb, depth, mask, edge) | pad
 #define NVALS 20  // of which are used
 #define MAX_ROLES 3
+
+#ifndef SCATTER_EXCHANGE_PER_TRI
+#define SCATTER_EXCHANGE_PER_TRI 1.1  // measured crossover: equal at 0.8-1.0 (cfg2 at 2.6-3.4 % coverage), exchange ahead from 1.3
+#endif
 
 struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_status_ptr exposes
     int overflow;
@@ -1608,6 +1613,18 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         DDX_LAUNCH_CHECK();
         DDX_HIP(hipStreamSynchronize(s));  // (the host vectors above are the copy sources)
         E.L.trisort = E.trisort;
+    }
+    // ---- which scatter variant: expected covered centres per triangle, from the observed segmentation mask (the hypotheses
+    // render the object at about the observed size; front and back faces both produce fragments).  Above about one centre per
+    // triangle the fragment-exchange variant wins (cfg2 at half the distance: 42 -> 37 us, at a third: 115 -> 63 us); below it
+    // costs occupancy (cfg3ref: 44 -> 52 us).  DDX_SCATTER_EXCHANGE=0/1 overrides (tuning).
+    {
+        EngineState hst;
+        DDX_HIP(hipMemcpyAsync(&hst, E.st, sizeof(EngineState), hipMemcpyDeviceToHost, s));
+        DDX_HIP(hipStreamSynchronize(s));
+        const double per_tri = 2.0 * (hst.c_mask / 3.0) / (double)std::max(E.d.T, 1);
+        E.L.scatter_exchange = per_tri > SCATTER_EXCHANGE_PER_TRI ? 1 : 0;
+        if (const char* ov = getenv("DDX_SCATTER_EXCHANGE")) E.L.scatter_exchange = atoi(ov) ? 1 : 0;
     }
     e->setup_done = true;
     return 0;

@@ -21,6 +21,7 @@ struct RasterScratch {
     size_t zper;              // entries per hypothesis = zwb * ceil(H/4) * 16
     int zwb;                  // 4x4 blocks per row = ceil(W/4)
     const int4* trisort;      // [T] or null: the triangles in the processing order of scatter_kernel, {v0, v1, v2, original id}
+    int scatter_exchange;     // 1: expect more than ~1 covered centre per triangle -- scatter_kernel's fragment-exchange variant
                               // (lane j takes record j; ids in zbuf stay the original ones, so the result does not depend on it)
     size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount)
     int ntx, nty, NT;

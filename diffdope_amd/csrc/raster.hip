@@ -65,6 +65,7 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.zper = zper;
     L.zwb = zwb;
     L.trisort = nullptr;
+    L.scatter_exchange = 0;
     L.ntx = ntx; L.nty = nty; L.NT = (int)NT;
     L.ndc.xs = 2.0f / (float)W; L.ndc.xo = 1.0f / (float)W - 1.0f;  // as make_pixndc (host float division is IEEE too)
     L.ndc.ys = 2.0f / (float)H; L.ndc.yo = 1.0f / (float)H - 1.0f;
@@ -134,7 +135,12 @@ struct ScatterCov { scatter_mask_t mask; int px0, py0, nxp; };
 
 // WALK: the lane resolves its covered centres itself, right here (the plain variant of the kernel; kept inside this function,
 // in the scope that computed the mask, because hoisting it out costs 2-3 % of the kernel in the compiler's schedule).
-template <bool WALK>
+// WALK = 2: ... unless one of the lanes that reached this point owns more than SCATTER_DIRECT_MAX centres, in which case they
+// all hand their masks to the wave's fragment exchange.
+#ifndef SCATTER_DIRECT_MAX
+#define SCATTER_DIRECT_MAX 3  // waves in which no lane owns more fragments than this resolve them lane by lane
+#endif
+template <int WALK>
 __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int H, int W, const RasterScratch& L, int b, int t,
                                                 int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c, ScatterCov& cv)
 {
@@ -172,7 +178,12 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                         for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
                             mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
                     }
-                    if (WALK) {
+                    bool walk = WALK == 1;
+                    if (WALK == 2) {
+                        const int cnt = RASTER_SMALL_PX > 32 ? __popcll(mask) : __popc((unsigned)mask);
+                        walk = __ballot(cnt > SCATTER_DIRECT_MAX) == 0ull;  // (over the lanes active here)
+                    }
+                    if (walk) {
                         // one depth evaluation + one atomic per covered centre: the wave walks max(popcount) rounds instead
                         // of max(bbox area), and the clip-space vertices are loaded once, up front
                         if (mask) {
@@ -244,9 +255,6 @@ __device__ __forceinline__ void scatter_walk(const ScatterCov& cv, const float* 
     }
 }
 
-#ifndef SCATTER_DIRECT_MAX
-#define SCATTER_DIRECT_MAX 3  // waves in which no lane owns more fragments than this resolve them lane by lane
-#endif
 // j-th (0-based) set bit of m; j < popcount(m)
 __device__ __forceinline__ int select_bit(scatter_mask_t m, int j)
 {
@@ -270,10 +278,12 @@ __device__ __forceinline__ int select_bit(scatter_mask_t m, int j)
 // would leave most of the chip without a workgroup (a 384-triangle CAD model x 64 hypotheses = 64 workgroups).
 // EXCHANGE: redistribute the fragments over the lanes of the wave (see below) -- pays when triangles own many centres
 // (the small-mesh variant); in the micro-polygon regime of the dense meshes the plain per-lane walk is ~10 % faster.
-template <int SCATTER_TPL, int SCATTER_NT, bool EXCHANGE>
+// MODE 0: plain; 1: exchange (small meshes); 2: plain unless a lane owns more than SCATTER_DIRECT_MAX centres
+template <int SCATTER_TPL, int SCATTER_NT, int MODE>
 __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
                                                       int T, int H, int W, RasterScratch L)
 {
+    constexpr bool EXCHANGE = MODE != 0;
     // fragment exchange of one wave: exclusive prefix of the lanes' fragment counts, their coverage masks and triangle records
     __shared__ int s_pref[EXCHANGE ? SCATTER_NT / 64 : 1][EXCHANGE ? 64 : 1];
     __shared__ scatter_mask_t s_mask[EXCHANGE ? SCATTER_NT / 64 : 1][EXCHANGE ? 64 : 1];
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
         if (t[k] >= T || !ok[k]) continue;
         // (plain variant: triangle by triangle -- coverage of both triangles first and all fragments afterwards measured
         // 2 us slower on cfg2: more atomics in flight at once make the atomicMin stream slower)
-        range[k] = scatter_one<!EXCHANGE>(pos, V, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k]);
+        range[k] = scatter_one<MODE == 0 ? 1 : MODE == 2 ? 2 : 0>(pos, V, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k]);
     }
     SPH(3);
     // ---- fragments.  A lane owns 0..64 covered centres of its triangle, most lanes none: walked lane by lane the wave runs
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < SCATTER_TPL; ++k) {
             const int cnt = RASTER_SMALL_PX > 32 ? __popcll(cv[k].mask) : __popc((unsigned)cv[k].mask);
-            if (__ballot(cnt > SCATTER_DIRECT_MAX) == 0ull) {
+            if (MODE == 1 && __ballot(cnt > SCATTER_DIRECT_MAX) == 0ull) {
                 // nobody owns more than a few centres: the exchange would cost more than the idle lanes do
                 scatter_walk(cv[k], P, i0[k], i1[k], i2[k], t[k], Z, ndc, L.zwb);
                 continue;
@@ -612,8 +622,13 @@ int raster_run(const float* pos, const int* tri, int B, int V, int T, int H, int
         DDX_HIP(hipMemsetAsync(L.counters, 0, L.zero_bytes, s));
         DDX_HIP(hipMemsetAsync(L.zbuf, 0xFF, L.zbuf_bytes, s));
     }
-    if ((long long)ddx_cdiv(T, 512) * B >= 1024) scatter_kernel<2, 256, false><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
-    else scatter_kernel<1, 64, true><<<dim3(ddx_cdiv(T, 64), B), 64, 0, s>>>(pos, tri, V, T, H, W, L);
+    if ((long long)ddx_cdiv(T, 512) * B >= 1024) {
+        // dense meshes: the plain kernel in the micro-polygon regime (64 VGPRs, no LDS); the hybrid (72 VGPRs, 19 KB LDS: 4-20 %
+        // slower there) when the caller expects triangles to own more than about one pixel centre each
+        if (L.scatter_exchange) scatter_kernel<2, 256, 2><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+        else scatter_kernel<2, 256, 0><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+    }
+    else scatter_kernel<1, 64, 1><<<dim3(ddx_cdiv(T, 64), B), 64, 0, s>>>(pos, tri, V, T, H, W, L);
     if (ev) DDX_HIP(hipEventRecord(ev[1], s));
     compact_big_kernel<<<B + RASTER_BIG_GRID, 256, 0, s>>>(pos, tri, B, V, T, H, W, L);
     DDX_LAUNCH_CHECK();

@@ -353,3 +353,34 @@ def test_engine_result_does_not_depend_on_the_order_of_the_mesh_file():
     torch.cuda.synchronize()
     np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(g0.abs().max()))
+
+
+def test_engine_close_up_dense_mesh_scatter_variants_agree(monkeypatch):
+    """A dense mesh seen from close (about two covered pixel centres per triangle): the engine picks the fragment-exchange
+    variant of scatter_kernel from the observed segmentation mask.  Forced on, forced off and chosen automatically the
+    optimisation is bit-identical (visibility is an order-independent atomicMin of exact keys), and iteration 0 of one
+    hypothesis matches the oracle."""
+    weights = dict(rgb=0.7, depth=1.0, mask=1.0)
+    sc = make_scene(80, 128, 480, 640, B=32, dist=3.0, textured=True, tex_size=256)
+    per_tri = 2.0 * float(sc["gt"]["segmentation"][..., 0].sum()) / sc["tri"].shape[0]
+    assert per_tri > 1.5
+    lrs = [0.2, 0.15, 0.1]
+    runs = {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("DDX_SCATTER_EXCHANGE", raising=False)
+        else:
+            monkeypatch.setenv("DDX_SCATTER_EXCHANGE", mode)
+        eng, p = _engine(sc, weights, lrs)
+        eng.run()
+        torch.cuda.synchronize()
+        eng.check()
+        runs[mode] = (eng.losses().cpu().numpy().copy(), p.cpu().numpy().copy())
+    for mode in ("1", None):
+        assert np.array_equal(runs["0"][0], runs[mode][0]) and np.array_equal(runs["0"][1], runs[mode][1])
+    R = sc["oracle"]
+    R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
+    total, logs, g_ref, _ = R.loss_and_grad(sc["params"][:, 5:6], sc["lr_mult"][5:6], global_B=32)
+    for i, key in enumerate(KEYS):
+        if key in logs:
+            np.testing.assert_allclose(runs[None][0][0, i, 5], logs[key][0], rtol=5e-5, atol=1e-7)
