@@ -71,6 +71,32 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N])
     }
 }
 
+// The same sums, left in the lanes of the LAST row only (lanes 48..63; other lanes hold partial sums): the two cross-row
+// levels as DPP row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- 6 VALU ops per value
+// where the readlane version above spends 4 + 4 readlanes + 3 adds + the SGPR->VGPR moves.  Association:
+// (r3 + r2) + (r1 + r0) with the rows summed by the same four in-row steps.
+template <int N>
+__device__ __forceinline__ void wave_sum_n_lastrow(float (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0xB1);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0x4E);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0x141);  // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) DDX_DPP_STEP(v[i], 0x140);  // row_mirror
+    // (through the builtin a masked row broadcast becomes v_mov 0 / v_mov_dpp / v_add: the combiner only folds full row masks.
+    // In-place v_add_f32_dpp leaves the masked-off rows untouched, which is the wanted result.  s_nop 1: a DPP read needs
+    // two wait states after the VALU write of its source, and the hazard recogniser does not look into asm.)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x142, 0xA, 0xF, false));
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x143, 0xC, 0xF, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

@@ -87,6 +87,8 @@ struct EngineDev {
     int* vnew;        // [V] old vertex id -> sorted id
     int* vold;        // [V] sorted id -> old vertex id
     int4* trisort;    // [T] {v0,v1,v2,id}: triangles in Morton order of their object-space centroids (scatter_kernel's processing order)
+    float4* crec;     // [T,4] (textured) or [T,5] (vertex colours): what the colour role needs of a covered triangle, in ONE
+                      // record fetched by triangle id: object-space positions of the 3 vertices (9), then uv (6) or colours (9)
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     EngineState* st;
     int st_role;      // shade role that advances the iteration counter (= roles[0])
@@ -131,6 +133,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
     const size_t o_perm = carve((size_t)d.T * sizeof(int4));
+    const size_t o_crec = carve((size_t)d.T * 5 * sizeof(float4));
     const size_t o_spos = carve((size_t)d.V * 3 * sizeof(float));
     const size_t o_suv = carve((size_t)d.V * 2 * sizeof(float));
     const size_t o_scol = carve((size_t)d.V * 3 * sizeof(float));
@@ -153,6 +156,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.seglist = (float2*)(p + o_seg);
     E.trirec = (int4*)(p + o_rec);
     E.trisort = (int4*)(p + o_perm);
+    E.crec = (float4*)(p + o_crec);
     E.spos = (float*)(p + o_spos);
     E.suv = (float*)(p + o_suv);
     E.scol = (float*)(p + o_scol);
@@ -390,6 +394,17 @@ __device__ __forceinline__ void acc_vertex(PixAcc& A, const float* __restrict__ 
     A.dF[8] = __fmaf_rn(gw, x, A.dF[8]); A.dF[9] = __fmaf_rn(gw, y, A.dF[9]); A.dF[10] = __fmaf_rn(gw, z, A.dF[10]); A.dF[11] += gw;
 }
 
+// rows x, y, w of final . [p; 1], accumulated over k = 0..3 from zero like the matrix core does (xfm_vertex): same bits
+__device__ __forceinline__ float4 clip_xyw(const float (&Fx)[4], const float (&Fy)[4], const float (&Fw)[4], float x, float y, float z)
+{
+    float4 o;
+    o.x = __fmaf_rn(Fx[3], 1.0f, __fmaf_rn(Fx[2], z, __fmaf_rn(Fx[1], y, __fmaf_rn(Fx[0], x, 0.f))));
+    o.y = __fmaf_rn(Fy[3], 1.0f, __fmaf_rn(Fy[2], z, __fmaf_rn(Fy[1], y, __fmaf_rn(Fy[0], x, 0.f))));
+    o.z = 0.f;  // (unused by the colour role)
+    o.w = __fmaf_rn(Fw[3], 1.0f, __fmaf_rn(Fw[2], z, __fmaf_rn(Fw[1], y, __fmaf_rn(Fw[0], x, 0.f))));
+    return o;
+}
+
 __device__ __forceinline__ void acc_vertex_regs(PixAcc& A, float x, float y, float z, float gx, float gy, float gw)
 {
     A.dF[0] = __fmaf_rn(gx, x, A.dF[0]); A.dF[1] = __fmaf_rn(gx, y, A.dF[1]); A.dF[2] = __fmaf_rn(gx, z, A.dF[2]); A.dF[3] += gx;
@@ -603,6 +618,13 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     // the first list entry is requested together with the count (one dependent round trip less; an entry beyond
     // the count is stale and unused)
     const int txy_first = k_first < L.NT ? L.active[(size_t)b * L.NT + k_first] : 0;
+    // colour role: rows x, y, w of this hypothesis' final = proj . mtx (uniform: scalar loads, requested with the tile list)
+    float Fx[4] = {0.f, 0.f, 0.f, 0.f}, Fy[4] = {0.f, 0.f, 0.f, 0.f}, Fw[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ROLE == 0) {
+        const float* Fm = E.mats + ((size_t)(E.st->it_next & 1) * d.B + b) * 32 + 16;  // it_next = this iteration (stable here)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { Fx[c] = Fm[c]; Fy[c] = Fm[4 + c]; Fw[c] = Fm[12 + c]; }
+    }
     for (int k = k_first; k < n_tiles; k += k_step) {
         const int txy = k == k_first ? txy_first : L.active[(size_t)b * L.NT + k];
         DDX_PHASE(0);
@@ -666,23 +688,18 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
         if (ROLE == 0 && id > 0) {
             const int t = id - 1;
-            const int v0 = tri[t * 3 + 0], v1 = tri[t * 3 + 1], v2 = tri[t * 3 + 2];
+            // ONE record per covered triangle, fetched by id: object-space positions + uv (or colours) of its vertices.  The
+            // clip-space vertices are recomputed from the hypothesis' matrix (uniform, in SGPRs) with the k-ordered fma chain
+            // the matrix core ran in the transform kernel -- the same bits -- instead of being gathered: the chain
+            // zbuf -> indices -> vertices -> texels loses a level, and 18 gathers become 4 loads of a static, shared table.
+            const float4* R = E.crec + (size_t)t * (d.Th > 0 ? 4 : 5);
+            const float4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
+            float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(d.Th > 0)) r4 = R[4];
             DDX_PHASE(2);
-            const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
-            // object-space positions (depth term, and the contraction of the vertex gradients at the end): requested
-            // with the clip vertices, not behind the texture fetch
-            const float x0 = pos[(size_t)v0 * 3], y0 = pos[(size_t)v0 * 3 + 1], z0 = pos[(size_t)v0 * 3 + 2];
-            const float x1 = pos[(size_t)v1 * 3], y1 = pos[(size_t)v1 * 3 + 1], z1 = pos[(size_t)v1 * 3 + 2];
-            const float x2 = pos[(size_t)v2 * 3], y2 = pos[(size_t)v2 * 3 + 1], z2 = pos[(size_t)v2 * 3 + 2];
-            // ... and the texture coordinates: behind `if (use_rgb && textured)` below they would only be requested
-            // after the clip vertices have arrived (the compiler does not speculate loads across the branch)
-            float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f, a2x = 0.f, a2y = 0.f;
-            if ((d.use_rgb || NR == 3) && d.Th > 0) {
-                const float* uv = E.suv;
-                a0x = uv[(size_t)v0 * 2]; a0y = uv[(size_t)v0 * 2 + 1];
-                a1x = uv[(size_t)v1 * 2]; a1y = uv[(size_t)v1 * 2 + 1];
-                a2x = uv[(size_t)v2 * 2]; a2y = uv[(size_t)v2 * 2 + 1];
-            }
+            const float x0 = r0.x, y0 = r0.y, z0 = r0.z, x1 = r0.w, y1 = r1.x, z1 = r1.y, x2 = r1.z, y2 = r1.w, z2 = r2.x;
+            const float a0x = r2.y, a0y = r2.z, a1x = r2.w, a1y = r3.x, a2x = r3.y, a2y = r3.z;  // (textured)
+            const float4 p0 = clip_xyw(Fx, Fy, Fw, x0, y0, z0), p1 = clip_xyw(Fx, Fy, Fw, x1, y1, z1), p2 = clip_xyw(Fx, Fy, Fw, x2, y2, z2);
             DDX_PHASE(3);
             Bary bc;
             pixel_bary(p0, p1, p2, px, py, H, W, bc);
@@ -716,10 +733,10 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     }
                     DDX_PHASE(4);
                 } else {
-                    const float* vc = E.scol;
+                    const float k0[3] = {r2.y, r2.z, r2.w}, k1[3] = {r3.x, r3.y, r3.z}, k2[3] = {r3.w, r4.x, r4.y};
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const float c0 = vc[(size_t)v0 * 3 + c], c1 = vc[(size_t)v1 * 3 + c], c2 = vc[(size_t)v2 * 3 + c];
+                        const float c0 = k0[c], c1 = k1[c], c2 = k2[c];
                         col[c] = __fmaf_rn(w2, c2, __fmaf_rn(v, c1, u * c0));
                         dcu[c] = c0 - c2;
                         dcv[c] = c1 - c2;
@@ -897,17 +914,23 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) vals[12 + i] = A.dM2[i];
         vals[16] = A.L[0]; vals[17] = A.L[1]; vals[18] = A.L[2]; vals[19] = A.L[3];
-        float mine = 0.f;
+        float mine = 0.f, mine2 = 0.f;
         bool nz = false;
 #pragma unroll
         for (int i = 0; i < NV; ++i) nz |= vals[i] != 0.f;
         if (__ballot(nz) != 0ull) {  // e.g. mask role on an interior quadrant: every term is exactly zero
-            wave_sum_n(vals);  // same association as wave_sum per value: bit-identical results
+            wave_sum_n_lastrow(vals);  // totals in lanes 48..63
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (lane == i) mine = vals[i];
+            for (int i = 0; i < 16; ++i)
+                if (lane == 48 + i) mine = vals[i];
+#pragma unroll
+            for (int i = 16; i < NV; ++i)
+                if (lane == 32 + i) mine2 = vals[i];
         }
-        if (lane < NPART) part[lane] = mine;
+        if (lane >= 48) {  // lanes 48..63 write values 0..15, lanes 48..55 the slots 16..23 (values 16..NV-1, then zero padding)
+            part[lane - 48] = mine;
+            if (lane < 56) part[lane - 32] = mine2;
+        }
         DDX_PHASE(6);
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
         if (ROLE == DDX_PHASE_ROLE && tid == 0 && k == k_first) {
@@ -1057,7 +1080,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
         }
         // the quadrant's loss terms: lanes hold up to 2 terms each (own_loss already restricted to owned pixels)
         vals[19] = own_loss;
-        float mine = 0.f;
+        float mine = 0.f, mine2 = 0.f;
         bool nz = false;
 #pragma unroll
         for (int i = 0; i < NVALS; ++i) nz |= vals[i] != 0.f;
@@ -1066,13 +1089,16 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
 #pragma unroll
             for (int i = 0; i < 12; ++i) red[i] = vals[i];
             red[12] = vals[19];
-            wave_sum_n(red);
+            wave_sum_n_lastrow(red);  // totals in lanes 48..63
 #pragma unroll
             for (int i = 0; i < 12; ++i)
-                if (lane == i) mine = red[i];
-            if (lane == 19) mine = red[12];
+                if (lane == 48 + i) mine = red[i];
+            if (lane == 32 + 19) mine2 = red[12];
         }
-        if (lane < NPART) part[lane] = mine;
+        if (lane >= 48) {  // slots 0..15 from lanes 48..63, slots 16..23 from lanes 48..55
+            part[lane - 48] = mine;
+            if (lane < 56) part[lane - 32] = mine2;
+        }
         wave_lds_sync();  // (the LDS arrays are reused by the next tile)
     }
 }
@@ -1535,6 +1561,27 @@ __global__ void remap_triangles_kernel(EngineDev E)
     E.stri[t * 3 + 0] = v0; E.stri[t * 3 + 1] = v1; E.stri[t * 3 + 2] = v2;
     E.trirec[t * 2 + 0] = make_int4(v0, v1, v2, rm(E.b.opp[t * 3 + 0]));
     E.trirec[t * 2 + 1] = make_int4(rm(E.b.opp[t * 3 + 1]), rm(E.b.opp[t * 3 + 2]), 0, 0);
+    // colour-role record (remap_vertices_kernel ran before this launch)
+    float r[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) r[i] = 0.f;
+    const int vv[3] = {v0, v1, v2};
+    const bool ok = (unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V;
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[k * 3 + c] = E.spos[(size_t)vv[k] * 3 + c];
+            if (E.d.Th > 0) {
+                if (E.b.uv) { r[9 + k * 2] = E.suv[(size_t)vv[k] * 2]; r[10 + k * 2] = E.suv[(size_t)vv[k] * 2 + 1]; }
+            } else if (E.b.vtx_color) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) r[9 + k * 3 + c] = E.scol[(size_t)vv[k] * 3 + c];
+            }
+        }
+    }
+    const int rs = E.d.Th > 0 ? 4 : 5;
+    for (int i = 0; i < rs; ++i) E.crec[(size_t)t * rs + i] = make_float4(r[i * 4], r[i * 4 + 1], r[i * 4 + 2], r[i * 4 + 3]);
 }
 
 static int engine_setup(ddx_engine* e, hipStream_t s)

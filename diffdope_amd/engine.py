@@ -52,7 +52,7 @@ class RefineEngine:
         f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
         self.pos, self.proj = f32(pos), f32(proj)
         self.tri = tri.to(device=dev, dtype=torch.int32).contiguous()
-        self.opp = build_topology(self.tri)
+        self.opp = build_topology(self.tri, cached=False)  # (once per engine: no need for the op-level cache)
         self.uv, self.tex, self.vtx_color = f32(uv), f32(tex), f32(vtx_color)
         if self.tex is not None and self.tex.dim() == 4:
             self.tex = self.tex[0].contiguous()

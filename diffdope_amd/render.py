@@ -215,19 +215,36 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="aut
 _topology_cache = {}
 
 
-def build_topology(tri):
-    """opp [T,3] int32 on tri's device (ddx_topology_build on the host, cached per index buffer)."""
-    key = (tri.data_ptr(), tuple(tri.shape), str(tri.device), tri._version)
-    hit = _topology_cache.get(key)
-    if hit is not None:
-        return hit
+def _tri_fingerprint(tri):
+    """Two independent 64-bit position-weighted sums of the index buffer, computed on its device (one small
+    reduction + one host read): what a cache hit is validated with."""
+    t = tri.reshape(-1).to(torch.int64)
+    i = torch.arange(t.numel(), device=t.device, dtype=torch.int64)
+    a = (t * (i * 2654435761 % 4294967291 + 1)).sum()
+    b = ((t + 40503) * ((i ^ (i >> 5)) * 2246822519 % 4294967279 + 7)).sum()
+    return tuple(torch.stack([a, b]).tolist())
+
+
+def build_topology(tri, cached=True):
+    """opp [T,3] int32 on tri's device (ddx_topology_build on the host).  cached=True keeps the result per index
+    buffer; a hit is validated against a fingerprint of the CONTENTS, because the address alone says nothing: the
+    caching allocator hands the block of a freed index buffer to the next one of the same size (a different mesh
+    with the same triangle count would silently get the old mesh's edges)."""
+    fp = key = None
+    if cached:
+        key = (tri.data_ptr(), tuple(tri.shape), str(tri.device))
+        fp = _tri_fingerprint(tri)
+        hit = _topology_cache.get(key)
+        if hit is not None and hit[0] == fp:
+            return hit[1]
     tri_h = np.ascontiguousarray(tri.detach().cpu().numpy().astype(np.int32))
     opp_h = np.empty_like(tri_h)
     _lib.check(_lib.load().ddx_topology_build(tri_h.ctypes.data, tri_h.shape[0], opp_h.ctypes.data), "ddx_topology_build")
     opp = torch.from_numpy(opp_h).to(tri.device)
-    if len(_topology_cache) > 16:
-        _topology_cache.clear()
-    _topology_cache[key] = opp
+    if cached:
+        if len(_topology_cache) > 16:
+            _topology_cache.clear()
+        _topology_cache[key] = (fp, opp)
     return opp
 
 

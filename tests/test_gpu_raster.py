@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from diffdope_amd import synthetic as syn
 from tests.scenes import clip_from_pixels, make_scene
 
 pytestmark = pytest.mark.gpu
@@ -211,3 +212,31 @@ def test_topology_matches_oracle():
     sc = make_scene(12, 16, 32, 32, B=1)
     opp = build_topology(T(sc["tri"])).cpu().numpy()
     assert np.array_equal(opp, orc.build_opposite(sc["tri"]))
+
+
+def test_topology_cache_is_validated_by_content_not_by_address():
+    """The op-level antialias keeps the edge topology per index buffer.  A freed index buffer's block is handed to the
+    next tensor of the same size by the caching allocator: a different mesh with the same triangle count at the same
+    address must not get the old mesh's edges (regression: the cache used to be keyed by address and shape only)."""
+    import gc
+
+    from diffdope_amd.render import build_topology
+
+    rng = np.random.RandomState(0)
+    pos, tri, _ = syn.blob_mesh(12, 16, seed=0)
+    perm = rng.permutation(tri.shape[0])
+    tri_b = np.ascontiguousarray(tri[perm][:, [1, 2, 0]])
+    a = torch.tensor(tri, dtype=torch.int32, device="cuda")
+    opp_a = build_topology(a).clone()
+    assert torch.equal(opp_a, build_topology(a, cached=False))
+    ptr = a.data_ptr()
+    del a
+    gc.collect()
+    b = torch.tensor(tri_b, dtype=torch.int32, device="cuda")  # (normally the very same block)
+    opp_b = build_topology(b)
+    assert torch.equal(opp_b, build_topology(b, cached=False))
+    if b.data_ptr() == ptr:
+        assert not torch.equal(opp_a, opp_b)
+    # in-place edits of the same tensor are seen too
+    b[:] = torch.tensor(tri, dtype=torch.int32, device="cuda")
+    assert torch.equal(build_topology(b), opp_a)
