@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
 {
     DDX_TRACE_BEGIN();
     const int z = blockIdx.z;
-    const int role = EDGE ? (z == 0 ? E.roles[0] : (z == 1 ? E.roles[1] : E.roles[2])) : (E.n_roles == 2 ? z : E.st_role);
+    const int role = z == 0 ? E.roles[0] : E.roles[1];
     __shared__ float s_pool[WAVES_PER_TILE][12 * 64];
     float* pool = s_pool[threadIdx.x >> 6];
     if (role == 0) shade_body<0, EDGE ? 3 : 2>(E, pool);
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
 }
 
 // ---------------------------------------------------------------------------------------------
-// update + next iteration's transform, one launch: grid (UPD_SLICES, B).
+// update + next iteration's transform, one launch: grid (B, UPD_SLICES).
 // Every workgroup of hypothesis b redundantly reduces b's quadrant partials (a few KB from L2, fixed order),
 // runs the proj^T / quaternion chain and the optimiser step in LDS, and then transforms ITS slice of the
 // vertices with the NEW pose on the matrix core (as pose_xfm_kernel), so the next iteration starts at the
@@ -1118,7 +1118,9 @@ template <int NR>
 __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 {
     const ddx_engine_desc& d = E.d;
-    const int b = blockIdx.y, B = d.B, slice = blockIdx.x, V = d.V;
+    // grid (B, slices): hypothesis b's workgroups get linear ids b + B * slice, i.e. (B a multiple of 8) the XCD b % 8 that ran
+    // b's shade workgroups and holds their partials in its L2 (slice-major was measured 1-3 % slower on cfg3, equal elsewhere)
+    const int b = blockIdx.x, B = d.B, slice = blockIdx.y, V = d.V;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float red[4][NPART];
     __shared__ float sums[NPART];
@@ -1453,8 +1455,9 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
         edge_kernel<<<ge, 256, 0, s>>>(E);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
-    if (d.use_edge) update_xfm_kernel<3><<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
-    else update_xfm_kernel<2><<<dim3(UPD_SLICES, d.B), 256, 0, s>>>(E);
+#define UPD_GRID dim3(d.B, UPD_SLICES)
+    if (d.use_edge) update_xfm_kernel<3><<<UPD_GRID, 256, 0, s>>>(E);
+    else update_xfm_kernel<2><<<UPD_GRID, 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
     DDX_LAUNCH_CHECK();
     return 0;
@@ -1504,7 +1507,10 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         E.n_roles = 0;
         E.role_mask = 0;
         for (int r = 0; r < MAX_ROLES; ++r) E.roles[r] = 0;
-        for (int r = 0; r < MAX_ROLES; ++r)
+        // grid z order: the MASK role first.  Workgroups are dispatched in linear-id order, so the role at z = 0 takes the cold
+        // misses on zbuf / observed images; the colour role is the long one (7 us per tile against 4) and now starts on lines
+        // the mask role's halo reads already pulled into the XCD's L2 (cfg2 shade 22.0 -> 20.3 us)
+        for (int r = MAX_ROLES - 1; r >= 0; --r)
             if (on[r]) {
                 E.role_mask |= 1 << r;
                 E.roles[E.n_roles++] = r;
