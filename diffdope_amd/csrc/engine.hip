@@ -68,7 +68,7 @@ struct EngineDev {
     ddx_engine_desc d;
     ddx_engine_buffers b;
     RasterScratch L;
-    float* clip;      // [B,V,4]
+    float* clip;      // [B,V,4] (rasteriser and mask role; the colour role recomputes its vertices from crec)
     float* mats;      // [2][B,2,16]: mtx | final, by iteration parity
     float* params2;   // [2][7,B]: the parameters, by iteration parity (b.params is the user-visible copy)
     float* partials;  // [B*NT*4*NR, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*NR + role, NR = 2 (3 with the edge role)
@@ -95,6 +95,8 @@ struct EngineDev {
     int n_roles;      // enabled shade roles (grid z of shade_kernel): 0 colour+depth, 1 antialiased mask, 2 edge
     int roles[MAX_ROLES];    // grid z -> role
     int role_mask;           // bit r set = role r runs
+    int s_shade, s_edge;     // slices per hypothesis of shade_kernel / edge_kernel (grid y)
+    int pslices;             // rows of the partial table per hypothesis: max(s_shade, s_edge) slices
     float* eval_grad;        // [7,B] or null.  Non-null = evaluation pass (ddx_engine_eval): d loss / d params and the
     float* eval_loss;        // [4,B] losses are written here, no optimiser step, no transform for a next iteration
 #ifdef DDX_TRACE
@@ -141,7 +143,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_vnew = carve((size_t)d.V * sizeof(int));
     const size_t o_vold = carve((size_t)d.V * sizeof(int));
     const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
-    const size_t o_part = carve((size_t)d.B * ntx * nty * 4 * MAX_ROLES * NPART * sizeof(float));  // per 8x8 quadrant and shade role
+    const size_t o_part = carve((size_t)d.B * 64 * 4 * MAX_ROLES * NPART * sizeof(float));  // per (slice <= 64, wave, role)
     const size_t o_edge = carve(d.use_edge ? (size_t)d.H * d.W * sizeof(float2) : 0);
     const size_t o_lum = carve(d.use_edge ? (size_t)d.B * d.H * d.W * sizeof(float) : 0);
     const size_t o_ubuf = carve(d.use_edge ? (size_t)d.B * d.H * d.W * 12 * sizeof(float) : 0);
@@ -625,6 +627,16 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) { Fx[c] = Fm[c]; Fy[c] = Fm[4 + c]; Fw[c] = Fm[12 + c]; }
     }
+    // every lane accumulates its pixels' terms over ALL the tiles of the workgroup; one wave reduction and one partial row
+    // per (slice, wave, role) at the end, instead of one per tile (update_xfm_kernel sums min(slices, tiles) rows)
+    PixAcc A;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) A.dF[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A.dM2[i] = 0.f;
+    A.L[0] = A.L[1] = A.L[2] = A.L[3] = 0.f;
+    const float lrb = E.b.lr_mult[b];
+    const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
     for (int k = k_first; k < n_tiles; k += k_step) {
         const int txy = k == k_first ? txy_first : L.active[(size_t)b * L.NT + k];
         DDX_PHASE(0);
@@ -633,8 +645,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
         const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * L.zper;
-        // stored by POSITION k in the hypothesis' ordered active list: update_xfm_kernel reads one contiguous run
-        float* part = E.partials + ((((size_t)b * L.NT + k) * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
         const int lx = lane % QUAD, ly = lane / QUAD;
         const int px = qx + lx, py = qy + ly;
         const int hidx = (ly + 1) * QH + lx + 1;
@@ -651,10 +661,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 const unsigned long long key = zb[zaddr(px, py, L.zwb)];
                 id = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
             }
-            if (__ballot(id > 0) == 0ull) {  // nothing drawn in this quadrant: only background terms
-                if (lane < NPART) part[lane] = 0.f;
-                continue;
-            }
+            if (__ballot(id > 0) == 0ull) continue;  // nothing drawn in this quadrant: only background terms
         } else {
             // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
             bool anycov = false;
@@ -670,22 +677,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 anycov |= v > 0;
             }
             s_m[wave][lane] = 0.f;
-            if (__ballot(anycov) == 0ull) {  // nothing drawn in or next to this quadrant: only background terms
-                if (lane < NPART) part[lane] = 0.f;
-                continue;
-            }
+            if (__ballot(anycov) == 0ull) continue;  // nothing drawn in or next to this quadrant: only background terms
             wave_lds_sync();
             id = ids[hidx];
         }
         DDX_PHASE(1);
-        PixAcc A;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) A.dF[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) A.dM2[i] = 0.f;
-        A.L[0] = A.L[1] = A.L[2] = A.L[3] = 0.f;
-        const float lrb = E.b.lr_mult[b];
-        const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
         if (ROLE == 0 && id > 0) {
             const int t = id - 1;
             // ONE record per covered triangle, fetched by id: object-space positions + uv (or colours) of its vertices.  The
@@ -906,7 +902,21 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             }
             wave_lds_sync();
         }
-        // ---- wave reduction -> one partial per quadrant (fixed order: bit-reproducible)
+        DDX_PHASE(6);
+#if defined(DDX_TRACE) && defined(DDX_PHASES)
+        if (ROLE == DDX_PHASE_ROLE && tid == 0 && k == k_first) {
+            const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+            if (wg < 4096) {
+                unsigned long long* q = E.trace + ((size_t)1 * 8192) * 4 + wg * 8;  // kernel slot 1 (unused), 8 stamps per workgroup
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = ph[i];
+            }
+        }
+#endif
+    }
+    if (k_first < n_tiles) {
+        // ---- wave reduction -> one partial row per (slice, wave, role) (fixed order: bit-reproducible)
+        float* part = E.partials + ((((size_t)b * E.pslices + blockIdx.y) * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
         constexpr int NV = NVALS - 1;  // (the 20th value, the edge loss, belongs to edge_kernel)
         float vals[NVALS];
 #pragma unroll
@@ -931,17 +941,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             part[lane - 48] = mine;
             if (lane < 56) part[lane - 32] = mine2;
         }
-        DDX_PHASE(6);
-#if defined(DDX_TRACE) && defined(DDX_PHASES)
-        if (ROLE == DDX_PHASE_ROLE && tid == 0 && k == k_first) {
-            const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-            if (wg < 4096) {
-                unsigned long long* q = E.trace + ((size_t)1 * 8192) * 4 + wg * 8;  // kernel slot 1 (unused), 8 stamps per workgroup
-#pragma unroll
-                for (int i = 0; i < 8; ++i) q[i] = ph[i];
-            }
-        }
-#endif
     }
 }
 
@@ -984,10 +983,14 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
     const float* __restrict__ lumb = E.lumbuf + (size_t)b * H * W;
     const float lrb = E.b.lr_mult[b];
     const float kc = d.w_edge * lrb * __fdiv_rn(1.0f, (float)d.B_global) / (2.0f * (float)H * (float)W) * 0.125f;
+    // accumulated over the workgroup's tiles, reduced once at the end (as shade_kernel): 12 d loss / d final + the loss.  Per-lane
+    // accumulators in LDS (13 registers held across the tile loop cost two waves per SIMD): slot [i][tid], conflict-free
+    __shared__ float s_acc[13][256];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) s_acc[i][tid] = 0.f;
     for (int k = blockIdx.y; k < n_tiles; k += gridDim.y) {
         const int txy = L.active[(size_t)b * L.NT + k];
         const int qx = (txy & 0xffff) * DDX_TILE + (wave & 1) * QUAD, qy = (txy >> 16) * DDX_TILE + (wave >> 1) * QUAD;
-        float* part = E.partials + ((((size_t)b * L.NT + k) * WAVES_PER_TILE + wave) * 3 + 2) * NPART;
         // ---- everything this quadrant needs is requested up front: the 12x12 (zbuf, lum) halo in 3 rounds of lanes, the
         // observed-image gradients of the 10x10 loss terms in 2, U of the owned pixel
         const int lx = lane % QUAD, ly = lane / QUAD;
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
             any |= cov[r];
         }
         if (__ballot(any) == 0ull) {  // nothing drawn in or around this quadrant: only background terms
-            if (lane < NPART) part[lane] = 0.f;
+            wave_lds_sync();  // (s_l is rewritten by the next tile)
             continue;
         }
         wave_lds_sync();
@@ -1060,9 +1063,6 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
         }
         wave_lds_sync();
         // ---- owned pixel: d loss / d lum from the 3x3 terms around it, times U
-        float vals[NVALS];
-#pragma unroll
-        for (int i = 0; i < NVALS; ++i) vals[i] = 0.f;
         if (own_cov) {
             float g = 0.f;
 #pragma unroll
@@ -1074,32 +1074,32 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
                     g = __fmaf_rn(s_cx[wave][n], (float)(dx * (2 - (dy < 0 ? -dy : dy))), g);
                     g = __fmaf_rn(s_cy[wave][n], (float)(dy * (2 - (dx < 0 ? -dx : dx))), g);
                 }
-            vals[0] = g * u0.x; vals[1] = g * u0.y; vals[2] = g * u0.z; vals[3] = g * u0.w;
-            vals[4] = g * u1.x; vals[5] = g * u1.y; vals[6] = g * u1.z; vals[7] = g * u1.w;
-            vals[8] = g * u2.x; vals[9] = g * u2.y; vals[10] = g * u2.z; vals[11] = g * u2.w;
+            const float uu[12] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s_acc[i][tid] += g * uu[i];  // (own slot: plain read-modify-write)
         }
         // the quadrant's loss terms: lanes hold up to 2 terms each (own_loss already restricted to owned pixels)
-        vals[19] = own_loss;
+        if (own_loss != 0.f) s_acc[12][tid] += own_loss;
+        wave_lds_sync();  // (the LDS arrays are reused by the next tile)
+    }
+    if ((int)blockIdx.y < n_tiles) {
+        float* part = E.partials + ((((size_t)b * E.pslices + blockIdx.y) * WAVES_PER_TILE + wave) * 3 + 2) * NPART;
         float mine = 0.f, mine2 = 0.f;
+        float acc[13];
         bool nz = false;
 #pragma unroll
-        for (int i = 0; i < NVALS; ++i) nz |= vals[i] != 0.f;
+        for (int i = 0; i < 13; ++i) { acc[i] = s_acc[i][tid]; nz |= acc[i] != 0.f; }
         if (__ballot(nz) != 0ull) {
-            float red[13];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) red[i] = vals[i];
-            red[12] = vals[19];
-            wave_sum_n_lastrow(red);  // totals in lanes 48..63
+            wave_sum_n_lastrow(acc);  // totals in lanes 48..63
 #pragma unroll
             for (int i = 0; i < 12; ++i)
-                if (lane == 48 + i) mine = red[i];
-            if (lane == 32 + 19) mine2 = red[12];
+                if (lane == 48 + i) mine = acc[i];
+            if (lane == 32 + 19) mine2 = acc[12];
         }
         if (lane >= 48) {  // slots 0..15 from lanes 48..63, slots 16..23 from lanes 48..55
             part[lane - 48] = mine;
             if (lane < 56) part[lane - 32] = mine2;
         }
-        wave_lds_sync();  // (the LDS arrays are reused by the next tile)
     }
 }
 
@@ -1154,12 +1154,17 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     // kernel is a chain of dependent round trips; these three would otherwise each add one.
     constexpr int PER = 4 * NR;  // partial slots per tile
     const int rmask = E.role_mask;
-    const float* pbase = E.partials + (size_t)b * NT * PER * NPART + j;
-    float v0[UPD_SPEC];  // slots grp, grp + 8, ...: the first UPD_SPEC x 8 slots (24 tiles with two roles) in ONE round trip
+    // partial rows of hypothesis b: (slice, wave, role), written by the workgroups of shade_kernel / edge_kernel that had at
+    // least one tile (slice < min(slices of that kernel, tiles)); rows beyond are stale and masked below
+    const int PS = E.pslices;
+    const float* pbase = E.partials + (size_t)b * PS * PER * NPART + j;
+    const int smax_r[3] = {E.s_shade, E.s_shade, E.s_edge};
+    float v0[UPD_SPEC];  // slots grp, grp + 8, ...: the first UPD_SPEC x 8 slots (24 slices with two roles) in ONE round trip
 #pragma unroll
     for (int u = 0; u < UPD_SPEC; ++u) {
         const int s = grp + u * 8;
-        const bool ok = j < NVALS && s < NT * PER && ((rmask >> (s % NR)) & 1);
+        const int r = s % NR;
+        const bool ok = j < NVALS && s < PS * PER && ((rmask >> r) & 1) && s / PER < (r == 0 ? smax_r[0] : (r == 1 ? smax_r[1] : smax_r[2]));
         v0[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
     }
     const int txy_first = tid < NT ? tiles[tid] : 0;
@@ -1193,7 +1198,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     // slots (tile position, quadrant, role) of hypothesis b are ONE contiguous run: v0[] was requested before the
     // count was known; fixed order => bit-reproducible
     {
-        const int nslot = n_act * PER;
+        const int nslot = min(PS, n_act) * PER;  // (slice s / PER has a tile <=> s / PER < n_act)
 #pragma unroll
         for (int u = 0; u < UPD_SPEC; ++u) acc += (grp + u * 8 < nslot) ? v0[u] : 0.f;
         if (j < NVALS)
@@ -1202,7 +1207,8 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per slot)
                     const int s = s0 + u * 8;
-                    const bool ok = s < nslot && ((rmask >> (s % NR)) & 1);
+                    const int r = s % NR;
+                    const bool ok = s < nslot && ((rmask >> r) & 1) && s / PER < (r == 0 ? smax_r[0] : (r == 1 ? smax_r[1] : smax_r[2]));
                     v[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
                 }
 #pragma unroll
@@ -1420,6 +1426,15 @@ static dim3 shade_grid(const ddx_engine_desc& d)
     return dim3(d.B, S);
 }
 
+// edge_kernel: 66 VGPRs, 7 waves/SIMD, so more resident workgroups than the shade kernel has
+static dim3 edge_grid(const ddx_engine_desc& d)
+{
+    int S = EDGE_GRID / d.B;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    return dim3(d.B, S);
+}
+
 // first iteration of a run: pose -> clip/snap (later iterations inherit them from update_xfm_kernel)
 static int run_prologue(ddx_engine* e, int it0, hipStream_t s)
 {
@@ -1450,9 +1465,7 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
     }
     if (d.use_edge) {
         if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
-        dim3 ge = shade_grid(d);  // 66 VGPRs: 7 waves/SIMD, so more resident workgroups than the shade kernel has
-        ge.y = (unsigned)((EDGE_GRID / d.B) < 1 ? 1 : ((EDGE_GRID / d.B) > 64 ? 64 : (EDGE_GRID / d.B)));
-        edge_kernel<<<ge, 256, 0, s>>>(E);
+        edge_kernel<<<edge_grid(d), 256, 0, s>>>(E);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
 #define UPD_GRID dim3(d.B, UPD_SLICES)
@@ -1522,6 +1535,9 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         }
         if (desc->use_edge) E.role_mask |= 4;  // slot 2
         E.st_role = E.roles[0];
+        E.s_shade = (int)shade_grid(*desc).y;
+        E.s_edge = desc->use_edge ? (int)edge_grid(*desc).y : 0;
+        E.pslices = E.s_shade > E.s_edge ? E.s_shade : E.s_edge;
     }
     const size_t need = engine_layout(e->dev, *desc, b.scratch);
     if (b.scratch_bytes < need) {
