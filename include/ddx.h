@@ -164,6 +164,11 @@ typedef struct ddx_engine_buffers {
 
 typedef struct ddx_engine ddx_engine;
 
+/* The first run of an engine performs its one-time setup on the run's stream (frame constants of the observed images, the
+ * internal spatially sorted copy of the mesh, per-triangle records) and reads the number of observed-mask pixels back to
+ * choose the rasteriser's fragment variant (expected covered pixel centres per triangle); the result of the optimisation
+ * does not depend on that choice (bit-identical, tests/test_gpu_engine.py).  Environment: DDX_SCATTER_EXCHANGE=0|1
+ * overrides the choice (tuning only). */
 size_t ddx_engine_scratch_bytes(const ddx_engine_desc* desc);
 int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* bufs, ddx_engine** out);
 /* Run iterations [it0, it0+n) (rows of lr_sched / loss_log / mtx_log).  use_graph != 0 replays a
