@@ -33,6 +33,7 @@
 // (summed once at engine creation); the third is evaluated per hypothesis and iteration over the
 // compacted list of pixels with seg0 != 0.  Pixels of active tiles add (actual - background) terms.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -76,7 +77,14 @@ struct EngineDev {
     float* lumbuf;    // [B,H*W] luminance of the rendered colour at covered pixels (written by the colour role, read by
     float* ubuf;      // [B,H*W,12] edge_kernel; garbage where zbuf says "background") and U = d lum / d final per pixel
     float* adam;      // [2][2,7,B]: first and second moments, by iteration parity
-    float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0
+    float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0 (setup only)
+    // the same pixels sorted by observed depth, with prefix sums (double) of |seg0| and |seg0| * depth: the whole-frame
+    // background depth term sum_i |seg0_i| |d - gt_i| and its derivative for a hypothesis' background depth d are two
+    // searches and six loads instead of a pass over the list (10 700 entries per workgroup on cfg5: 10 of the update's 21 us)
+    float* seg_gd;    // [n_seg] ascending
+    double* seg_W;    // [n_seg + 1] W[k] = sum_{i<k} |seg0_i|
+    double* seg_G;    // [n_seg + 1] G[k] = sum_{i<k} |seg0_i| gt_i
+    int nseg;
     // Internal, spatially sorted copy of the mesh (built once per engine): vertices renumbered in Morton order of their
     // object-space position, so that the vertex data of neighbouring triangles / pixels are neighbours in memory whatever
     // order the mesh file had (a randomly ordered vertex list cost 15-20 % otherwise); triangle ids are NOT renumbered.
@@ -133,6 +141,9 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_par = carve((size_t)2 * 7 * d.B * sizeof(float));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
+    const size_t o_sgd = carve(d.use_depth ? (size_t)d.H * d.W * sizeof(float) : 0);
+    const size_t o_sW = carve(d.use_depth ? ((size_t)d.H * d.W + 1) * sizeof(double) : sizeof(double));
+    const size_t o_sG = carve(d.use_depth ? ((size_t)d.H * d.W + 1) * sizeof(double) : sizeof(double));
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
     const size_t o_perm = carve((size_t)d.T * sizeof(int4));
     const size_t o_crec = carve((size_t)d.T * 5 * sizeof(float4));
@@ -156,6 +167,9 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.params2 = (float*)(p + o_par);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
+    E.seg_gd = (float*)(p + o_sgd);
+    E.seg_W = (double*)(p + o_sW);
+    E.seg_G = (double*)(p + o_sG);
     E.trirec = (int4*)(p + o_rec);
     E.trisort = (int4*)(p + o_perm);
     E.crec = (float4*)(p + o_crec);
@@ -1112,7 +1126,6 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
 // over the slices.
 #define UPD_SLICES 8
 #define UPD_SPEC 24  // partial slots per thread requested before the tile count is known
-#define SEG_PRE 16  // seg-list entries per thread requested up front (covers 4096 masked pixels; the rest loops)
 
 template <int NR>
 __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
@@ -1168,13 +1181,9 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         v0[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
     }
     const int txy_first = tid < NT ? tiles[tid] : 0;
-    const int ns = d.use_depth ? E.st->n_seg : 0;
-    float2 sg[SEG_PRE];
-#pragma unroll
-    for (int k = 0; k < SEG_PRE; ++k) {
-        const int i = tid + k * 256;
-        sg[k] = i < ns ? E.seglist[i] : make_float2(0.f, 0.f);
-    }
+    // totals of the sorted seg list (its size is known to the host since setup)
+    const int ns = d.use_depth ? E.nseg : 0;
+    const double segWn = E.seg_W[ns], segGn = E.seg_G[ns];
     const int per = (V + UPD_SLICES - 1) / UPD_SLICES;
     const int n_begin = slice * per, n_end = min(V, n_begin + per);
     float px[4], py[4], pz[4];
@@ -1246,29 +1255,38 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     __syncthreads();
     UPH(2);
-    // ---- whole-frame background depth term over the compact seg list
-    float bgsum = 0.f, bgder = 0.f;
-    if (d.use_depth) {
-#pragma unroll
-        for (int k = 0; k < SEG_PRE; ++k) {  // an absent entry is (0,0): contributes exactly 0 to both sums
-            const float x = (dbg - sg[k].x) * sg[k].y;
-            bgsum += fabsf(x);
-            bgder += sgnf(x) * sg[k].y;
+    // ---- whole-frame background depth term: sum_i w_i |dbg - g_i| and sum_i w_i sgn(dbg - g_i) (w = |seg0|, g = observed depth)
+    // from the sorted list: k1 = #(g < dbg), k2 = #(g <= dbg) by a 64-way search per round on the last wave (no barrier), then
+    // prefix-sum differences in double
+    __shared__ float s_bg[2];
+    if (d.use_depth && wave == 3) {
+        int lo1 = 0, hi1 = ns, lo2 = 0, hi2 = ns, k1 = -1, k2 = -1;
+        while (k1 < 0 || k2 < 0) {  // (wave-uniform)
+            const int span1 = hi1 - lo1, span2 = hi2 - lo2;
+            const int step1 = (span1 + 63) / 64, step2 = (span2 + 63) / 64;
+            const int i1 = lo1 + lane * step1, i2 = lo2 + lane * step2;
+            const bool in1 = k1 < 0 && span1 > 0 && i1 < hi1, in2 = k2 < 0 && span2 > 0 && i2 < hi2;
+            const float g1 = in1 ? E.seg_gd[i1] : 0.f, g2 = in2 ? E.seg_gd[i2] : 0.f;
+            const int c1 = __popcll(__ballot(in1 && g1 < dbg)), c2 = __popcll(__ballot(in2 && g2 <= dbg));
+            if (k1 < 0) {
+                if (span1 <= 0 || c1 == 0) k1 = lo1;
+                else if (step1 == 1) k1 = lo1 + c1;
+                else { const int pv = lo1 + (c1 - 1) * step1; lo1 = pv + 1; hi1 = min(pv + step1, hi1); }
+            }
+            if (k2 < 0) {
+                if (span2 <= 0 || c2 == 0) k2 = lo2;
+                else if (step2 == 1) k2 = lo2 + c2;
+                else { const int pv = lo2 + (c2 - 1) * step2; lo2 = pv + 1; hi2 = min(pv + step2, hi2); }
+            }
         }
-        for (int i = tid + SEG_PRE * 256; i < ns; i += 256) {
-            const float2 e = E.seglist[i];
-            const float x = (dbg - e.x) * e.y;
-            bgsum += fabsf(x);
-            bgder += sgnf(x) * e.y;
+        if (lane == 0) {
+            const double W1 = E.seg_W[k1], G1 = E.seg_G[k1], W2 = E.seg_W[k2], G2 = E.seg_G[k2], dd = (double)dbg;
+            s_bg[0] = (float)((dd * W1 - G1) + ((segGn - G2) - dd * (segWn - W2)));
+            s_bg[1] = (float)(W1 - (segWn - W2));
         }
-        bgsum = wave_sum(bgsum);
-        bgder = wave_sum(bgder);
-        __syncthreads();
-        if (lane == 0) { red[wave][0] = bgsum; red[wave][1] = bgder; }
-        __syncthreads();
-        bgsum = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        bgder = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
+    __syncthreads();
+    const float bgsum = d.use_depth ? s_bg[0] : 0.f, bgder = d.use_depth ? s_bg[1] : 0.f;
     UPH(3);
     // ---- tail on wave 0, one lane per output where the work allows
     const bool writer = slice == 0;
@@ -1691,6 +1709,29 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         EngineState hst;
         DDX_HIP(hipMemcpyAsync(&hst, E.st, sizeof(EngineState), hipMemcpyDeviceToHost, s));
         DDX_HIP(hipStreamSynchronize(s));
+        // sorted seg list + prefix sums (see EngineDev::seg_gd)
+        E.nseg = 0;
+        std::vector<double> hW(1, 0.0), hG(1, 0.0);
+        std::vector<float> hgd;
+        if (E.d.use_depth) {
+            const int n = hst.n_seg;
+            std::vector<float2> hs((size_t)n);
+            if (n > 0) DDX_HIP(hipMemcpyAsync(hs.data(), E.seglist, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, s));
+            DDX_HIP(hipStreamSynchronize(s));
+            std::sort(hs.begin(), hs.end(), [](const float2& a, const float2& b) { return a.x < b.x; });
+            hgd.resize((size_t)n); hW.resize((size_t)n + 1); hG.resize((size_t)n + 1);
+            for (int i = 0; i < n; ++i) {
+                const double w = std::fabs((double)hs[(size_t)i].y);
+                hgd[(size_t)i] = hs[(size_t)i].x;
+                hW[(size_t)i + 1] = hW[(size_t)i] + w;
+                hG[(size_t)i + 1] = hG[(size_t)i] + w * (double)hs[(size_t)i].x;
+            }
+            E.nseg = n;
+            if (n > 0) DDX_HIP(hipMemcpyAsync(E.seg_gd, hgd.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+        }
+        DDX_HIP(hipMemcpyAsync(E.seg_W, hW.data(), hW.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        DDX_HIP(hipMemcpyAsync(E.seg_G, hG.data(), hG.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        DDX_HIP(hipStreamSynchronize(s));  // (host vectors are the copy sources)
         const double per_tri = 2.0 * (hst.c_mask / 3.0) / (double)std::max(E.d.T, 1);
         E.L.scatter_exchange = per_tri > SCATTER_EXCHANGE_PER_TRI ? 1 : 0;
         if (const char* ov = getenv("DDX_SCATTER_EXCHANGE")) E.L.scatter_exchange = atoi(ov) ? 1 : 0;
