@@ -431,6 +431,7 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
 //     merging into zbuf with atomicMin.
 #define BIG_SCAN 1024  // (hypothesis, tile) flags scanned per step of the large-triangle pass
 
+#define CB_ROUNDS 16  // (CB_ROUNDS * 4 waves = 64 counts: one wave-wide prefix)
 __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int B,
                                                           int V, int T, int H, int W, RasterScratch L)
 {
@@ -447,18 +448,46 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
         const int b = blockIdx.x;
         const int* flg = L.tile_flag + (size_t)b * L.NT;
         int* out = L.active + (size_t)b * L.NT;
+        // 16 rounds of 256 flags at a time: all loads in flight at once, one ordered prefix over the (round, wave) counts --
+        // a load / ballot / barrier loop per 256 flags paid one memory round trip per round (5 on 640x480, 15 on 1280x720)
+        __shared__ int s_cnt[CB_ROUNDS * 4], s_off[CB_ROUNDS * 4 + 1];
         int carry = 0;
-        for (int start = 0; start < L.NT; start += 256) {
-            const int i = start + tid;
-            const bool act = i < L.NT && flg[i] != 0;
-            const unsigned long long m = __ballot(act);
+        for (int start = 0; start < L.NT; start += CB_ROUNDS * 256) {
+            int fl[CB_ROUNDS];
+#pragma unroll
+            for (int c = 0; c < CB_ROUNDS; ++c) {
+                const int i = start + c * 256 + tid;
+                fl[c] = i < L.NT ? flg[i] : 0;
+            }
+            unsigned long long m[CB_ROUNDS];
+#pragma unroll
+            for (int c = 0; c < CB_ROUNDS; ++c) m[c] = __ballot(fl[c] != 0);
+            __syncthreads();  // (s_cnt / s_off of the previous super-round are no longer read)
+            if (lane < CB_ROUNDS) {
+                unsigned long long mine = 0ull;
+#pragma unroll
+                for (int c = 0; c < CB_ROUNDS; ++c) mine = lane == c ? m[c] : mine;
+                s_cnt[lane * 4 + wave] = __popcll(mine);
+            }
             __syncthreads();
-            if (lane == 0) wcnt[wave] = __popcll(m);
+            if (wave == 0) {  // exclusive prefix of the CB_ROUNDS * 4 = 64 counts in (round, wave) order
+                const int v = s_cnt[lane];
+                int incl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
+                }
+                s_off[lane] = incl - v;
+                if (lane == 63) s_off[64] = incl;
+            }
             __syncthreads();
-            int off = carry;
-            for (int w = 0; w < wave; ++w) off += wcnt[w];
-            if (act) out[off + __popcll(m & ((1ull << lane) - 1ull))] = ((i / L.ntx) << 16) | (i % L.ntx);  // (ty, tx) packed
-            carry += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+#pragma unroll
+            for (int c = 0; c < CB_ROUNDS; ++c) {
+                const int i = start + c * 256 + tid;
+                if (fl[c] != 0) out[carry + s_off[c * 4 + wave] + __popcll(m[c] & ((1ull << lane) - 1ull))] = ((i / L.ntx) << 16) | (i % L.ntx);  // (ty, tx) packed
+            }
+            carry += s_off[64];
         }
         if (tid == 0) L.b_count[b] = carry;
         return;
