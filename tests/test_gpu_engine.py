@@ -153,7 +153,8 @@ def test_render_texture_batch_autograd_matches_oracle():
         np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
 
 
-@pytest.mark.parametrize("rows,cols,H,W,B,dist", [(4, 6, 50, 70, 1, 1.2), (6, 8, 120, 160, 3, 1.0), (16, 20, 37, 53, 2, 1.8)])
+@pytest.mark.parametrize("rows,cols,H,W,B,dist", [(4, 6, 50, 70, 1, 1.2), (6, 8, 120, 160, 3, 1.0), (16, 20, 37, 53, 2, 1.8),
+                                                  (24, 32, 1083, 1925, 2, 2.0)])  # 8228 tiles: more than one compaction pass
 def test_engine_large_triangles_ragged_sizes_single_hypothesis(rows, cols, H, W, B, dist):
     """Low-poly meshes close to the camera (every triangle takes the tile pass), resolutions that are not
     multiples of the tile size, B = 1: losses and gradients still match the oracle."""
