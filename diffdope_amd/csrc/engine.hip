@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
 // vertices with the NEW pose on the matrix core (as pose_xfm_kernel), so the next iteration starts at the
 // rasteriser.  Slice 0 also writes parameters, optimiser state and logs; the zbuf / tile-flag re-arm is split
 // over the slices.
-#define UPD_SLICES 8
+#define UPD_SLICES 8  // at most; fewer for large batches (upd_slices())
 #define UPD_SPEC 24  // partial slots per thread requested before the tile count is known
 
 template <int NR>
@@ -1184,7 +1184,8 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     // totals of the sorted seg list (its size is known to the host since setup)
     const int ns = d.use_depth ? E.nseg : 0;
     const double segWn = E.seg_W[ns], segGn = E.seg_G[ns];
-    const int per = (V + UPD_SLICES - 1) / UPD_SLICES;
+    const int n_slices = (int)gridDim.y;  // a power of two <= UPD_SLICES
+    const int per = (V + n_slices - 1) / n_slices;
     const int n_begin = slice * per, n_end = min(V, n_begin + per);
     float px[4], py[4], pz[4];
 #pragma unroll
@@ -1233,7 +1234,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         if (start + tid < n_act) {
             const int txy = start == 0 ? txy_first : tiles[start + tid];
             s_tiles[tid] = txy;
-            if (((start + tid) % UPD_SLICES) == slice) {
+            if (((start + tid) & (n_slices - 1)) == slice) {
                 const int tile = (txy >> 16) * E.L.ntx + (txy & 0xffff);
                 E.L.tile_flag[(size_t)b * NT + tile] = 0;
                 E.L.tile_big[(size_t)b * NT + tile] = 0;
@@ -1242,7 +1243,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         __syncthreads();
         const int na = min(256, n_act - start);
         const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
-        for (int s = slice; s < na; s += UPD_SLICES) {  // (start is a multiple of 256, hence of UPD_SLICES)
+        for (int s = slice; s < na; s += n_slices) {  // (start is a multiple of 256, hence of n_slices)
             const int txy = s_tiles[s];
             const int zx = (txy & 0xffff) * DDX_TILE + lx, zy = (txy >> 16) * DDX_TILE + ly;
             if (zx < d.W && zy < d.H) E.L.zbuf[(size_t)b * E.L.zper + zaddr(zx, zy, E.L.zwb)] = ~0ull;
@@ -1444,6 +1445,16 @@ static dim3 shade_grid(const ddx_engine_desc& d)
     return dim3(d.B, S);
 }
 
+// update_xfm_kernel: every slice of a hypothesis repeats the ~6 us chain (partial sums, optimiser step, matrices) before it
+// transforms its share of the vertices; the time is flat in the slice count while all workgroups are resident (1024 at
+// 4 waves/SIMD), so large batches get fewer slices instead of several rounds of that chain (512 hypotheses on the cfg2 mesh: 50 -> 38 us)
+static int upd_slices(const ddx_engine_desc& d)
+{
+    int sl = UPD_SLICES;
+    while (sl > 1 && (long long)d.B * sl > 1024) sl >>= 1;
+    return sl;
+}
+
 // edge_kernel: 66 VGPRs, 7 waves/SIMD, so more resident workgroups than the shade kernel has
 static dim3 edge_grid(const ddx_engine_desc& d)
 {
@@ -1486,7 +1497,7 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
         edge_kernel<<<edge_grid(d), 256, 0, s>>>(E);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
-#define UPD_GRID dim3(d.B, UPD_SLICES)
+#define UPD_GRID dim3(d.B, upd_slices(d))
     if (d.use_edge) update_xfm_kernel<3><<<UPD_GRID, 256, 0, s>>>(E);
     else update_xfm_kernel<2><<<UPD_GRID, 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
