@@ -1162,9 +1162,9 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     const int n_act = E.L.b_count[b];
     const int* tiles = E.L.active + (size_t)b * NT;
     // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the
-    // first chunk of the tile list (speculative: entries beyond n_act are stale and unused), the compact seg list
-    // of the background depth term, and the first batch of vertex positions of the transform at the end.  The
-    // kernel is a chain of dependent round trips; these three would otherwise each add one.
+    // first chunk of the tile list (speculative: entries beyond n_act are stale and unused), the partial rows, the totals of
+    // the sorted seg list, and the first batch of vertex positions of the transform at the end.  The kernel is a chain
+    // of dependent round trips; these would otherwise each add one.
     constexpr int PER = 4 * NR;  // partial slots per tile
     const int rmask = E.role_mask;
     // partial rows of hypothesis b: (slice, wave, role), written by the workgroups of shade_kernel / edge_kernel that had at
