@@ -161,7 +161,6 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                 // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
                 const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
                 if (area != 0) {
-                    alive = true;
                     const bool flip = area < 0;
                     const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
                     const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
@@ -178,6 +177,7 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                         for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
                             mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
                     }
+                    alive = mask != 0;  // a small triangle that covers no centre draws nothing: no tile to flag
                     bool walk = WALK == 1;
                     if (WALK == 2) {
                         const int cnt = RASTER_SMALL_PX > 32 ? __popcll(mask) : __popc((unsigned)mask);
