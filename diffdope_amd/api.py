@@ -604,8 +604,11 @@ class DiffDope:
         hp = self.cfg.hyperparameters
         return [hp.base_lr * hp.lr_decay ** (it / hp.nb_iterations + 1) for it in range(hp.nb_iterations + 1)]
 
-    def run_optimization(self, fused=None, optimizer="sgd", global_batch=None):
-        """diffdope.py:1634-1714.  fused=None picks the fused engine when every loss function is a built-in."""
+    def run_optimization(self, fused=None, optimizer="sgd", global_batch=None, wait=True):
+        """diffdope.py:1634-1714.  fused=None picks the fused engine when every loss function is a built-in.
+        wait=False (fused path only) enqueues the whole optimisation on the current stream and returns; call
+        finish_optimization() to synchronise and fetch the results -- several objects can then run on one stream each
+        and fill each other's launch tails (bop.refine_frame)."""
         self.losses_values = {}
         self.optimization_results = []
         self._refresh_gt()
@@ -615,11 +618,18 @@ class DiffDope:
         if fused and not builtin:
             raise RuntimeError("the fused engine only knows l1_rgb_with_mask / l1_depth_with_mask / l1_mask / l1_edge")
         if fused:
-            self._run_fused(optimizer, global_batch)
+            self._fused_enqueue(optimizer, global_batch)
+            if wait:
+                self.finish_optimization()
         else:
             self._run_autograd()
 
-    def _run_fused(self, optimizer, global_batch):
+    def finish_optimization(self):
+        """Synchronise with a run_optimization(wait=False) and fetch its results (no-op otherwise)."""
+        if getattr(self, "_pending", None) is not None:
+            self._fused_collect()
+
+    def _fused_enqueue(self, optimizer, global_batch):
         r = self.object3d.mesh()
         lw = self.cfg.losses
         weights = {}
@@ -633,6 +643,12 @@ class DiffDope:
         eng = RefineEngine(r["pos"][0], r["pos_idx"][0], self.camera.cam_proj[0], self.resolution, gt, params, self.learning_rates,
                            self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, **tex)
         eng.run()
+        self._pending = (eng, params, weights, torch.cuda.current_stream())
+
+    def _fused_collect(self):
+        eng, params, weights, stream = self._pending
+        self._pending = None
+        stream.synchronize()
         eng.check()
         self.object3d.load_params_tensor(params)
         losses = eng.losses().cpu()

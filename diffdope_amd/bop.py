@@ -43,6 +43,9 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
     dev = torch.device("cuda", torch.cuda.current_device())
     table = torch.zeros((n, 18), dtype=torch.float32, device=dev)
     handles = {}
+    # the local objects run on one stream each: every engine is a chain of four latency-bound kernels per iteration, and
+    # the kernels of another object fill their launch tails (4 objects of BASELINE config 5: 22.6 -> 20.8 ms per frame)
+    main = torch.cuda.current_stream()
     for i, o in enumerate(objects):
         if owner_of(i, world) != rank:
             continue
@@ -51,13 +54,18 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
         sc = Scene(tensor_rgb=scene.tensor_rgb, tensor_depth=scene.tensor_depth, tensor_segmentation=masks[i])
         cfg_i = cfg if "losses" not in o else {**cfg, "losses": {**cfg["losses"], **o["losses"]}}
         dd = DiffDope(cfg=cfg_i, camera=camera, object3d=obj, scene=sc)
-        dd.run_optimization(optimizer=optimizer)
+        st = torch.cuda.Stream()
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            dd.run_optimization(optimizer=optimizer, wait=False)
+        handles[i] = dd
+    for i, dd in handles.items():
+        dd.finish_optimization()
         best = int(dd.get_argmin())
         stacked = torch.stack([t[-1] for t in dd.losses_values.values()], dim=0).mean(0)
         table[i, 0] = float(stacked[best])
         table[i, 1] = best
         table[i, 2:] = torch.as_tensor(dd.get_pose(best)).reshape(16).to(dev)
-        handles[i] = dd
     if world > 1:
         from .dist import merge_object_tables
 

@@ -148,3 +148,28 @@ def test_file_based_run_recovers_pose(tmp_path):
     first, last = d.losses_values["rgb"][0].mean(), d.losses_values["rgb"][-1].min()
     assert last < first
     assert ang < 5e-3 and dt < 2e-3, (ang, dt)
+
+
+def test_deferred_runs_on_separate_streams_equal_blocking_runs():
+    """run_optimization(wait=False) + finish_optimization(): two objects enqueued on one stream each give the results of two
+    blocking runs, bit for bit."""
+    sc = make_scene(16, 20, 60, 80, B=1, dist=1.8)
+    ref = []
+    for losses in (("rgb", "mask"), ("depth", "mask")):
+        d = _ddope(sc, losses, 4)
+        d.run_optimization(fused=True)
+        ref.append((d.object3d.params_tensor().clone(), {k: v.clone() for k, v in d.losses_values.items()}))
+    runs = []
+    main = torch.cuda.current_stream()
+    for losses in (("rgb", "mask"), ("depth", "mask")):
+        d = _ddope(sc, losses, 4)
+        st = torch.cuda.Stream()
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            d.run_optimization(fused=True, wait=False)
+        runs.append(d)
+    for d, (p, lv) in zip(runs, ref):
+        assert not d.losses_values  # nothing fetched yet
+        d.finish_optimization()
+        assert torch.equal(d.object3d.params_tensor(), p)
+        assert set(d.losses_values) == set(lv) and all(torch.equal(d.losses_values[k], lv[k]) for k in lv)
