@@ -385,3 +385,26 @@ def test_engine_close_up_dense_mesh_scatter_variants_agree(monkeypatch):
     for i, key in enumerate(KEYS):
         if key in logs:
             np.testing.assert_allclose(runs[None][0][0, i, 5], logs[key][0], rtol=5e-5, atol=1e-7)
+
+
+def test_engine_large_batch_not_a_multiple_of_eight():
+    """300 hypotheses (the update kernel then runs 2 slices per hypothesis instead of 8, the shade grid 3 slices): losses and
+    the SGD step of sampled hypotheses match the oracle, which renders them with the batch-of-300 mean factor."""
+    sc = make_scene(16, 20, 60, 80, B=300, dist=1.8)
+    weights = dict(rgb=0.7, depth=1.0, mask=1.0)
+    R = sc["oracle"]
+    R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
+    lr = 0.25
+    eng, p = _engine(sc, weights, [lr])
+    eng.run()
+    torch.cuda.synchronize()
+    eng.check()
+    lg = eng.losses()[0].cpu().numpy()
+    pn = p.cpu().numpy()
+    for j in (0, 7, 151, 299):
+        total, logs, g_ref, _ = R.loss_and_grad(sc["params"][:, j:j + 1], sc["lr_mult"][j:j + 1], global_B=300)
+        for i, key in enumerate(KEYS):
+            if key in logs:
+                np.testing.assert_allclose(lg[i, j], logs[key][0], rtol=5e-5, atol=1e-7)
+        g_gpu = (sc["params"][:, j] - pn[:, j]) / lr
+        np.testing.assert_allclose(g_gpu, g_ref[:, 0], rtol=5e-3, atol=5e-3 * np.abs(g_ref).max() + 2e-6)
