@@ -435,10 +435,9 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
 __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int B,
                                                           int V, int T, int H, int W, RasterScratch L)
 {
-    __shared__ int wcnt[4];
-    __shared__ int4 s_e0[256], s_e1[256], s_e2[256];  // staged LARGE triangles: per edge (e.lo, e.hi, step x, step y) at the tile origin
-    __shared__ int s_t[256];                          // ... their ids
-    __shared__ float4 s_p0[256], s_p1[256], s_p2[256];  // ... and their clip-space vertices
+    __shared__ int4 s_e0[4][64], s_e1[4][64], s_e2[4][64];  // staged LARGE triangles of each wave's tile: per edge (e.lo, e.hi, step x, step y) at the tile origin
+    __shared__ int s_t[4][64];                              // ... their ids
+    __shared__ float4 s_p0[4][64], s_p1[4][64], s_p2[4][64];  // ... and their clip-space vertices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     DDX_TRACE_BEGIN();
 #ifdef DDX_TRACE
@@ -518,7 +517,13 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
     }
     __syncthreads();
     const int nbig = s_nbig;
-    for (int e = 0; e < nbig; ++e) {
+    // ---- one WAVE per large tile (four tiles in flight per workgroup, no workgroup barrier inside): a tile is a chain of
+    // four dependent gathers (list entry -> vertex ids -> snapped vertices -> clip vertices) before its pixel loop, and a
+    // workgroup that walked its tiles one by one paid the chain once per tile (3-4.5 us each: 51 us for the 24-triangle
+    // hugetri workload, 13 tiles per workgroup; 32 us now).  Lanes test 64 candidates per round and then shade 4 pixels
+    // each.  (Dealing (tile, round of 64 candidates) items to the waves instead -- for workgroups with fewer than four
+    // tiles -- was measured: no better on the 384-triangle lowpoly workload, 27 -> 28.5 us.)
+    for (int e = wave; e < nbig; e += 4) {  // (wave-uniform)
         const int flat = s_big[e];
         const int b = flat / L.NT, tile = flat - b * L.NT;
         const int tcx = tile % L.ntx, tcy = tile / L.ntx;
@@ -526,14 +531,14 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
         const int2* S = L.snap + (size_t)b * V;
         const uint2* BL = L.biglist + (size_t)b * T;
         const int n_big = min(L.bigcount[b], T);
-        const int px = tcx * DDX_TILE + tid % DDX_TILE, py = tcy * DDX_TILE + tid / DDX_TILE;
-        const bool inimg = px < W && py < H;
-        unsigned long long best = ~0ull;
-        for (int r0 = 0; r0 < n_big; r0 += 256) {
+        const int lx = lane % DDX_TILE, ly0 = lane / DDX_TILE;  // pixels (lx, ly0 + 4 q), q = 0..3
+        const int px = tcx * DDX_TILE + lx;
+        unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        for (int r0 = 0; r0 < n_big; r0 += 64) {
             // ---- the LARGE triangles of this hypothesis whose tile range contains this tile: ballot-compacted, and
-            // everything the pixel loop needs (snapped + clip-space vertices) is staged in LDS by the thread that found
-            // the hit -- 256 parallel gathers instead of one dependent gather chain per triangle and pixel loop step
-            const int idx = r0 + tid;
+            // everything the pixel loop needs (edge functions + clip-space vertices) is staged in LDS by the lane that found
+            // the hit -- parallel gathers instead of one dependent gather chain per triangle and pixel loop step
+            const int idx = r0 + lane;
             bool hit = false;
             uint2 ent = make_uint2(0u, 0u);
             if (idx < n_big) {
@@ -570,47 +575,53 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
                         // pixel centre (int64) with the ownership rule folded in (e + own - 1 >= 0), and the 32-bit
                         // steps per pixel in x and y
                         int dx = st.X[kb] - st.X[ka], dy = st.Y[kb] - st.Y[ka];
-                        long long e = (long long)dx * (long long)(cy0 - st.Y[ka]) - (long long)dy * (long long)(cx0 - st.X[ka]);
-                        if (flip) { e = -e; dx = -dx; dy = -dy; }
-                        e += ((dy > 0) || (dy == 0 && dx < 0)) ? 0 : -1;
-                        es[k] = make_int4((int)(unsigned)(e & 0xffffffffll), (int)(e >> 32), -dy * DDX_SUBPIX, dx * DDX_SUBPIX);
+                        long long ev = (long long)dx * (long long)(cy0 - st.Y[ka]) - (long long)dy * (long long)(cx0 - st.X[ka]);
+                        if (flip) { ev = -ev; dx = -dx; dy = -dy; }
+                        ev += ((dy > 0) || (dy == 0 && dx < 0)) ? 0 : -1;
+                        es[k] = make_int4((int)(unsigned)(ev & 0xffffffffll), (int)(ev >> 32), -dy * DDX_SUBPIX, dx * DDX_SUBPIX);
                     }
                 }
             }
             const unsigned long long m = __ballot(hit);
-            __syncthreads();  // (the previous round's pixel loop is done with the staging arrays and wcnt)
-            if (lane == 0) wcnt[wave] = __popcll(m);
-            __syncthreads();
-            int off = 0;
-            for (int w = 0; w < wave; ++w) off += wcnt[w];
-            const int nh = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            const int nh = __popcll(m);
+            if (nh == 0) continue;  // (wave-uniform)
             if (hit) {
-                const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-                const int t = (int)ent.x;
-                s_e0[slot] = es[0]; s_e1[slot] = es[1]; s_e2[slot] = es[2];
-                s_t[slot] = t;
-                s_p0[slot] = ld4(P + (size_t)i0 * 4);
-                s_p1[slot] = ld4(P + (size_t)i1 * 4);
-                s_p2[slot] = ld4(P + (size_t)i2 * 4);
+                const int slot = __popcll(m & ((1ull << lane) - 1ull));
+                s_e0[wave][slot] = es[0]; s_e1[wave][slot] = es[1]; s_e2[wave][slot] = es[2];
+                s_t[wave][slot] = (int)ent.x;
+                s_p0[wave][slot] = ld4(P + (size_t)i0 * 4);
+                s_p1[wave][slot] = ld4(P + (size_t)i1 * 4);
+                s_p2[wave][slot] = ld4(P + (size_t)i2 * 4);
             }
-            __syncthreads();
-            // ---- lane = pixel over the staged triangles (wave-uniform walk, LDS broadcast reads)
-            if (inimg) {
-                const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- lane = 4 pixels of the tile over the staged triangles (wave-uniform walk, LDS broadcast reads)
+            if (px < W) {
                 for (int j = 0; j < nh; ++j) {
-                    const int4 q0 = s_e0[j], q1 = s_e1[j], q2 = s_e2[j];
-                    const long long v0 = (((long long)q0.y << 32) | (unsigned)q0.x) + (long long)lx * q0.z + (long long)ly * q0.w;
-                    const long long v1 = (((long long)q1.y << 32) | (unsigned)q1.x) + (long long)lx * q1.z + (long long)ly * q1.w;
-                    const long long v2 = (((long long)q2.y << 32) | (unsigned)q2.x) + (long long)lx * q2.z + (long long)ly * q2.w;
-                    if ((v0 | v1 | v2) < 0) continue;
-                    const unsigned long long key = frag_key(s_p0[j], s_p1[j], s_p2[j], px, py, H, W, s_t[j]);
-                    best = key < best ? key : best;
+                    const int4 q0 = s_e0[wave][j], q1 = s_e1[wave][j], q2 = s_e2[wave][j];
+                    const long long c0 = (((long long)q0.y << 32) | (unsigned)q0.x) + (long long)lx * q0.z;
+                    const long long c1 = (((long long)q1.y << 32) | (unsigned)q1.x) + (long long)lx * q1.z;
+                    const long long c2 = (((long long)q2.y << 32) | (unsigned)q2.x) + (long long)lx * q2.z;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ly = ly0 + 4 * q, py = tcy * DDX_TILE + ly;
+                        const long long v0 = c0 + (long long)ly * q0.w, v1 = c1 + (long long)ly * q1.w, v2 = c2 + (long long)ly * q2.w;
+                        if ((v0 | v1 | v2) < 0 || py >= H) continue;
+                        const unsigned long long key = frag_key(s_p0[wave][j], s_p1[wave][j], s_p2[wave][j], px, py, H, W, s_t[wave][j]);
+                        best[q] = key < best[q] ? key : best[q];
+                    }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the staging arrays are rewritten by the next round)
         }
-        if (best != ~0ull) atomicMin(L.zbuf + (size_t)b * L.zper + zaddr(px, py, L.zwb), best);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int py = tcy * DDX_TILE + ly0 + 4 * q;
+            if (best[q] != ~0ull) atomicMin(L.zbuf + (size_t)b * L.zper + zaddr(px, py, L.zwb), best[q]);
+        }
 #ifdef DDX_TRACE
-        n_done += 1 + ((unsigned long long)n_big << 32);
+        if (wave == 0) n_done += 1 + ((unsigned long long)n_big << 32);
 #endif
     }
     }
