@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
 {
     __shared__ int4 s_e0[4][64], s_e1[4][64], s_e2[4][64];  // staged LARGE triangles of each wave's tile: per edge (e.lo, e.hi, step x, step y) at the tile origin
     __shared__ int s_t[4][64];                              // ... their ids
+    __shared__ int s_cand[4][256];                          // range-test survivors of 256 list entries (per wave)
     __shared__ float4 s_p0[4][64], s_p1[4][64], s_p2[4][64];  // ... and their clip-space vertices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     DDX_TRACE_BEGIN();
@@ -534,19 +535,37 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
         const int lx = lane % DDX_TILE, ly0 = lane / DDX_TILE;  // pixels (lx, ly0 + 4 q), q = 0..3
         const int px = tcx * DDX_TILE + lx;
         unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-        for (int r0 = 0; r0 < n_big; r0 += 64) {
-            // ---- the LARGE triangles of this hypothesis whose tile range contains this tile: ballot-compacted, and
-            // everything the pixel loop needs (edge functions + clip-space vertices) is staged in LDS by the lane that found
-            // the hit -- parallel gathers instead of one dependent gather chain per triangle and pixel loop step
-            const int idx = r0 + lane;
-            bool hit = false;
-            uint2 ent = make_uint2(0u, 0u);
-            if (idx < n_big) {
-                ent = BL[idx];
-                const unsigned r = ent.y;
-                const int x0 = r & 255, y0 = (r >> 8) & 255, nx = (r >> 16) & 255, ny = r >> 24;
-                hit = tcx >= x0 && tcx <= x0 + nx && tcy >= y0 && tcy <= y0 + ny;
+        for (int c0 = 0; c0 < n_big; c0 += 256) {
+            // ---- (1) range test of 256 list entries at once (4 coalesced loads in flight, nothing dependent): the ids of the
+            // triangles whose packed tile range contains this tile, compacted into the wave's candidate list
+            int ncand = 0;
+            {
+                uint2 en[4];
+                bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = c0 + u * 64 + lane;
+                    en[u] = idx < n_big ? BL[idx] : make_uint2(0u, 0u);
+                    const unsigned r = en[u].y;
+                    const int x0 = r & 255, y0 = (r >> 8) & 255, nx = (r >> 16) & 255, ny = r >> 24;
+                    in[u] = idx < n_big && tcx >= x0 && tcx <= x0 + nx && tcy >= y0 && tcy <= y0 + ny;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long mu = __ballot(in[u]);
+                    if (in[u]) s_cand[wave][ncand + __popcll(mu & ((1ull << lane) - 1ull))] = (int)en[u].x;
+                    ncand += __popcll(mu);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
+        for (int r0 = 0; r0 < ncand; r0 += 64) {
+            // ---- (2) 64 candidates per round: exact refinement, and everything the pixel loop needs (edge functions +
+            // clip-space vertices) is staged in LDS by the lane that found the hit -- parallel gathers instead of one
+            // dependent gather chain per triangle and pixel loop step
+            const int idx = r0 + lane;
+            bool hit = idx < ncand;
+            uint2 ent = make_uint2(hit ? (unsigned)s_cand[wave][idx] : 0u, 0u);
             // the packed range is the triangle's bbox in tiles: refine with the exact edge predicate at the four corner
             // pixel centres of the tile -- all four outside one edge => no centre of the tile can be covered
             int i0 = 0, i1 = 0, i2 = 0;
@@ -614,6 +633,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // (the staging arrays are rewritten by the next round)
+        }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
