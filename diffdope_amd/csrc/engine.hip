@@ -116,6 +116,7 @@ struct ddx_engine {
     EngineDev dev;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    int graph_chunk = 1;  // iterations per captured graph
     hipStream_t side = nullptr;    // second branch of the iteration (mask role of the shading stage)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool setup_done = false;
@@ -1765,7 +1766,9 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
         hipStream_t cs;
         DDX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         DDX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        int err = run_iteration(e, cs, nullptr);
+        int err = 0;
+        e->graph_chunk = std::max(1, std::min(use_graph, 64));  // use_graph = iterations per captured graph
+        for (int k = 0; k < e->graph_chunk && !err; ++k) err = run_iteration(e, cs, nullptr);
         hipError_t ce = hipStreamEndCapture(cs, &e->graph);
         if (err || ce != hipSuccess) {
             (void)hipStreamDestroy(cs);
@@ -1775,11 +1778,13 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
         DDX_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
         DDX_HIP(hipStreamDestroy(cs));
     }
-    for (int i = 0; i < n; ++i) {
-        if (use_graph) {
+    for (int i = 0; i < n;) {
+        if (use_graph && i + e->graph_chunk <= n) {
             DDX_HIP(hipGraphLaunch(e->exec, s));
-        } else if (int err = run_iteration(e, s, nullptr)) {
-            return err;
+            i += e->graph_chunk;
+        } else {
+            if (int err = run_iteration(e, s, nullptr)) return err;
+            ++i;
         }
     }
     e->adam_parity = (it0 + n) & 1;

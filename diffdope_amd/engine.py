@@ -105,8 +105,8 @@ class RefineEngine:
 
     def run(self, n=None, use_graph=False):
         """Run n iterations (default: all remaining) asynchronously on the current stream.
-        use_graph=True replays one captured hipGraph per iteration; with 4 launches per iteration plain stream
-        launches measured ~5 % faster on MI355X, so that is the default."""
+        use_graph=k (or True = 1) replays a captured hipGraph of k iterations; with 4 launches per iteration plain
+        stream launches measured 9 % faster than k = 1 and equal to k = 20 on MI355X, so streams are the default."""
         n = self.max_iters - self.it if n is None else n
         _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
         self.it += n

@@ -58,7 +58,7 @@ def test_engine_graph_replay_equals_stream_launches_and_is_deterministic(w):
     sc = make_scene(16, 20, 60, 80, B=4, dist=1.8)
     lrs = [0.05] * 6
     outs = []
-    for use_graph in (False, True, True):
+    for use_graph in (False, True, True, 4):  # (4: graphs of 4 iterations + 2 iterations launched kernel by kernel)
         eng, params = _engine(sc, w, lrs)
         eng.run(use_graph=use_graph)
         torch.cuda.synchronize()
