@@ -196,8 +196,12 @@ def main():
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kms[dom],
+                         # what the kernel really moves (PMC HBM-side bytes of the committed profile / live duration):
+                         "traffic_GBps": (traffic / (kms[dom] * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "note": "algorithmic bytes = SURVEY 8(d) visibility-buffer model (full-frame G-buffer streams); this "
-                                 "engine touches active tiles only, so frac can exceed 1 -- see DESIGN.md and profiles/"},
+                                 "engine touches active tiles only, so frac can exceed 1 (traffic_frac_of_peak is the DRAM utilisation: the kernels "
+                                 "are bound by dependent-latency chains x resident workgroups, not by bytes) -- see DESIGN.md and profiles/"},
             "kernel_ms": kms, "kernel_ms_events": kms_ev, "stage_ms": groups,
             "final_pose": {"argmin_global_index": gidx, "argmin_loss": gloss,
                            "rot_err_rad_best": float(rot[lbest]), "trans_err_m_best": float(tr[lbest]), "add_m_best": float(add[lbest]),
