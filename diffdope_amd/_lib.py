@@ -59,6 +59,10 @@ _SIGNATURES = {
     "ddx_engine_run": (_I, [_P, _I, _I, _I, _P]),
     "ddx_engine_eval": (_I, [_P, _I, _P, _P, _P]),
     "ddx_select_best": (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    "ddx_render_loss_fwd": (_I, [_P, _I, _P, _P]),
+    "ddx_render_loss_bwd": (_I, [_P, _I, _P, _P]),
+    "ddx_sgd_step": (_I, [_P, _P, ctypes.c_float, _I, _P]),
+    "ddx_adam_step": (_I, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "ddx_engine_status_ptr": (_P, [_P]),
     "ddx_engine_profile": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I, _P]),
     "ddx_engine_destroy": (None, [_P]),

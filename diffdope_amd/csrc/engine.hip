@@ -107,6 +107,7 @@ struct EngineDev {
     int pslices;             // rows of the partial table per hypothesis: max(s_shade, s_edge) slices
     float* eval_grad;        // [7,B] or null.  Non-null = evaluation pass (ddx_engine_eval): d loss / d params and the
     float* eval_loss;        // [4,B] losses are written here, no optimiser step, no transform for a next iteration
+    float* eval_tmp;         // [7,B] gradient sink of ddx_render_loss_fwd
 #ifdef DDX_TRACE
     unsigned long long* trace;  // [4 kernels][8192 workgroups][4]: start, end (s_memtime), hw id, work units
 #endif
@@ -140,6 +141,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_mats = carve((size_t)2 * d.B * 32 * sizeof(float));
     const size_t o_adam = carve((size_t)2 * 14 * d.B * sizeof(float));
     const size_t o_par = carve((size_t)2 * 7 * d.B * sizeof(float));
+    const size_t o_etmp = carve((size_t)7 * d.B * sizeof(float));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_sgd = carve(d.use_depth ? (size_t)d.H * d.W * sizeof(float) : 0);
@@ -166,6 +168,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.mats = (float*)(p + o_mats);
     E.adam = (float*)(p + o_adam);
     E.params2 = (float*)(p + o_par);
+    E.eval_tmp = (float*)(p + o_etmp);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.seg_gd = (float*)(p + o_sgd);
@@ -1865,6 +1868,62 @@ extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* lo
     e->dev.eval_grad = nullptr;
     e->dev.eval_loss = nullptr;
     return err;
+}
+
+// SURVEY 8(b2) names for the fused pass: forward (losses) and backward (d loss / d params).  Forward and analytic backward
+// are ONE pass in this engine (the pixel's gradient is known as soon as it is shaded), so both run ddx_engine_eval.
+extern "C" int ddx_render_loss_fwd(ddx_engine* e, int it, float* loss_out, void* stream)
+{
+    DDX_REQUIRE(e && loss_out, DDX_E_NULL, "render_loss_fwd: NULL pointer");
+    return ddx_engine_eval(e, it, e->dev.eval_tmp, loss_out, stream);
+}
+
+extern "C" int ddx_render_loss_bwd(ddx_engine* e, int it, float* grad_out, void* stream)
+{
+    DDX_REQUIRE(e && grad_out, DDX_E_NULL, "render_loss_bwd: NULL pointer");
+    return ddx_engine_eval(e, it, grad_out, nullptr, stream);
+}
+
+// stand-alone optimiser steps over n floats (the engine's own loop has them fused into update_xfm_kernel)
+__global__ void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float lr, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = p[i] - lr * g[i];
+}
+
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 float lr, float b1, float b2, float eps, int step, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // (the expressions of update_xfm_kernel, so a caller stepping with this gets the engine's trajectory bit for bit)
+    const float c1 = 1.f - exp2f((float)step * log2f(b1)), c2 = 1.f - exp2f((float)step * log2f(b2));
+    const float gi = g[i];
+    const float m1 = b1 * m[i] + (1.f - b1) * gi;
+    const float m2 = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = m1; v[i] = m2;
+    p[i] = p[i] - lr * (m1 / c1) / (sqrtf(m2 / c2) + eps);
+}
+
+extern "C" int ddx_sgd_step(float* params, const float* grad, float lr, int n, void* stream)
+{
+    DDX_REQUIRE(params && grad, DDX_E_NULL, "sgd_step: NULL pointer");
+    DDX_REQUIRE(n >= 0, DDX_E_SHAPE, "sgd_step: n = %d", n);
+    if (n == 0) return 0;
+    sgd_step_kernel<<<ddx_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(params, grad, lr, n);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                             float eps, int step, int n, void* stream)
+{
+    DDX_REQUIRE(params && grad && exp_avg && exp_avg_sq, DDX_E_NULL, "adam_step: NULL pointer");
+    DDX_REQUIRE(n >= 0 && step >= 1, DDX_E_SHAPE, "adam_step: n = %d, step = %d (steps count from 1)", n, step);
+    if (n == 0) return 0;
+    adam_step_kernel<<<ddx_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(params, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, n);
+    DDX_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" const int32_t* ddx_engine_status_ptr(ddx_engine* e) { return e ? &e->dev.st->overflow : nullptr; }

@@ -181,6 +181,19 @@ int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
  * are left untouched.  loss = sum_k sum_b lr_mult[b] * loss_out[k,b] / B_global  (diffdope.py:534-613);
  * `it` only selects the mtx_log row the pose matrices are logged to. */
 int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* loss_out, void* stream);
+/* The fused pass under the names of a forward / backward pair (what a torch.autograd.Function around the loss of
+ * diffdope.py:1707-1711 binds): ddx_render_loss_fwd writes the weighted per-hypothesis losses [4,B], ddx_render_loss_bwd
+ * d loss / d params [7,B] (the 7 nn.Parameters of diffdope.py:1019-1026).  Forward and analytic backward are ONE pass in
+ * this engine, so each call runs it (= ddx_engine_eval); a caller that needs both calls ddx_engine_eval once. */
+int ddx_render_loss_fwd(ddx_engine* e, int it, float* loss_out, void* stream);
+int ddx_render_loss_bwd(ddx_engine* e, int it, float* grad_out, void* stream);
+/* Stand-alone optimiser steps over n floats (params [7,B] -> n = 7 B), for callers that run the evaluation pass and step
+ * themselves: p -= lr g (torch.optim.SGD as diffdope.py:1642-1644 uses it; lr from the schedule of :1657-1664), and Adam
+ * (torch.optim.Adam update, bias correction with step counted from 1; the engine's own fused update uses the same
+ * expressions).  ddx_engine_run has both fused into its last kernel. */
+int ddx_sgd_step(float* params, const float* grad, float lr, int n, void* stream);
+int ddx_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                  int step, int n, void* stream);
 /* get_argmin / get_pose (diffdope.py:1488-1513,1618-1632) for the local hypotheses, on the device:
  * loss_rows [4,B] (one row of loss_log), row_mask bit r = loss row r takes part in the mean, mtx [B,16],
  * lo = global index of the first local hypothesis; out18 = (mean loss of the winner, its global index, its 4x4
