@@ -54,6 +54,8 @@ _SIGNATURES = {
     "ddx_topology_build": (_I, [_P, _I, _P]),
     "ddx_antialias_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ddx_antialias_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ddx_masked_l1_fwd": (_I, [_P, _P, _P, _I, _I, _LL, _P, _P, _P]),
+    "ddx_masked_l1_bwd": (_I, [_P, _P, _P, _I, _P, _I, _LL, _P, _P]),
     "ddx_engine_scratch_bytes": (_SZ, [ctypes.POINTER(EngineDesc)]),
     "ddx_engine_create": (_I, [ctypes.POINTER(EngineDesc), ctypes.POINTER(EngineBuffers), ctypes.POINTER(_P)]),
     "ddx_engine_run": (_I, [_P, _I, _I, _I, _P]),

@@ -24,7 +24,7 @@ from . import io_img, io_ply
 from . import ops as dd_ops
 from .engine import RefineEngine
 from .pose import matrix_batch_44_from_position_quat
-from .render import RasterizeGLContext, render_texture_batch
+from .render import RasterizeGLContext, masked_l1_mean, render_texture_batch
 
 log = logging.getLogger(__name__)
 
@@ -108,25 +108,24 @@ def dist_batch_lr(tensor, learning_rates, channels=[1, 2, 3]):
 
 
 def l1_rgb_with_mask(ddope):
-    diff_rgb = torch.abs((ddope.renders["rgb"] - ddope.gt_tensors["rgb"]) * ddope.gt_tensors["segmentation"])
-    lr_diff_rgb = dist_batch_lr(diff_rgb, ddope.learning_rates)
-    ddope.add_loss_value("rgb", torch.mean(diff_rgb.detach(), (1, 2, 3)) * ddope.cfg.losses.weight_rgb)
-    return lr_diff_rgb.mean() * ddope.cfg.losses.weight_rgb
+    """diffdope.py:547-562 (image-space part fused for ROCm tensors: render.masked_l1_mean)."""
+    v = masked_l1_mean(ddope.renders["rgb"], ddope.gt_tensors["rgb"], ddope.gt_tensors["segmentation"])
+    ddope.add_loss_value("rgb", v.detach() * ddope.cfg.losses.weight_rgb)
+    return (v * ddope.learning_rates).mean() * ddope.cfg.losses.weight_rgb
 
 
 def l1_depth_with_mask(ddope):
-    diff_depth = torch.abs((ddope.renders["depth"] - ddope.gt_tensors["depth"]) * ddope.gt_tensors["segmentation"][..., 0])
-    lr_diff_depth = dist_batch_lr(diff_depth, ddope.learning_rates, [1, 2])
-    ddope.add_loss_value("depth", torch.mean(diff_depth.detach(), (1, 2)) * ddope.cfg.losses.weight_depth)
-    return lr_diff_depth.mean() * ddope.cfg.losses.weight_depth
+    """diffdope.py:565-580."""
+    v = masked_l1_mean(ddope.renders["depth"], ddope.gt_tensors["depth"], ddope.gt_tensors["segmentation"], mask_channel0=True)
+    ddope.add_loss_value("depth", v.detach() * ddope.cfg.losses.weight_depth)
+    return (v * ddope.learning_rates).mean() * ddope.cfg.losses.weight_depth
 
 
 def l1_mask(ddope):
-    mask = ddope.renders["mask"]
-    diff_mask = torch.abs(mask - ddope.gt_tensors["segmentation"])
-    lr_diff_mask = dist_batch_lr(diff_mask, ddope.learning_rates)
-    ddope.add_loss_value("mask_selection", torch.mean(torch.abs(diff_mask.detach()), (1, 2, 3)) * ddope.cfg.losses.weight_mask)
-    return lr_diff_mask.mean() * ddope.cfg.losses.weight_mask
+    """diffdope.py:583-613."""
+    v = masked_l1_mean(ddope.renders["mask"], ddope.gt_tensors["segmentation"])
+    ddope.add_loss_value("mask_selection", v.detach() * ddope.cfg.losses.weight_mask)
+    return (v * ddope.learning_rates).mean() * ddope.cfg.losses.weight_mask
 
 
 _SOBEL = None

@@ -296,3 +296,76 @@ extern "C" int ddx_antialias_bwd(const float* color, int C, const float* rast, c
     DDX_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Masked L1 mean per hypothesis -- the image-space part of l1_rgb_with_mask / l1_depth_with_mask / l1_mask
+// (diffdope.py:547-613) for the materialising op-by-op path: out[b] = mean_i |(x[b,i] - y[i]) * m[i * m_stride]| with the
+// observed image y and mask m shared by all hypotheses (m == NULL: no mask).  In torch the expression is ~10 full-frame
+// element-wise / reduction kernels forward and as many backward, each a round trip through HBM of a [B,H,W,3] tensor; here
+// the forward reads x once and the backward writes d x once.  Fixed two-stage reduction order: bit-reproducible.
+#define ML1_CHUNKS 128
+__global__ __launch_bounds__(256) void masked_l1_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ m, int m_stride, long long N,
+                                                                float* __restrict__ partial)
+{
+    const int b = blockIdx.y, c = blockIdx.x;
+    const long long per = (N + ML1_CHUNKS - 1) / ML1_CHUNKS;
+    const long long i0 = (long long)c * per, i1 = i0 + per < N ? i0 + per : N;
+    const float* xb = x + (size_t)b * N;
+    float acc = 0.f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float mk = m ? m[i * m_stride] : 1.0f;
+        acc += fabsf((xb[i] - y[i]) * mk);
+    }
+    acc = wave_sum(acc);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * ML1_CHUNKS + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(ML1_CHUNKS) void masked_l1_final_kernel(const float* __restrict__ partial, long long N, float* __restrict__ out)
+{
+    const int b = blockIdx.x;
+    float v = partial[(size_t)b * ML1_CHUNKS + threadIdx.x];
+    v = wave_sum(v);
+    __shared__ float red[2];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = __fdiv_rn(red[0] + red[1], (float)N);
+}
+
+__global__ __launch_bounds__(256) void masked_l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ m, int m_stride, const float* __restrict__ gout,
+                                                            long long N, long long total, float* __restrict__ dx)
+{
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long long)gridDim.x * 256) {
+        const long long b = j / N, i = j - b * N;
+        const float mk = m ? m[i * m_stride] : 1.0f;
+        const float d = (x[j] - y[i]) * mk;
+        const float sg = (float)((d > 0.f) - (d < 0.f));
+        dx[j] = sg * mk * (gout[b] / (float)N);
+    }
+}
+
+extern "C" int ddx_masked_l1_fwd(const float* x, const float* y, const float* m, int m_stride, int B, long long N, float* partial,
+                                 float* out, void* stream)
+{
+    DDX_REQUIRE(x && y && partial && out, DDX_E_NULL, "masked_l1_fwd: NULL pointer");
+    DDX_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && m_stride >= 1, DDX_E_SHAPE, "masked_l1_fwd: bad shape B=%d N=%lld stride=%d", B, N, m_stride);
+    masked_l1_partial_kernel<<<dim3(ML1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, N, partial);
+    masked_l1_final_kernel<<<B, ML1_CHUNKS, 0, (hipStream_t)stream>>>(partial, N, out);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_masked_l1_bwd(const float* x, const float* y, const float* m, int m_stride, const float* gout, int B, long long N,
+                                 float* dx, void* stream)
+{
+    DDX_REQUIRE(x && y && gout && dx, DDX_E_NULL, "masked_l1_bwd: NULL pointer");
+    DDX_REQUIRE(B >= 1 && N >= 1 && m_stride >= 1, DDX_E_SHAPE, "masked_l1_bwd: bad shape");
+    const long long total = (long long)B * N;
+    masked_l1_bwd_kernel<<<PIX_GRID(total), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, gout, N, total, dx);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}

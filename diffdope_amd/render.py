@@ -286,6 +286,52 @@ def antialias_construct_topology_hash(tri):
 
 
 # ------------------------------------------------------------------------------------------------
+class _masked_l1_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, m, m_stride):
+        B = x.shape[0]
+        N = x[0].numel()
+        out = torch.empty((B,), dtype=torch.float32, device=x.device)
+        partial = torch.empty((B, 128), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().ddx_masked_l1_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(m) if m is not None else None, int(m_stride), B, N,
+                                                 _lib.ptr(partial), _lib.ptr(out), _lib.stream_ptr()), "ddx_masked_l1_fwd")
+        ctx.save_for_backward(x, y, m)
+        ctx.m_stride = int(m_stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, m = ctx.saved_tensors
+        B = x.shape[0]
+        N = x[0].numel()
+        gout = _f32c(gout, "gout")
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().ddx_masked_l1_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(m) if m is not None else None, ctx.m_stride,
+                                                 _lib.ptr(gout), B, N, _lib.ptr(dx), _lib.stream_ptr()), "ddx_masked_l1_bwd")
+        return dx, None, None, None
+
+
+def masked_l1_mean(x, y, mask=None, mask_channel0=False):
+    """mean over all but the batch axis of |(x - y) * mask| -> [B]: the image-space part of the reference's built-in losses
+    (diffdope.py:547-613) as ONE forward and ONE backward kernel for ROCm tensors.  x [B,...]; y and mask describe ONE observed
+    image (shape x.shape[1:], or batched views of it with batch stride 0, or a batch of size 1); mask_channel0: mask is [...,3] and
+    its channel 0 masks an x without channel axis (l1_depth_with_mask).  Other inputs take the torch expression."""
+    def one(t):
+        if t is None:
+            return None
+        if t.dim() == x.dim() and (t.shape[0] == 1 or t.stride(0) == 0):
+            t = t[0]
+        return t
+    y1, m1 = one(y), one(mask)
+    tail = tuple(x.shape[1:])
+    fusable = (x.is_cuda and x.dtype == torch.float32 and tuple(y1.shape) == tail and y1.dtype == torch.float32
+               and (m1 is None or (m1.dtype == torch.float32 and tuple(m1.shape) == (tail + (3,) if mask_channel0 else tail))))
+    if not fusable:
+        mk = 1.0 if mask is None else (mask[..., 0] if mask_channel0 else mask)
+        return torch.mean(torch.abs((x - y) * mk), tuple(range(1, x.dim())))
+    return _masked_l1_func.apply(x.contiguous(), y1.contiguous(), None if m1 is None else m1.contiguous(), 3 if mask_channel0 else 1)
+
+
 def _interpolate_wrapper(attr, rast, attr_idx, rast_db=None):
     """diffdope.py:143-153"""
     return interpolate(attr.contiguous(), rast, attr_idx, rast_db=rast_db, diff_attrs=None if rast_db is None else "all")

@@ -116,6 +116,15 @@ int ddx_antialias_bwd(const float* color, int C, const float* rast, const float*
                       const int32_t* opp, int B, int V, int T, int H, int W, const float* dout,
                       float* dcolor, float* dpos, void* stream);
 
+/* Image-space part of the built-in losses for the op-by-op path (diffdope.py:547-613: l1_rgb_with_mask :547-562,
+ * l1_depth_with_mask :565-580, l1_mask :583-613): out[b] = mean_i |(x[b,i] - y[i]) * m[i * m_stride]|, with the observed image y [N]
+ * and mask m shared by the B hypotheses (m NULL = no mask; m_stride 3 reads channel 0 of a [H,W,3] mask for a [H,W] depth image).
+ * partial: caller scratch [B,128] floats.  Backward: dx[b,i] = sign(.) * m * gout[b] / N.  Fixed reduction order. */
+int ddx_masked_l1_fwd(const float* x, const float* y, const float* m, int m_stride, int B, long long N, float* partial, float* out,
+                      void* stream);
+int ddx_masked_l1_bwd(const float* x, const float* y, const float* m, int m_stride, const float* gout, int B, long long N, float* dx,
+                      void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused refinement engine: the body of DiffDope.run_optimization (diffdope.py:1656-1714) for the
  * built-in losses (l1_rgb_with_mask / l1_depth_with_mask / l1_mask, diffdope.py:547-613):

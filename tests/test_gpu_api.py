@@ -173,3 +173,29 @@ def test_deferred_runs_on_separate_streams_equal_blocking_runs():
         d.finish_optimization()
         assert torch.equal(d.object3d.params_tensor(), p)
         assert set(d.losses_values) == set(lv) and all(torch.equal(d.losses_values[k], lv[k]) for k in lv)
+
+
+def test_masked_l1_mean_matches_the_torch_expression():
+    """render.masked_l1_mean (one forward + one backward kernel) against the reference's torch expressions
+    (diffdope.py:547-613), values and gradients, incl. batched stride-0 views of the observed image and the
+    channel-0 mask of the depth term."""
+    from diffdope_amd.render import masked_l1_mean
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B, H, W = 5, 37, 53
+    seg = (torch.rand(1, H, W, 3, device="cuda", generator=g) > 0.4).float()
+    for shape, ch0 in (((B, H, W, 3), False), ((B, H, W), True)):
+        x = torch.randn(shape, device="cuda", generator=g, requires_grad=True)
+        y = torch.randn((1,) + shape[1:], device="cuda", generator=g)
+        yb, sb = y.expand(shape), seg.expand(B, H, W, 3)  # batch stride 0, as DiffDope holds its gt tensors
+        lr = torch.rand(B, device="cuda", generator=g)
+        ref = torch.mean(torch.abs((x - yb) * (sb[..., 0] if ch0 else sb)), tuple(range(1, x.dim())))
+        out = masked_l1_mean(x, yb, sb, mask_channel0=ch0)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6)
+        g_ref, = torch.autograd.grad((ref * lr).mean(), x)
+        g_out, = torch.autograd.grad((out * lr).mean(), x)
+        np.testing.assert_allclose(g_out.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-6, atol=1e-12)
+    x = torch.rand((B, H, W, 3), device="cuda", generator=g, requires_grad=True)
+    ref = torch.mean(torch.abs(x - seg), (1, 2, 3))
+    out = masked_l1_mean(x, seg)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6)

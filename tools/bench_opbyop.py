@@ -6,7 +6,7 @@ import diffdope_amd as dd
 from diffdope_amd import workloads as wl
 from diffdope_amd.render import RasterizeContext, render_texture_batch
 
-cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+cfg = next((a for a in sys.argv[1:] if not a.startswith('--')), 'cfg2')
 dev = torch.device('cuda:0')
 w = wl.build(cfg, dev)
 B, H, W = w['B'], w['H'], w['W']
@@ -18,17 +18,28 @@ gt = {k: v[None] for k, v in w['gt'].items()}
 lr_mult = w['lr_mult']
 wt = w['weights']
 
+from diffdope_amd.render import masked_l1_mean
+FUSED_LOSS = '--torch-losses' not in sys.argv  # the built-in loss functions use render.masked_l1_mean; --torch-losses: the plain expressions
+
 def step():
     q = params[:4].T / torch.norm(params[:4].T, dim=1, keepdim=True)
     mtx = dd.matrix_batch_44_from_position_quat(q=q, p=params[4:].T)
     r = render_texture_batch(ctx, ex(w['proj']), mtx, ex(w['pos']), ex(w['tri']), [H, W], **kw)
     loss = 0
-    if wt.get('rgb') is not None:
-        loss = loss + (torch.abs((r['rgb'] - gt['rgb']) * gt['segmentation']).mean((1, 2, 3)) * lr_mult).mean() * wt['rgb']
-    if wt.get('depth') is not None:
-        loss = loss + (torch.abs((r['depth'] - gt['depth']) * gt['segmentation'][..., 0]).mean((1, 2)) * lr_mult).mean() * wt['depth']
-    if wt.get('mask') is not None:
-        loss = loss + (torch.abs(r['mask'] - gt['segmentation']).mean((1, 2, 3)) * lr_mult).mean() * wt['mask']
+    if FUSED_LOSS:
+        if wt.get('rgb') is not None:
+            loss = loss + (masked_l1_mean(r['rgb'], gt['rgb'], gt['segmentation']) * lr_mult).mean() * wt['rgb']
+        if wt.get('depth') is not None:
+            loss = loss + (masked_l1_mean(r['depth'], gt['depth'], gt['segmentation'], mask_channel0=True) * lr_mult).mean() * wt['depth']
+        if wt.get('mask') is not None:
+            loss = loss + (masked_l1_mean(r['mask'], gt['segmentation']) * lr_mult).mean() * wt['mask']
+    else:
+        if wt.get('rgb') is not None:
+            loss = loss + (torch.abs((r['rgb'] - gt['rgb']) * gt['segmentation']).mean((1, 2, 3)) * lr_mult).mean() * wt['rgb']
+        if wt.get('depth') is not None:
+            loss = loss + (torch.abs((r['depth'] - gt['depth']) * gt['segmentation'][..., 0]).mean((1, 2)) * lr_mult).mean() * wt['depth']
+        if wt.get('mask') is not None:
+            loss = loss + (torch.abs(r['mask'] - gt['segmentation']).mean((1, 2, 3)) * lr_mult).mean() * wt['mask']
     g, = torch.autograd.grad(loss, params)
     with torch.no_grad():
         params.sub_(1e-3 * g)
@@ -38,4 +49,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 20
 for _ in range(n): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f'{cfg}: op-by-op path {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s  (peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB)')
+print(f'{cfg} ({"fused masked-L1 losses" if FUSED_LOSS else "torch loss expressions"}): op-by-op path {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s  (peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB)')
