@@ -208,7 +208,7 @@ def main():
                            "rot_err_rad_median": float(np.median(rot)), "trans_err_m_median": float(np.median(tr))},
             "engine_status": st,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (the CPU leg is timed on rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
     if use_dist:
