@@ -25,7 +25,8 @@ class EngineDesc(ctypes.Structure):
         ("optimizer", ctypes.c_int32),
         ("adam_beta1", ctypes.c_float), ("adam_beta2", ctypes.c_float), ("adam_eps", ctypes.c_float),
         ("max_iters", ctypes.c_int32), ("use_edge", ctypes.c_int32), ("w_edge", ctypes.c_float),
-        ("reserved", ctypes.c_int32 * 6),
+        ("shade_slices", ctypes.c_int32), ("edge_slices", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 

@@ -118,8 +118,6 @@ struct ddx_engine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int graph_chunk = 1;  // iterations per captured graph
-    hipStream_t side = nullptr;    // second branch of the iteration (mask role of the shading stage)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool setup_done = false;
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
 };
@@ -1443,7 +1441,7 @@ static const char* const kKernelNames[K_COUNT] = {"scatter_kernel", "compact_big
 // shading grid (B, S): S slices per hypothesis, SHADE_GRID workgroups per role in total (all resident at 4 waves/SIMD)
 static dim3 shade_grid(const ddx_engine_desc& d)
 {
-    int S = SHADE_GRID / d.B;
+    int S = d.shade_slices > 0 ? d.shade_slices : SHADE_GRID / d.B;
     if (S < 1) S = 1;
     if (S > 64) S = 64;
     return dim3(d.B, S);
@@ -1462,7 +1460,7 @@ static int upd_slices(const ddx_engine_desc& d)
 // edge_kernel: 66 VGPRs, 7 waves/SIMD, so more resident workgroups than the shade kernel has
 static dim3 edge_grid(const ddx_engine_desc& d)
 {
-    int S = EDGE_GRID / d.B;
+    int S = d.edge_slices > 0 ? d.edge_slices : EDGE_GRID / d.B;
     if (S < 1) S = 1;
     if (S > 64) S = 64;
     return dim3(d.B, S);
@@ -1576,12 +1574,6 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     if (b.scratch_bytes < need) {
         delete e;
         DDX_REQUIRE(false, DDX_E_SCRATCH, "engine_create: scratch %zu < required %zu bytes", b.scratch_bytes, need);
-    }
-    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
-        ddx_engine_destroy(e);
-        DDX_REQUIRE(false, 1, "engine_create: could not create the side stream / events");
     }
 #ifdef DDX_TRACE
     DDX_HIP(hipMalloc(&e->dev.trace, (size_t)4 * 8192 * 4 * 8));
@@ -1964,8 +1956,5 @@ extern "C" void ddx_engine_destroy(ddx_engine* e)
     if (!e) return;
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
 }

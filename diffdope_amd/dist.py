@@ -41,7 +41,7 @@ def global_argmin(per_hyp_loss, mtx, lo=0, group=None):
     table[rank, 0] = loss
     table[rank, 1] = (idx + lo).to(table.dtype)
     table[rank, 2:] = m.to(table.dtype)
-    if world > 1:
+    if dist.is_initialized():  # (also with one rank: the collective path is the same code at every world size)
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     # row arg-min, ties -> lowest global index
     losses, gidx = table[:, 0], table[:, 1]
@@ -67,7 +67,7 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
     table = torch.zeros((world, 18), dtype=torch.float32, device=loss_rows.device)
     _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table[rank].data_ptr(),
                                    _lib.stream_ptr()), "ddx_select_best")
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     t = table.cpu()  # the one synchronisation
     losses, gidx = t[:, 0], t[:, 1]
@@ -81,6 +81,6 @@ def merge_object_tables(table, group=None):
     object i and zero elsewhere, so a single all_reduce(SUM) gives every rank the complete table."""
     import torch.distributed as dist
 
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     return table

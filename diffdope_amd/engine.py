@@ -41,10 +41,13 @@ class RefineEngine:
         weights: dict(rgb=, depth=, mask=, edge=) -- None/absent disables the term (cfg.losses); "edge" is this
             build's extension (Sobel-gradient L1 of the luminance, no reference counterpart: oracle orc_loss_edge)
         global_batch: batch size of the whole job when hypotheses are sharded over GPUs
+        shade_slices / edge_slices: workgroups per hypothesis of the shading / edge launches (0 = from B).  A shard
+            that must reproduce the unsharded run bit for bit passes the unsharded engine's `slices` (ddx.h)
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
-                 vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True):
+                 vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True, shade_slices=0,
+                 edge_slices=0):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":
@@ -83,6 +86,7 @@ class RefineEngine:
         d.optimizer = {"sgd": 0, "adam": 1}[optimizer]
         d.adam_beta1, d.adam_beta2, d.adam_eps = adam
         d.max_iters = n_it
+        d.shade_slices, d.edge_slices = int(shade_slices), int(edge_slices)
         self.desc = d
         nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))
         if nbytes == 0:
@@ -127,6 +131,12 @@ class RefineEngine:
         gets its gradient from the analytic backward of the kernels, so any torch optimiser can drive the fused path:
             opt = torch.optim.Adam([p], lr=1e-2);  loss = eng.loss(p);  loss.backward();  opt.step()"""
         return _FusedLoss.apply(self.params if params is None else params, self)
+
+    @property
+    def slices(self):
+        """(shade_slices, edge_slices) this engine runs with: what a shard of this batch passes to reproduce it bitwise."""
+        auto = lambda grid: max(1, min(64, grid // self.B))
+        return (self.desc.shade_slices or auto(1024), self.desc.edge_slices or auto(1792))
 
     def rewind(self, it=0):
         self.it = it

@@ -1,7 +1,9 @@
 """Minimal PLY reader (ASCII and binary little/big endian) -- stands in for trimesh.load(path, force="mesh")
 at diffdope/diffdope.py:784 (trimesh is not a dependency of this build).  Reads vertex positions, optional
-normals, texture coordinates (texture_u/texture_v, s/t or u/v), vertex colours, polygon faces (fan
-triangulated) and the `comment TextureFile <name>` header MeshLab/Blender write."""
+normals, texture coordinates (per vertex: texture_u/texture_v, s/t or u/v; or per face corner: the face element's
+`property list uchar float texcoord` that MeshLab writes for wedge UVs -- vertices are then un-merged per distinct
+(vertex, uv) pair, as trimesh does), vertex colours, polygon faces (fan triangulated) and the
+`comment TextureFile <name>` header MeshLab/Blender write."""
 import os
 
 import numpy as np
@@ -10,6 +12,11 @@ _TYPES = {
     "char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
     "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8",
 }
+
+
+def _list_dtype(item_type):
+    """numpy dtype list items are held in: the declared item type decides (indices int64, texcoords float64)."""
+    return np.float64 if item_type[0] == "f" else np.int64
 
 
 def read_ply(path):
@@ -57,7 +64,7 @@ def read_ply(path):
                     for p in el["props"]:
                         if "list" in p:
                             k = int(tokens[pos]); pos += 1
-                            rows[p["name"]].append(np.array(tokens[pos:pos + k], dtype=np.int64)); pos += k
+                            rows[p["name"]].append(np.array(tokens[pos:pos + k], dtype=_list_dtype(p["list"][1]))); pos += k
                         else:
                             rows[p["name"]].append(float(tokens[pos])); pos += 1
                 out[el["name"]] = rows
@@ -78,7 +85,7 @@ def read_ply(path):
                         if "list" in p:
                             ct, it = np.dtype(bo + p["list"][0]), np.dtype(bo + p["list"][1])
                             k = int(np.frombuffer(data, ct, 1, off)[0]); off += ct.itemsize
-                            rows[p["name"]].append(np.frombuffer(data, it, k, off).astype(np.int64)); off += it.itemsize * k
+                            rows[p["name"]].append(np.frombuffer(data, it, k, off).astype(_list_dtype(p["list"][1]))); off += it.itemsize * k
                         else:
                             t = np.dtype(bo + p["type"])
                             rows[p["name"]].append(float(np.frombuffer(data, t, 1, off)[0])); off += t.itemsize
@@ -100,6 +107,27 @@ def read_ply(path):
             for i in range(1, len(poly) - 1):  # fan triangulation
                 faces.append((poly[0], poly[i], poly[i + 1]))
     faces = np.array(faces, dtype=np.int32).reshape(-1, 3)
+    # per-face-corner ("wedge") texture coordinates: un-merge the vertices, one per distinct (vertex, u, v)
+    tkey = next((k for k in ("texcoord", "texcoords", "uv") if k in fe), None)
+    if tkey is not None and key is not None and len(faces):
+        corner_v, corner_uv = [], []
+        for poly, tc in zip(fe[key], fe[tkey]):
+            tc = np.asarray(tc, np.float64).reshape(-1, 2)
+            if len(tc) != len(poly):
+                raise ValueError(f"{path}: face with {len(poly)} vertices carries {len(tc)} texture coordinates")
+            for i in range(1, len(poly) - 1):
+                for c in (0, i, i + 1):
+                    corner_v.append(int(poly[c]))
+                    corner_uv.append(tc[c])
+        corner_v = np.asarray(corner_v, np.int64)
+        corner_uv = np.asarray(corner_uv, np.float32).reshape(-1, 2)
+        rec = np.concatenate([corner_v[:, None].astype(np.float64), corner_uv.astype(np.float64)], 1)
+        uniq, inverse = np.unique(rec, axis=0, return_inverse=True)
+        src = uniq[:, 0].astype(np.int64)
+        pos, uv = pos[src], uniq[:, 1:].astype(np.float32)
+        normals = None if normals is None else normals[src]
+        colors = None if colors is None else colors[src]
+        faces = np.asarray(inverse, np.int32).reshape(-1, 3)
     if texture_file is not None:
         texture_file = os.path.join(os.path.dirname(os.path.abspath(path)), texture_file)
     return dict(pos=pos, faces=faces, normals=normals, uv=uv, colors=colors, texture_file=texture_file)

@@ -8,10 +8,12 @@ csrc/renderops.hip), plus `render_texture_batch` (diffdope.py:156-234) written a
     texture(tex, uv, uv_da, filter_mode="linear")     -> out
     antialias(color, rast, pos, tri)          -> out
 
-Differences that are visible to callers: the pixel-derivative outputs (`rast_db`, `out_da`) are
-zero-stride zero placeholders (diff-dope discards them or feeds them to texture(..., "linear") which
-ignores them); only filter_mode="linear" / boundary wrap is implemented; everything needs ROCm
-tensors (no CPU fallback).
+Differences that are visible to callers: the pixel-derivative outputs (`rast_db`, `out_da`) are NOT computed --
+diff-dope discards them or hands them to texture(..., "linear"), which ignores them (diffdope.py:212-226).  They
+are returned as `PixelDerivativesNotComputed` placeholders of the right shape that can be passed around (to
+interpolate / texture, as the reference does) but raise RuntimeError as soon as any arithmetic, indexing or copy
+consumes them, so a user loss that relies on them fails loudly instead of reading zeros; only filter_mode="linear" /
+boundary wrap is implemented (mip-mapped filtering raises); everything needs ROCm tensors (no CPU fallback).
 """
 import numpy as np
 import torch
@@ -36,6 +38,34 @@ def _i32c(t, name):
     if t.dim() != 2 or t.shape[1] != 3:
         raise RuntimeError(f"{name} must be [num_triangles, 3], got {tuple(t.shape)}")
     return t.contiguous()
+
+
+class PixelDerivativesNotComputed(torch.Tensor):
+    """Shape-only stand-in for nvdiffrast's screen-space derivative outputs (rast_db of dr.rasterize, the second output of
+    dr.interpolate with diff_attrs): inspecting it (shape, dtype, device, repr) and passing it on is fine, computing with it
+    raises."""
+
+    _PASSIVE = {"__get__", "size", "dim", "stride", "__repr__", "__len__", "numel", "is_contiguous", "__format__", "__str__",
+                "data_ptr", "storage_offset", "is_floating_point", "element_size", "_is_view", "__hash__", "ndimension", "nelement"}
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        name = getattr(func, "__name__", str(func))
+        if name in cls._PASSIVE:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **(kwargs or {}))
+        raise RuntimeError(
+            f"{name}: pixel derivatives (rast_db / diff_attrs outputs) are not computed by diffdope_amd -- diff-dope never consumes "
+            "them (diffdope.py:212-226) and only filter_mode='linear' texture sampling is implemented")
+
+    def __repr__(self):
+        with torch._C.DisableTorchFunctionSubclass():
+            return f"PixelDerivativesNotComputed(shape={tuple(self.shape)})"
+
+
+def _not_computed(shape, device):
+    z = torch.zeros((1,) * len(shape), dtype=torch.float32, device=device).expand(*shape)
+    return z.as_subclass(PixelDerivativesNotComputed)
 
 
 class RasterizeContext:
@@ -79,12 +109,10 @@ class _rasterize_func(torch.autograd.Function):
                                          _lib.ptr(rast), _lib.stream_ptr()), "ddx_rasterize_fwd")
         ctx.save_for_backward(pos, tri, rast)
         ctx.res = (H, W)
-        rast_db = torch.zeros((1, 1, 1, 4), dtype=torch.float32, device=pos.device).expand(B, H, W, 4)
-        ctx.mark_non_differentiable(rast_db)
-        return rast, rast_db
+        return rast
 
     @staticmethod
-    def backward(ctx, drast, _ddb):
+    def backward(ctx, drast):
         pos, tri, rast = ctx.saved_tensors
         H, W = ctx.res
         B, V, T = pos.shape[0], pos.shape[1], tri.shape[0]
@@ -96,10 +124,12 @@ class _rasterize_func(torch.autograd.Function):
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
-    """dr.rasterize (diffdope.py:198-200).  Returns (rast [B,H,W,4] = (u,v,z/w,tri_id+1), rast_db placeholder)."""
+    """dr.rasterize (diffdope.py:198-200).  Returns (rast [B,H,W,4] = (u,v,z/w,tri_id+1), rast_db placeholder that raises
+    when consumed)."""
     if ranges is not None:
         raise RuntimeError("range mode is not implemented (diff-dope uses instanced mode only)")
-    return _rasterize_func.apply(glctx, pos, tri, resolution)
+    rast = _rasterize_func.apply(glctx, pos, tri, resolution)
+    return rast, _not_computed(tuple(rast.shape), rast.device)
 
 
 class _interpolate_func(torch.autograd.Function):
@@ -151,11 +181,13 @@ class _interpolate_func(torch.autograd.Function):
 
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
-    """dr.interpolate (diffdope.py:147-153).  Returns (out [B,H,W,A], out_da placeholder)."""
+    """dr.interpolate (diffdope.py:147-153).  Returns (out [B,H,W,A], out_da): out_da is the empty [B,H,W,0] tensor
+    nvdiffrast returns without diff_attrs, and with diff_attrs a [B,H,W,2A] placeholder that raises when consumed (rast_db is
+    accepted and ignored)."""
     out = _interpolate_func.apply(attr, rast, tri)
     if rast_db is not None and diff_attrs is not None:
-        A = out.shape[-1]
-        out_da = torch.zeros((1, 1, 1, 1), dtype=torch.float32, device=out.device).expand(*out.shape[:3], 2 * A)
+        n = out.shape[-1] if isinstance(diff_attrs, str) else len(diff_attrs)
+        out_da = _not_computed(tuple(out.shape[:3]) + (2 * n,), out.device)
     else:
         out_da = torch.zeros((out.shape[0], out.shape[1], out.shape[2], 0), dtype=torch.float32, device=out.device)
     return out, out_da
@@ -316,13 +348,14 @@ def masked_l1_mean(x, y, mask=None, mask_channel0=False):
     (diffdope.py:547-613) as ONE forward and ONE backward kernel for ROCm tensors.  x [B,...]; y and mask describe ONE observed
     image (shape x.shape[1:], or batched views of it with batch stride 0, or a batch of size 1); mask_channel0: mask is [...,3] and
     its channel 0 masks an x without channel axis (l1_depth_with_mask).  Other inputs take the torch expression."""
-    def one(t):
+    def one(t, rank):
+        # strip a broadcast batch axis: `rank` is the rank the tensor has WITH a batch axis
         if t is None:
             return None
-        if t.dim() == x.dim() and (t.shape[0] == 1 or t.stride(0) == 0):
+        if t.dim() == rank and (t.shape[0] == 1 or t.stride(0) == 0):
             t = t[0]
         return t
-    y1, m1 = one(y), one(mask)
+    y1, m1 = one(y, x.dim()), one(mask, x.dim() + 1 if mask_channel0 else x.dim())
     tail = tuple(x.shape[1:])
     fusable = (x.is_cuda and x.dtype == torch.float32 and tuple(y1.shape) == tail and y1.dtype == torch.float32
                and (m1 is None or (m1.dtype == torch.float32 and tuple(m1.shape) == (tail + (3,) if mask_channel0 else tail))))
@@ -332,45 +365,36 @@ def masked_l1_mean(x, y, mask=None, mask_channel0=False):
     return _masked_l1_func.apply(x.contiguous(), y1.contiguous(), None if m1 is None else m1.contiguous(), 3 if mask_channel0 else 1)
 
 
-def _interpolate_wrapper(attr, rast, attr_idx, rast_db=None):
-    """diffdope.py:143-153"""
-    return interpolate(attr.contiguous(), rast, attr_idx, rast_db=rast_db, diff_attrs=None if rast_db is None else "all")
-
-
 def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None, uv_idx=None, tex=None, vtx_color=None,
                          return_rast_out=False):
-    """Same signature, outputs and op order as diffdope.py:156-234 (op-by-op path: materialises every
-    image; the fused engine in diffdope_amd.engine is the fast path for the built-in losses).
+    """The materialising render of diffdope.py:156-234 (same signature and outputs), for user loss functions that read
+    ddope.renders; the built-in losses take the fused engine (diffdope_amd.engine) instead.
 
-    Returns dict(rgb [B,H,W,3], depth [B,H,W], rast_out or None, mask [B,H,W,3]).
+    Args as the reference: proj_cam [B,4,4], mtx [B,4,4], pos [B,V,3], pos_idx [B,T,3] or [T,3] int32, resolution int or
+    [H,W], and either (uv [B,V,2], uv_idx, tex [B,Th,Tw,3]) or vtx_color [B,V,3].
+    Returns dict(rgb [B,H,W,3], depth [B,H,W], rast_out [B,H,W,4] or None, mask [B,H,W,3]).
     """
-    if not type(resolution) == list:
-        resolution = [resolution, resolution]
-    dev = pos.device
-    posw = torch.cat([pos, torch.ones([pos.shape[0], pos.shape[1], 1], device=dev)], axis=2)
-    final_mtx_proj = torch.matmul(proj_cam, mtx)
-    pos_clip_ja = dd_ops.xfm_points(pos.contiguous(), final_mtx_proj)
-    tri = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
-    rast_out, rast_out_db = rasterize(glctx, pos_clip_ja, tri, resolution=resolution)
-
-    gb_pos, _ = _interpolate_wrapper(posw, rast_out, tri, rast_db=rast_out_db)
-    shape_keep = gb_pos.shape
-    gb_pos = gb_pos.reshape(shape_keep[0], -1, shape_keep[-1])[..., :3]
-    depth = dd_ops.xfm_points(gb_pos.contiguous(), mtx)
-    depth = depth.reshape(shape_keep)[..., 2] * -1
-
-    ones = torch.ones((1, tri.shape[0], 3), device=dev)  # the reference indexes a [B,T,3] ones tensor per vertex
-    mask, _ = interpolate(ones, rast_out, tri, rast_db=rast_out_db, diff_attrs="all")
-    mask = antialias(mask, rast_out, pos_clip_ja, tri)
-
+    H, W = (resolution if isinstance(resolution, (list, tuple)) else (resolution, resolution))
+    faces = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
+    # clip-space vertices and visibility (:195-200)
+    clip = dd_ops.xfm_points(pos.contiguous(), torch.matmul(proj_cam, mtx))
+    rast, _ = rasterize(glctx, clip, faces, resolution=[H, W])
+    covered = rast[..., 3:].clamp(0, 1)
+    # depth: object-space position under each pixel, through the pose, camera z negated (:203-209); a background pixel
+    # interpolates to the origin, so its depth is -mtx[2,3], as in the reference
+    homog = torch.cat([pos, pos.new_ones(pos.shape[0], pos.shape[1], 1)], dim=2)
+    surf, _ = interpolate(homog.contiguous(), rast, faces)
+    B = surf.shape[0]
+    cam = dd_ops.xfm_points(surf[..., :3].reshape(B, H * W, 3).contiguous(), mtx)
+    depth = -cam[..., 2].reshape(B, H, W)
+    # silhouette: coverage with antialiased edges (:212-214; the reference interpolates a tensor of ones)
+    cover, _ = interpolate(torch.ones((1, faces.shape[0], 3), device=pos.device), rast, faces)
+    mask = antialias(cover, rast, clip, faces)
+    # colour: bilinear texture lookup at the interpolated uv, or interpolated vertex colours; background zeroed (:216-231)
     if vtx_color is None:
-        uvi = uv_idx[0] if uv_idx.dim() == 3 else uv_idx
-        texc, texd = interpolate(uv, rast_out, uvi, rast_db=rast_out_db, diff_attrs="all")
-        color = texture(tex, texc, texd, filter_mode="linear")
-        color = color * torch.clamp(rast_out[..., -1:], 0, 1)
+        uv_faces = uv_idx[0] if uv_idx.dim() == 3 else uv_idx
+        tc, _ = interpolate(uv, rast, uv_faces)
+        rgb = texture(tex, tc, filter_mode="linear") * covered
     else:
-        color, _ = interpolate(vtx_color, rast_out, tri)
-        color = color * torch.clamp(rast_out[..., -1:], 0, 1)
-    if not return_rast_out:
-        rast_out = None
-    return {"rgb": color, "depth": depth, "rast_out": rast_out, "mask": mask}
+        rgb = interpolate(vtx_color, rast, faces)[0] * covered
+    return {"rgb": rgb, "depth": depth, "rast_out": rast if return_rast_out else None, "mask": mask}

@@ -63,7 +63,7 @@ def build(name, device, B=None, seed=0, global_lo=0, global_B=None, rot_deg=10.0
     H, W = cfg["H"], cfg["W"]
     pos, tri, uv = syn.blob_mesh(cfg["rows"], cfg["cols"], seed=seed)
     T = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=device)
-    out = dict(name=name, H=H, W=W, B=B, global_B=global_B, weights=cfg["weights"], V=pos.shape[0], T=tri.shape[0])
+    out = dict(name=name, H=H, W=W, B=B, global_B=global_B, weights=cfg["weights"], V=pos.shape[0], T=tri.shape[0], distance=float(distance))
     out["pos"], out["tri"] = T(pos), T(tri, torch.int32)
     if cfg["textured"]:
         out["uv"], out["tex"], out["vtx_color"] = T(uv), T(syn.texture(cfg["tex"], seed=seed + 1)), None
@@ -94,6 +94,25 @@ def build(name, device, B=None, seed=0, global_lo=0, global_B=None, rot_deg=10.0
         lr_mult[b] = math.exp(random.Random(3 + g).uniform(math.log(0.5), math.log(2.0)))
     out["params0"], out["lr_mult"] = T(params), T(lr_mult)
     return out
+
+
+def bench_lr_schedule(n_it, optimizer):
+    """The optimiser learning rates bench.py runs a workload with: the reference's decayed schedule (diffdope.py:1657-1661,
+    base 20 x decay 0.1 => 2.0 ... 0.2) scaled to the synthetic scenes (x 0.5 for SGD, x 0.0025 for Adam)."""
+    base = 0.005 if optimizer == "adam" else 1.0
+    return [base * l / 2.0 for l in lr_schedule(max(n_it - 1, 1), 20, 0.1)][:n_it]
+
+
+def engine_for(w, lrs, optimizer="sgd", params=None, global_batch=None, **kw):
+    """RefineEngine on workload `w` exactly as bench.py times it (the parity tests build theirs through this too).
+    Returns (engine, params): params [7,B] is updated in place by the engine."""
+    from .engine import RefineEngine
+
+    params = w["params0"].clone() if params is None else params
+    eng = RefineEngine(w["pos"], w["tri"], w["proj"], [w["H"], w["W"]], w["gt"], params, w["lr_mult"], lrs, w["weights"],
+                       uv=w["uv"], tex=w["tex"], vtx_color=w["vtx_color"], optimizer=optimizer,
+                       global_batch=global_batch or w["global_B"], **kw)
+    return eng, params
 
 
 def pose_errors(params, q_gt, t_gt, unit_m=0.1):

@@ -369,15 +369,26 @@ class RenderOracle:
         dparams = pose_bwd(params, dmtx)
         return total, logs, dparams, r
 
-    def optimise(self, params0, lr_mult, lrs, optimizer="sgd", record=False):
-        """diffdope.py:1634-1714 with SGD (reference) -- returns final params, loss logs, mtx history."""
+    def optimise(self, params0, lr_mult, lrs, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_B=None):
+        """diffdope.py:1634-1714: SGD (the reference's optimiser, :1642-1644) or Adam (north_star; torch.optim.Adam's
+        update, step counted from 1) -- returns final params, loss logs, mtx history."""
+        dt = self.dt.type
         params = _c(params0, self.dt).copy()
         logs_hist = {}
         mtx_hist = []
-        for lr in lrs:
-            total, logs, g, r = self.loss_and_grad(params, lr_mult)
+        m1 = np.zeros_like(params)
+        m2 = np.zeros_like(params)
+        b1, b2, eps = (dt(x) for x in adam)
+        for step, lr in enumerate(lrs, start=1):
+            total, logs, g, r = self.loss_and_grad(params, lr_mult, global_B=global_B)
             mtx_hist.append(pose_fwd(params))
             for k, v in logs.items():
                 logs_hist.setdefault(k, []).append(v.copy())
-            params = (params - self.dt.type(lr) * g).astype(self.dt)
+            if optimizer == "sgd":
+                params = (params - dt(lr) * g).astype(self.dt)
+            else:
+                m1 = (b1 * m1 + (dt(1) - b1) * g).astype(self.dt)
+                m2 = (b2 * m2 + (dt(1) - b2) * g * g).astype(self.dt)
+                c1, c2 = dt(1.0 - float(b1) ** step), dt(1.0 - float(b2) ** step)
+                params = (params - dt(lr) * (m1 / c1) / (np.sqrt(m2 / c2) + eps)).astype(self.dt)
         return params, {k: np.stack(v) for k, v in logs_hist.items()}, np.stack(mtx_hist)

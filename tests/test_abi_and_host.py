@@ -111,3 +111,47 @@ def test_shard_ranges_partition_the_batch():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (the driver's plain form) re-executes itself under
+    torch.distributed.run with N ranks on 127.0.0.1; with WORLD_SIZE in the environment it does not."""
+    import importlib
+    import sys
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise Stop
+
+    monkeypatch.setattr(bench.os, "execv", fake_execv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(Stop):
+        bench.main()
+    a = seen["argv"]
+    assert a[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    assert a[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and a[-7].endswith("bench.py")
+    # and the byte models the JSON line carries are self-consistent
+    c = bench.compulsory_bytes(10449, 20480, 307200, 64, 1600, 228000.0, True, 2, 16, dict(rgb=True, depth=False, mask=True, edge=False))
+    assert abs(c["iteration"] - (c["scatter_kernel"] + c["shade_kernel"] + c["update_xfm_kernel"])) < 1e-6
+    assert 0 < c["shade_kernel"] < bench.algorithmic_bytes(10449, 20480, 307200, 64)["shade_kernel"]
+
+
+def test_pixel_derivative_placeholders_raise_when_consumed():
+    """rast_db / diff_attrs outputs are not computed (diff-dope discards them, diffdope.py:212-226): the placeholders can be
+    inspected and passed on, but any arithmetic / indexing / copy on them raises instead of silently reading zeros."""
+    from diffdope_amd.render import PixelDerivativesNotComputed, _not_computed
+
+    z = _not_computed((2, 3, 4, 4), "cpu")
+    assert isinstance(z, PixelDerivativesNotComputed) and tuple(z.shape) == (2, 3, 4, 4) and z.dim() == 4 and z.dtype == torch.float32
+    assert "PixelDerivativesNotComputed" in repr(z)
+    for use in (lambda: z + 1, lambda: z[0], lambda: z.sum(), lambda: torch.cat([z, z]), lambda: z.contiguous(), lambda: z * z, lambda: z.cpu()):
+        with pytest.raises(RuntimeError, match="pixel derivatives"):
+            use()

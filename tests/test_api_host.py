@@ -78,6 +78,40 @@ def test_ply_ascii_binary_and_mesh_class(tmp_path):
     np.testing.assert_allclose(mesh2.vtx_normals.numpy(), [[0, 0, 1]] * 4, atol=1e-6)
 
 
+def test_ply_per_face_texcoords_unmerge_vertices(tmp_path):
+    """MeshLab wedge UVs: `property list uchar float texcoord` on the face element (ASCII and binary).  A vertex used with
+    two different uvs becomes two vertices (what trimesh.load(force="mesh") does at diffdope.py:784); identical
+    (vertex, uv) pairs stay merged; positions, colours and the triangle geometry are preserved."""
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    faces = [[0, 1, 2], [0, 2, 3]]
+    # vertex 0 carries the same uv in both faces, vertex 2 a different one per face
+    tcs = [[0.0, 0.0, 1.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.5, 0.25, 0.0, 1.0]]
+    pa = str(tmp_path / "w.ply")
+    with open(pa, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment TextureFile t.png\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                "element face 2\nproperty list uchar int vertex_indices\nproperty list uchar float texcoord\nend_header\n")
+        for p_ in pos:
+            f.write(" ".join(f"{v:.6f}" for v in p_) + "\n")
+        for t, tc in zip(faces, tcs):
+            f.write("3 " + " ".join(map(str, t)) + " 6 " + " ".join(f"{v:.6f}" for v in tc) + "\n")
+    pb = str(tmp_path / "wb.ply")
+    with open(pb, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                b"element face 2\nproperty list uchar int vertex_indices\nproperty list uchar float texcoord\nend_header\n")
+        for p_ in pos:
+            f.write(struct.pack("<fff", *p_))
+        for t, tc in zip(faces, tcs):
+            f.write(struct.pack("<Biii", 3, *t) + struct.pack("<B6f", 6, *tc))
+    for path in (pa, pb):
+        m = io_ply.read_ply(path)
+        assert m["pos"].shape == (5, 3) and m["uv"].shape == (5, 2) and m["faces"].shape == (2, 3)  # vertex 2 split, vertex 0 not
+        # every face corner still carries its own position and its own uv
+        got_pos = m["pos"][m["faces"].reshape(-1)]
+        got_uv = m["uv"][m["faces"].reshape(-1)]
+        np.testing.assert_allclose(got_pos, pos[np.array(faces).reshape(-1)], atol=1e-6)
+        np.testing.assert_allclose(got_uv, np.array(tcs, np.float32).reshape(-1, 2), atol=1e-6)
+
+
 def test_image_loading_flip_and_resize_rules(tmp_path):
     from PIL import Image as PILImage
 

@@ -179,11 +179,24 @@ def test_masked_l1_mean_matches_the_torch_expression():
     """render.masked_l1_mean (one forward + one backward kernel) against the reference's torch expressions
     (diffdope.py:547-613), values and gradients, incl. batched stride-0 views of the observed image and the
     channel-0 mask of the depth term."""
+    from diffdope_amd import render
     from diffdope_amd.render import masked_l1_mean
 
+    hits = []
+    orig = render._masked_l1_func.apply
+    monkey = lambda *a: (hits.append(a[3]), orig(*a))[1]
     g = torch.Generator(device="cuda").manual_seed(0)
     B, H, W = 5, 37, 53
     seg = (torch.rand(1, H, W, 3, device="cuda", generator=g) > 0.4).float()
+    render._masked_l1_func.apply = monkey
+    try:
+        for shape, ch0 in (((B, H, W, 3), False), ((B, H, W), True)):
+            x = torch.randn(shape, device="cuda", generator=g)
+            y = torch.randn((1,) + shape[1:], device="cuda", generator=g)
+            masked_l1_mean(x, y.expand(shape), seg.expand(B, H, W, 3), mask_channel0=ch0)
+    finally:
+        render._masked_l1_func.apply = orig
+    assert hits == [1, 3]  # both the rgb-shaped and the depth-shaped (channel-0 mask) calls took the single-kernel path
     for shape, ch0 in (((B, H, W, 3), False), ((B, H, W), True)):
         x = torch.randn(shape, device="cuda", generator=g, requires_grad=True)
         y = torch.randn((1,) + shape[1:], device="cuda", generator=g)

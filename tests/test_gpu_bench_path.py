@@ -1,0 +1,178 @@
+"""GPU parity of the path bench.py times: the fused engine on the BASELINE workloads exactly as
+`workloads.build` / `workloads.engine_for` make them (cfg2 = configs[1], the headline; cfg1 = configs[0]), the fused
+Adam and SGD updates over several iterations, and hypothesis sharding (global_batch != B) on one GPU.
+
+The observed images of these workloads are rendered by the HIP renderer (workloads.build); the oracle gets the same
+images, so what is compared is the engine's loss / gradient / update arithmetic on the bench's own inputs."""
+import numpy as np
+import pytest
+import torch
+
+from diffdope_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("rgb", "depth", "mask_selection", "edge")
+
+
+def _oracle_for(w):
+    from oracle import oracle as orc
+
+    npy = lambda t: None if t is None else t.detach().cpu().numpy()
+    kw = dict(uv=npy(w["uv"]), tex=npy(w["tex"])) if w["tex"] is not None else dict(vtx_color=npy(w["vtx_color"]))
+    wts = {k: w["weights"].get(k) for k in ("rgb", "depth", "mask", "edge")}
+    return orc.RenderOracle(npy(w["pos"]), npy(w["tri"]), npy(w["proj"]), w["H"], w["W"], {k: npy(v) for k, v in w["gt"].items()},
+                            wts, dtype=np.float32, **kw)
+
+
+def _pose_close(pa, pb, tol_rad=1e-3, tol_m=1e-3):
+    """Every hypothesis of params pa vs pb [7,B]: rotation geodesic < tol_rad, translation < tol_m (1 unit = 0.1 m)."""
+    worst = (0.0, 0.0)
+    for b in range(pa.shape[1]):
+        ang = syn.rotation_geodesic(pa[:4, b], pb[:4, b])
+        dt = float(np.linalg.norm(pa[4:, b] - pb[4:, b])) * 0.1
+        worst = (max(worst[0], ang), max(worst[1], dt))
+        assert ang < tol_rad and dt < tol_m, (b, ang, dt)
+    return worst
+
+
+@pytest.mark.parametrize("name,B", [("cfg2", 64), ("cfg1", 1), ("cfg1", 4)])
+def test_fused_engine_on_the_bench_workload_against_oracle(name, B):
+    """The engine as bench.py builds it (cfg2: 80x128 mesh = 20 480 triangles, 640x480, rgb+mask, distance 7.5, 64 hypotheses;
+    cfg1: 77x90 mesh = 13 860 triangles, 160x120, mask only): evaluation pass of the whole batch, two hypotheses against
+    the oracle (losses rtol 5e-5, pose gradient 3e-3 of its largest component), duplicated hypotheses bit-identical, and the
+    first optimiser iteration (SGD) reproduces params - lr * grad."""
+    from diffdope_amd import workloads as wl
+
+    w = wl.build(name, torch.device("cuda"), B=B)
+    p0 = w["params0"].clone()
+    lrm = w["lr_mult"].clone()
+    dup = None
+    if B >= 4:
+        dup = (1, B - 1)
+        p0[:, dup[1]] = p0[:, dup[0]]
+        lrm[dup[1]] = lrm[dup[0]]
+    w = dict(w, params0=p0, lr_mult=lrm)
+    lrs = wl.bench_lr_schedule(25, "sgd")
+    eng, params = wl.engine_for(w, lrs, optimizer="sgd")
+    losses, grad = eng.loss_and_grad()
+    torch.cuda.synchronize()
+    st = eng.check()
+    assert st["active_tiles"] > 0
+    assert torch.equal(params, p0)
+    lg, g = losses.cpu().numpy(), grad.cpu().numpy()
+    if dup:
+        assert np.array_equal(lg[:, dup[0]], lg[:, dup[1]]) and np.array_equal(g[:, dup[0]], g[:, dup[1]])
+    R = _oracle_for(w)
+    pn, ln = p0.cpu().numpy(), lrm.cpu().numpy()
+    for b in sorted({0, B // 2}):
+        total, logs, g_ref, _ = R.loss_and_grad(pn[:, b:b + 1], ln[b:b + 1], global_B=B)
+        for i, key in enumerate(KEYS):
+            if key in logs:
+                np.testing.assert_allclose(lg[i, b], logs[key][0], rtol=5e-5, atol=1e-7)
+            else:
+                assert lg[i, b] == 0
+        np.testing.assert_allclose(g[:, b], g_ref[:, 0], rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    # one fused iteration == the evaluation pass's gradient through the reference's SGD update (diffdope.py:1642-1644)
+    eng.run(1)
+    torch.cuda.synchronize()
+    expect = p0 - np.float32(lrs[0]) * grad
+    assert torch.equal(params, expect)
+    assert torch.equal(eng.losses()[0], losses)
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_fused_optimiser_on_cfg2_matches_a_torch_optimizer_driven_by_the_evaluation_pass(optimizer):
+    """What bench.py times (cfg2, 64 hypotheses, fused Adam -- and the reference's SGD) for 12 iterations against
+    torch.optim.{Adam,SGD} stepping on the gradients of RefineEngine.loss(): final poses of all 64 hypotheses within
+    1e-3 rad / 1e-3 m (north_star tolerance), per-iteration logged losses equal to fp32 rounding of the trajectory."""
+    from diffdope_amd import workloads as wl
+
+    n = 12
+    w = wl.build("cfg2", torch.device("cuda"))
+    lrs = wl.bench_lr_schedule(n, optimizer)
+    eng, params = wl.engine_for(w, lrs, optimizer=optimizer)
+    eng.run(n)
+    torch.cuda.synchronize()
+    eng.check()
+    eng2, _ = wl.engine_for(w, lrs, optimizer=optimizer)
+    p = w["params0"].clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=lrs[0], betas=(0.9, 0.999), eps=1e-8) if optimizer == "adam" else torch.optim.SGD([p], lr=lrs[0])
+    vals = []
+    for it in range(n):
+        for gr in opt.param_groups:
+            gr["lr"] = lrs[it]
+        opt.zero_grad()
+        val = eng2.loss(p)
+        val.backward()
+        opt.step()
+        vals.append(float(val.detach()))
+    worst = _pose_close(params.cpu().numpy(), p.detach().cpu().numpy())
+    assert worst[0] < 1e-3 and worst[1] < 1e-3
+    # the logged losses of the fused run, folded like the scalar loss (sum_k sum_b lr_b * L[k,b] / B), follow the torch-driven run
+    fused = (eng.losses().sum(1) * w["lr_mult"][None]).sum(1).cpu().numpy() / w["B"]
+    np.testing.assert_allclose(fused, np.array(vals), rtol=2e-3)
+    assert fused[-1] < fused[0]
+
+
+@pytest.mark.parametrize("weights", [dict(rgb=0.7, mask=1.0), dict(rgb=0.7, depth=1.0, mask=1.0)])
+def test_fused_adam_matches_the_oracle_adam_loop(weights):
+    """Fused Adam (update_xfm_kernel) against the oracle's op-by-op loop with torch.optim.Adam's update: 15 iterations,
+    final poses within 1e-3 rad / 1e-3 m, first-iteration losses to rounding."""
+    from tests.scenes import make_scene
+    import diffdope_amd as dd
+
+    sc = make_scene(16, 20, 60, 80, B=4, dist=1.8, rot_deg=6.0, trans=0.02)
+    R = sc["oracle"]
+    R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
+    lrs = [0.004 * (0.9 ** i) for i in range(15)]
+    p_ref, logs_ref, _ = R.optimise(sc["params"], sc["lr_mult"], lrs, optimizer="adam")
+    T = lambda a, **k: torch.tensor(np.ascontiguousarray(a), device="cuda", **k)
+    params = T(sc["params"])
+    eng = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [sc["H"], sc["W"]], {k: T(v) for k, v in sc["gt"].items()},
+                          params, T(sc["lr_mult"]), lrs, weights, uv=T(sc["uv"]), tex=T(sc["tex"]), optimizer="adam")
+    eng.run()
+    torch.cuda.synchronize()
+    eng.check()
+    _pose_close(params.cpu().numpy(), p_ref)
+    lg = eng.losses().cpu().numpy()
+    for i, key in enumerate(KEYS):
+        if key in logs_ref:
+            np.testing.assert_allclose(lg[0, i], logs_ref[key][0], rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(lg[-1, i], logs_ref[key][-1], rtol=5e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_engine_shard_invariance(optimizer):
+    """Hypothesis sharding (the batch mean of diffdope.py:562 keeps the GLOBAL batch size): cfg2's 64 hypotheses
+    run once as one batch and once as two shards of 32 with global_batch = 64.  With the unsharded run's slice counts the
+    shards reproduce it BIT FOR BIT (parameters, loss log, pose log); with the shards' own default slice counts (the
+    fixed-order gradient sum is then grouped differently) to fp32 rounding."""
+    from diffdope_amd import workloads as wl
+
+    n = 6
+    w = wl.build("cfg2", torch.device("cuda"))
+    lrs = wl.bench_lr_schedule(n, optimizer)
+    eng, params = wl.engine_for(w, lrs, optimizer=optimizer)
+    eng.run(n)
+    torch.cuda.synchronize()
+    eng.check()
+    B, h = w["B"], w["B"] // 2
+    for pinned in (True, False):
+        kw = dict(shade_slices=eng.slices[0], edge_slices=eng.slices[1]) if pinned else {}
+        outs = []
+        for lo in (0, h):
+            ws = dict(w, params0=w["params0"][:, lo:lo + h].contiguous(), lr_mult=w["lr_mult"][lo:lo + h].contiguous(), B=h)
+            e, p = wl.engine_for(ws, lrs, optimizer=optimizer, global_batch=B, **kw)
+            e.run(n)
+            torch.cuda.synchronize()
+            e.check()
+            outs.append((p, e.losses(), e.mtx_log))
+        p_sh = torch.cat([o[0] for o in outs], 1)
+        l_sh = torch.cat([o[1] for o in outs], 2)
+        m_sh = torch.cat([o[2] for o in outs], 1)
+        if pinned:
+            assert torch.equal(p_sh, params) and torch.equal(l_sh, eng.losses()) and torch.equal(m_sh, eng.mtx_log)
+        else:
+            _pose_close(p_sh.cpu().numpy(), params.cpu().numpy(), 2e-5, 2e-5)
+            np.testing.assert_allclose(l_sh.cpu().numpy(), eng.losses().cpu().numpy(), rtol=1e-4, atol=1e-7)

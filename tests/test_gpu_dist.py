@@ -1,0 +1,66 @@
+"""The RCCL path on one rank (`-m gpu`): what the driver's 2/4/8-GPU bench uses, exercised on the 1-GPU box --
+process-group initialisation with backend "nccl" (= RCCL on ROCm), the fused arg-min selection + all_reduce of the
+[world,18] table, the multi-object table merge, and bench.py end to end with DDX_FORCE_DIST=1.  Run in subprocesses so
+that the test process itself never holds a process group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r"""
+import os, sys, torch, numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)d", rank=0, world_size=1, device_id=dev)
+from diffdope_amd import dist as ddist
+g = torch.Generator(device="cpu").manual_seed(0)
+rows = torch.rand(4, 64, generator=g).cuda()
+rows[:, 40] = rows[:, 3] = rows.min(1).values - 0.5      # tie: index 3 wins
+mtx = torch.rand(64, 16, generator=g).cuda()
+ref = ddist.global_argmin(rows[[0, 2]].mean(0), mtx.reshape(64, 4, 4), lo=128)
+got = ddist.global_argmin_fused(rows, 0b0101, mtx, lo=128)
+assert got[0] == ref[0] == 131, (got[0], ref[0])
+assert abs(got[1] - ref[1]) < 1e-6 and torch.equal(got[2].cpu(), ref[2].cpu())
+tab = torch.rand(5, 18, generator=g).cuda()
+merged = ddist.merge_object_tables(tab.clone())
+torch.cuda.synchronize()
+assert torch.equal(merged, tab)                           # one rank owns every row: SUM over one rank = identity
+assert dist.get_backend() == "nccl"
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_one_rank_argmin_and_object_table():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _SCRIPT % dict(root=ROOT, port=_free_port())], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_runs_through_the_rccl_path_on_one_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DDX_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["global_hypotheses"] == 64
+    assert line["final_pose"]["argmin_global_index"] in range(64)

@@ -240,3 +240,33 @@ def test_topology_cache_is_validated_by_content_not_by_address():
     # in-place edits of the same tensor are seen too
     b[:] = torch.tensor(tri, dtype=torch.int32, device="cuda")
     assert torch.equal(build_topology(b), opp_a)
+
+
+def test_reference_call_pattern_with_pixel_derivative_placeholders():
+    """The reference's own call sequence (diffdope.py:198-226: rast_db handed to interpolate(..., diff_attrs="all"), texd handed
+    to texture(..., filter_mode="linear")) runs; the derivative outputs are placeholders that raise when a caller computes
+    with them, and mip-mapped filtering (which would need them) raises."""
+    import diffdope_amd as dd
+    import diffdope_amd.render as dr
+
+    sc = make_scene(8, 10, 40, 56, B=2, dist=1.6)
+    from oracle import oracle as orc
+
+    T = lambda a, **k: torch.tensor(np.ascontiguousarray(a), device="cuda", **k)
+    mtx = T(orc.pose_fwd(sc["params"]))
+    clip = dd.xfm_points(T(sc["pos"])[None].expand(2, -1, -1).contiguous(), torch.matmul(T(sc["proj"])[None], mtx))
+    ctx = dr.RasterizeGLContext()
+    rast, rast_db = dr.rasterize(ctx, clip, T(sc["tri"]), resolution=[sc["H"], sc["W"]])
+    assert isinstance(rast_db, dr.PixelDerivativesNotComputed) and tuple(rast_db.shape) == tuple(rast.shape)
+    texc, texd = dr.interpolate(T(sc["uv"])[None], rast, T(sc["tri"]), rast_db=rast_db, diff_attrs="all")
+    assert isinstance(texd, dr.PixelDerivativesNotComputed) and tuple(texd.shape) == tuple(texc.shape[:3]) + (4,)
+    col = dr.texture(T(sc["tex"])[None], texc, texd, filter_mode="linear")
+    assert tuple(col.shape) == tuple(texc.shape[:3]) + (3,) and torch.isfinite(col).all()
+    _, none_da = dr.interpolate(T(sc["uv"])[None], rast, T(sc["tri"]))
+    assert tuple(none_da.shape) == tuple(texc.shape[:3]) + (0,)
+    with pytest.raises(RuntimeError, match="pixel derivatives"):
+        (texd * 2).sum()
+    with pytest.raises(RuntimeError, match="pixel derivatives"):
+        rast_db[..., 0]
+    with pytest.raises(RuntimeError, match="linear"):
+        dr.texture(T(sc["tex"])[None], texc, texd, filter_mode="linear-mipmap-linear")
