@@ -48,14 +48,15 @@ def test_example_mesh_and_images_parse_like_the_originals():
     np.testing.assert_allclose(mesh.uv.numpy()[:3, 1], 1 - np.array(exp["first_uv"])[:, 1], atol=1e-6)
     # the observation: 8-bit rgb, uint16 depth in 1/100 units, 8-bit mask covering ~1 % of the frame; bottom-up rows
     sc = dd.Scene(**cfg.scene)
-    assert sc.get_resolution() == [90, 160]
+    assert sc.get_resolution() == [180, 320]
     seg = sc.tensor_segmentation.img_tensor
-    assert tuple(seg.shape) == (90, 160, 3) and float(seg.min()) == 0.0 and float(seg.max()) == 1.0  # (bilinear resize, as cv2.resize: soft edge)
-    assert abs(float(seg[..., 0].mean()) - exp["scene"]["seg_fraction"]) < 0.004
+    assert tuple(seg.shape) == (180, 320, 3) and float(seg.min()) == 0.0 and float(seg.max()) == 1.0  # (bilinear resize, as cv2.resize: soft edge)
+    assert exp["seg_pixels_in_window"] == exp["seg_pixels"]  # the window holds the whole object
+    assert abs(float(seg[..., 0].mean()) - exp["seg_pixels"] / (640.0 * 360.0)) < 0.002
     d = sc.tensor_depth.img_tensor
     inside = d[seg[..., 0] > 0]
     assert abs(float(inside.mean()) - exp["scene"]["depth_at_seg_mean_units"]) < 0.15 and float(d.max()) <= exp["scene"]["depth_max_raw"] / 100.0
-    assert abs(float(sc.tensor_rgb.img_tensor.mean()) - exp["scene"]["rgb_mean"]) < 0.01
+    assert abs(float(sc.tensor_rgb.img_tensor.mean()) - exp["scene"]["rgb_mean_in_window"]) < 0.01
     # the yaml pose through opencv_2_opengl: the object sits in front of the GL camera (z < 0) at ~7.5 units (747 mm x 0.01)
     obj = dd.Object3D(**dict(cfg.object3d, batchsize=2, model_path=None))
     p = obj.params_tensor().numpy()
@@ -96,7 +97,7 @@ def test_example_scene_refines_with_the_reference_defaults():
     runs = []
     for fused in (True, True, False):
         d = dd.DiffDope(cfg=_cfg())
-        assert d.batchsize == 8 and d.resolution == [90, 160] and [f.__name__ for f in d.loss_functions] == ["l1_mask"]
+        assert d.batchsize == 8 and d.resolution == [180, 320] and [f.__name__ for f in d.loss_functions] == ["l1_mask"]
         d.run_optimization(fused=fused)
         runs.append(d)
     a, a2, b = runs

@@ -72,7 +72,9 @@ def test_fused_engine_on_the_bench_workload_against_oracle(name, B):
                 np.testing.assert_allclose(lg[i, b], logs[key][0], rtol=5e-5, atol=1e-7)
             else:
                 assert lg[i, b] == 0
-        np.testing.assert_allclose(g[:, b], g_ref[:, 0], rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+        # (cfg1: 13 860 triangles on 160x120 are far below a pixel each, so hardly any silhouette pair antialiases and the mask
+        # term's gradient is zero up to cancellation noise -- in the oracle exactly as on the GPU; hence the absolute floor)
+        np.testing.assert_allclose(g[:, b], g_ref[:, 0], rtol=3e-3, atol=max(3e-3 * np.abs(g_ref).max(), 1e-9))
     # one fused iteration == the evaluation pass's gradient through the reference's SGD update (diffdope.py:1642-1644)
     eng.run(1)
     torch.cuda.synchronize()

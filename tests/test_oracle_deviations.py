@@ -1,0 +1,173 @@
+"""The four DECLARED deviations of this build from nvdiffrast at the unpinned boundary (nvdiffrast is
+un-vendored and un-pinned).  Each test states, for a hand-built case, what nvdiffrast's published algorithm
+yields and what this build yields, so the size and the trigger of every deviation is on record.  CPU only (the HIP
+kernels are held to this oracle bit-for-bit / to tolerance by the -m gpu tests).
+
+  D1  a triangle with a vertex at clip w <= 0 is dropped, nvdiffrast (GL) clips it against the view volume
+  D2  rasterize backward: a barycentric saturated by the [0,1] clamp passes no gradient, nvdiffrast differentiates
+      the unclamped expression
+  D3  antialias: of two triangle edges that cross the pixel-pair segment the one with the LARGER crossing parameter is
+      used (explicit max), ties resolved to the lower edge index
+  D4  coverage of a pixel centre lying exactly on an (unshared) triangle edge: own ownership rule on 1/256-pixel snapped
+      coordinates; GL hardware applies the top-left rule of its own fixed-point grid
+"""
+import numpy as np
+
+from oracle import oracle as orc
+from tests.test_oracle_known_answers import clip_from_pixels
+
+
+def _homogeneous_inside(P, px, py, H, W):
+    """Reference semantics of clipped rasterisation without clipping (Olano & Greer homogeneous 2-D rasterisation, float64):
+    pixel centre inside the triangle's visible part <=> the three homogeneous edge functions share the sign of their sum
+    and the interpolated w is positive and -w <= z <= w."""
+    fx, fy = (px + 0.5) / W * 2 - 1, (py + 0.5) / H * 2 - 1
+    q = [(p[0] - fx * p[3], p[1] - fy * p[3]) for p in P]
+    a = [q[1][0] * q[2][1] - q[1][1] * q[2][0], q[2][0] * q[0][1] - q[2][1] * q[0][0], q[0][0] * q[1][1] - q[0][1] * q[1][0]]
+    s = sum(a)
+    if s == 0 or not all(ai * s >= 0 for ai in a):
+        return False
+    w = sum(ai * p[3] for ai, p in zip(a, P)) / s
+    z = sum(ai * p[2] for ai, p in zip(a, P)) / s
+    return w > 0 and -w <= z <= w
+
+
+def test_d1_triangle_straddling_the_camera_plane_is_dropped_not_clipped():
+    H, W = 16, 16
+    # two vertices in front of the camera (w = 1) on the left of the frame, the third behind it (w = -0.5)
+    P = np.array([[-0.9, -0.8, 0.0, 1.0], [-0.9, 0.8, 0.0, 1.0], [0.6, 0.0, 0.2, -0.5]], np.float64)
+    tri = np.array([[0, 1, 2]], np.int32)
+    want = np.array([[_homogeneous_inside(P, x, y, H, W) for x in range(W)] for y in range(H)])
+    assert 20 < want.sum() < H * W  # nvdiffrast (GL clipping): the visible part of the triangle is drawn
+    rast = orc.rasterize_fwd(P[None], tri, H, W)
+    assert np.all(rast[0, ..., 3] == 0)  # this build: the whole triangle is dropped (snap_triangle: any w <= 0)
+    # with the third vertex moved just in front of the camera the same triangle IS drawn, covering the pixels the
+    # homogeneous test predicts (so the deviation is confined to w <= 0 triangles)
+    P2 = P.copy()
+    P2[2] = [0.6, 0.0, 0.2, 0.5]
+    want2 = np.array([[_homogeneous_inside(P2, x, y, H, W) for x in range(W)] for y in range(H)])
+    got2 = orc.rasterize_fwd(P2[None], tri, H, W)[0, ..., 3] > 0
+    assert want2.sum() > 20 and (got2 != want2).sum() <= 2  # (edge-centre ties only)
+
+
+def test_d1_pose_gradient_when_part_of_a_mesh_crosses_the_camera_plane():
+    """Characterises the trigger on a whole mesh: a hypothesis so close that the camera plane cuts the object loses the
+    straddling triangles; loss and pose gradient stay finite, and the analytic gradient is still the derivative of what is
+    drawn (finite differences, float64)."""
+    from diffdope_amd import synthetic as syn
+
+    pos, tri, uv = syn.blob_mesh(6, 8, seed=0)
+    H, W = 24, 32
+    proj = orc.projection_matrix(**syn.camera_intrinsics(W, H))
+    R = orc.RenderOracle(pos, tri, proj, H, W, {}, dict(rgb=None, depth=1.0, mask=1.0), vtx_color=syn.vertex_colors(pos, seed=5), dtype=np.float64)
+    p_far = np.array([[0.1], [0.2], [0.05], [0.97], [0.0], [0.0], [-1.6]])
+    r = R.render(orc.pose_fwd(p_far))
+    cov = r["rast"][0, ..., 3] > 0
+    R.gt = {"depth": r["depth"].copy(), "segmentation": np.repeat(cov[None, ..., None], 3, -1).astype(np.float64)}
+    p_cut = p_far.copy()
+    p_cut[6, 0] = -0.25  # the camera plane now cuts the object: some vertices have w = -z_cam <= 0
+    clip = R.render(orc.pose_fwd(p_cut))["pos_clip"][0]
+    n_behind = int((clip[:, 3] <= 0).sum())
+    straddlers = sum(1 for t in tri if 0 < sum(clip[v, 3] <= 0 for v in t) < 3)
+    assert n_behind > 0 and straddlers > 0
+    total, logs, g, _ = R.loss_and_grad(p_cut, np.ones(1))
+    assert np.isfinite(total) and np.all(np.isfinite(g))
+    eps = 1e-6
+    for i in (4, 6):
+        pp, pm = p_cut.copy(), p_cut.copy()
+        pp[i, 0] += eps
+        pm[i, 0] -= eps
+        fd = (R.loss_and_grad(pp, np.ones(1), want_grad=False)[0] - R.loss_and_grad(pm, np.ones(1), want_grad=False)[0]) / (2 * eps)
+        assert abs(fd - g[i, 0]) < 1e-4 * max(1.0, abs(fd)), (i, fd, g[i, 0])
+
+
+def test_d2_saturated_barycentric_passes_no_gradient():
+    H, W = 8, 8
+    # The right edge of the triangle runs 0.4/256 pixel LEFT of the centre of pixel (4,3).  The fixed-point rule snaps the
+    # edge onto the centre and owns it (upward edge), so the pixel is covered; the float barycentric of the vertex opposite
+    # that edge (vertex 0 here, so it is `u`) comes out slightly negative and the forward clamps it to 0, as nvdiffrast's
+    # output is clamped.
+    xe = 4.5 - 0.4 / 256
+    pix = np.array([[0.5, 4.0], [xe, 0.5], [xe, 7.5]])
+    P = clip_from_pixels(pix, H, W, z=0.0)[None]
+    tri = np.array([[0, 1, 2]], np.int32)
+    rast = orc.rasterize_fwd(P, tri, H, W)
+    assert rast[0, 3, 4, 3] == 1 and rast[0, 3, 4, 0] == 0.0  # covered, u saturated at 0
+    u_unclamped = (xe - 4.5) / (xe - 0.5)  # weight of vertex 0 at the centre: distance past the edge / triangle width
+    assert -2e-3 < u_unclamped < 0
+    # backward of d loss / d u = 1 at that pixel: this build passes nothing through the saturated component ...
+    d = np.zeros_like(rast)
+    d[0, 3, 4, 0] = 1.0
+    g_sat = orc.rasterize_bwd(P, tri, rast, d)
+    assert np.all(g_sat == 0)
+    # ... nvdiffrast differentiates the unclamped expression: the same 1/width-sized gradient an interior pixel carries
+    d2 = np.zeros_like(rast)
+    d2[0, 3, 3, 0] = 1.0  # its left neighbour, clear interior (u = 0.25)
+    g_int = orc.rasterize_bwd(P, tri, rast, d2)
+    assert 0 < rast[0, 3, 3, 0] < 1 and np.abs(g_int[0, :, 0]).max() > 0.2  # d u / d x_clip ~ (W/2) / (width in pixels) = 4 / 4
+    # the deviation is confined to saturated pixels: the analytic gradient at the interior pixel is the true derivative
+    eps = 1e-6
+    Pp, Pm = P.copy(), P.copy()
+    Pp[0, 0, 0] += eps
+    Pm[0, 0, 0] -= eps
+    fd = (orc.rasterize_fwd(Pp, tri, H, W)[0, 3, 3, 0] - orc.rasterize_fwd(Pm, tri, H, W)[0, 3, 3, 0]) / (2 * eps)
+    assert abs(fd - g_int[0, 0, 0]) < 1e-6 * max(1.0, abs(fd))
+
+
+def test_d3_antialias_edge_choice_by_largest_crossing_parameter():
+    """A sliver narrower than a pixel covers the centre of pixel (5,4) and not that of (6,4): BOTH of its steep edges cross
+    the row of centres inside the (-eps, 1+eps) window around the pair segment -- the entry edge 0.002 px left of centre 5,
+    the exit edge 0.372 px right of it.  This build takes the crossing with the larger parameter along the direction
+    covered -> uncovered (explicit max), i.e. the exit edge, so pixel 5 ends with the analytic box coverage of that edge."""
+    H, W = 8, 12
+    pix = np.array([[5.47, -10.0], [5.9, -10.0], [5.685, 100.0]])
+    tri = np.array([[0, 1, 2]], np.int32)
+    P = clip_from_pixels(pix, H, W, z=0.0)[None]
+    rast = orc.rasterize_fwd(P, tri, H, W)
+    assert rast[0, 4, 5, 3] == 1 and rast[0, 4, 6, 3] == 0 and rast[0, 4, 4, 3] == 0
+    cov = orc.interpolate_fwd(np.ones((1, 3, 1)), rast, tri)
+    out = orc.antialias_fwd(cov, rast, P, tri)
+    x_exit = 5.9 - (4.5 + 10.0) / 110.0 * (5.9 - 5.685)
+    x_entry = 5.47 + (4.5 + 10.0) / 110.0 * (5.685 - 5.47)
+    assert -0.0625 < x_entry - 5.5 < 0 < x_exit - 5.5 < 1  # both crossings inside the acceptance window of the (5,6) pair
+    # pair (5,6): exit edge chosen -> pixel 5 keeps 1 - (0.5 - 0.372) = 0.872 (choosing the entry edge instead, crossing
+    # parameter -0.002 clamped to 0, would have blended half of pixel 5 away); pair (4,5) then takes the 0.498 that lies left of
+    # the entry edge: pixel 5 ends with exactly the sliver's analytic width inside it
+    np.testing.assert_allclose(out[0, 4, 5, 0], x_exit - x_entry, atol=1e-6)
+    assert out[0, 4, 6, 0] == 0.0 and out[0, 4, 4, 0] == 0.0
+    # a plain vertical silhouette for scale (K5): the pixel pair straddling an edge at x = 5.8 leaves 0.8 in pixel 5
+    pix_q = np.array([[-4.0, -4.0], [5.8, -4.0], [5.8, H + 4.0], [-4.0, H + 4.0]])
+    tri_q = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    Pq = clip_from_pixels(pix_q, H, W, z=0.0)[None]
+    rq = orc.rasterize_fwd(Pq, tri_q, H, W)
+    oq = orc.antialias_fwd(orc.interpolate_fwd(np.ones((1, 4, 1)), rq, tri_q), rq, Pq, tri_q)
+    np.testing.assert_allclose(oq[0, 4, 5:8, 0], [0.8, 0.0, 0.0], atol=1e-9)
+
+
+def test_d4_pixel_centre_exactly_on_an_unshared_edge():
+    """Ownership of pixel centres lying exactly on triangle edges (after the 1/256-pixel snap).  Own rule (oracle edge_inside):
+    with the triangle oriented counter-clockwise in bottom-up window coordinates a centre on an edge is covered iff the edge
+    runs upward (dy > 0: the triangle's right side) or is horizontal running leftward (its top side).  GL / D3D hardware use
+    the top-LEFT rule in top-down window coordinates.  The two agree on every centre not exactly on an edge."""
+    H, W = 8, 8
+    # axis-aligned right triangle with vertices on pixel centres: legs on column x = 1.5 and row y = 1.5, hypotenuse x + y = 8
+    pix = np.array([[1.5, 1.5], [6.5, 1.5], [1.5, 6.5]])
+    rast = orc.rasterize_fwd(clip_from_pixels(pix, H, W)[None], np.array([[0, 1, 2]], np.int32), H, W)
+    ids = rast[0, ..., 3] > 0
+    own = {"bottom_row": bool(ids[1, 3]), "left_col": bool(ids[3, 1]), "hypotenuse": bool(ids[3, 4]), "interior": bool(ids[2, 2])}
+    assert own["interior"]
+    # own rule: bottom edge runs in +x (dy = 0, dx > 0) -> not owned; left edge runs downward (dy < 0) -> not owned;
+    # hypotenuse runs up-left (dy > 0) -> owned
+    assert own == {"bottom_row": False, "left_col": False, "hypotenuse": True, "interior": True}
+    # top-left rule in top-down coordinates (rows flipped): "top" = this bottom row, "left" = the left column -> it would own
+    # exactly the two legs and not the hypotenuse: the complement on these measure-zero centres
+    gl = {"bottom_row": True, "left_col": True, "hypotenuse": False, "interior": True}
+    assert all(own[k] != gl[k] for k in ("bottom_row", "left_col", "hypotenuse"))
+    # watertightness, the property both rules exist for: adding the mirrored triangle covers every centre of the square once
+    quad = np.array([[1.5, 1.5], [6.5, 1.5], [1.5, 6.5], [6.5, 6.5]])
+    r2 = orc.rasterize_fwd(clip_from_pixels(quad, H, W)[None], np.array([[0, 1, 2], [1, 3, 2]], np.int32), H, W)
+    ids2 = r2[0, ..., 3]
+    assert ids2[3, 4] in (1, 2) and (ids2[2:6, 2:6] > 0).all()
+    # and a centre NOT on an edge is decided identically by any rule: nudge the triangle by 1/64 pixel
+    r3 = orc.rasterize_fwd(clip_from_pixels(pix + 1 / 64, H, W)[None], np.array([[0, 1, 2]], np.int32), H, W)
+    assert not r3[0, 1, 3, 3] and not r3[0, 3, 1, 3] and r3[0, 2, 2, 3] and r3[0, 3, 3, 3]
