@@ -98,6 +98,11 @@ struct EngineDev {
     float4* crec;     // [T,4] (textured) or [T,5] (vertex colours): what the colour role needs of a covered triangle, in ONE
                       // record fetched by triangle id: object-space positions of the 3 vertices (9), then uv (6) or colours (9)
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
+    float4* texq;     // [Th*Tw,4] the texture as one 64-byte record per texel (x,y): the 2x2 bilinear footprint whose corner it
+                      // is -- (x,y), (x+1,y), (x,y+1), (x+1,y+1) with wrap, rgb each, 4 floats of padding -- or null.  A
+                      // sample is then ONE 64-byte sector instead of two 24-byte row pieces (2.75 sectors on average): the
+                      // object is minified (cfg2: 30 texels per pixel), so no two samples share a line anyway and the texel
+                      // gathers are most of the shading kernel's DRAM traffic.  4x the memory of the [Th,Tw,3] texture.
     EngineState* st;
     int st_role;      // shade role that advances the iteration counter (= roles[0])
     int n_roles;      // enabled shade roles (grid z of shade_kernel): 0 colour+depth, 1 antialiased mask, 2 edge
@@ -148,6 +153,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
     const size_t o_perm = carve((size_t)d.T * sizeof(int4));
     const size_t o_crec = carve((size_t)d.T * 5 * sizeof(float4));
+    const size_t o_texq = carve(d.Th > 0 ? (size_t)d.Th * d.Tw * 4 * sizeof(float4) : 0);
     const size_t o_spos = carve((size_t)d.V * 3 * sizeof(float));
     const size_t o_suv = carve((size_t)d.V * 2 * sizeof(float));
     const size_t o_scol = carve((size_t)d.V * 3 * sizeof(float));
@@ -175,6 +181,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.trirec = (int4*)(p + o_rec);
     E.trisort = (int4*)(p + o_perm);
     E.crec = (float4*)(p + o_crec);
+    E.texq = d.Th > 0 ? (float4*)(p + o_texq) : nullptr;
     E.spos = (float*)(p + o_spos);
     E.suv = (float*)(p + o_suv);
     E.scol = (float*)(p + o_scol);
@@ -319,44 +326,32 @@ __device__ __forceinline__ void pose_matrices(float q[4], const float t[3], cons
         }
 }
 
+// row r of final = proj . mtx, the k-ordered fma chain of pose_matrices (same bits).  The matrix-core transform wants row
+// lane % 4 of final in each lane; selecting it from a full F[16] held in registers compiles to an indexed scratch array (four
+// scratch loads in the tail of update_xfm_kernel), computing just that row from proj's row r does not.
+__device__ __forceinline__ void final_row(const float pr[4], const float M[16], float Fr[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a = __fmaf_rn(pr[k], M[k * 4 + c], a);
+        Fr[c] = a;
+    }
+}
+
 // one vertex per lane on the matrix core: four v_mfma_f32_4x4x1_16b_f32 with A = row (lane%4) of final and
 // B = p[k] (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain), then the
 // 1/256-pixel window-coordinate snap.  Must be called by all 64 lanes of a wave.
-__device__ __forceinline__ void xfm_vertex_regs(const EngineDev& E, const float F[16], int b, int n, bool live, int lane,
+__device__ __forceinline__ void xfm_vertex_regs(const EngineDev& E, const float Fr[4] /* row lane % 4 of final */, int b, int n, bool live,
                                                 float px, float py, float pz)
 {
     const int V = E.d.V;
-    const int r = lane & 3;
-    const float a0 = r == 0 ? F[0] : (r == 1 ? F[4] : (r == 2 ? F[8] : F[12]));
-    const float a1 = r == 0 ? F[1] : (r == 1 ? F[5] : (r == 2 ? F[9] : F[13]));
-    const float a2 = r == 0 ? F[2] : (r == 1 ? F[6] : (r == 2 ? F[10] : F[14]));
-    const float a3 = r == 0 ? F[3] : (r == 1 ? F[7] : (r == 2 ? F[11] : F[15]));
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, px, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, py, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, pz, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, 1.0f, acc, 0, 0, 0);
-    if (!live) return;
-    *reinterpret_cast<f32x4*>(E.clip + ((size_t)b * V + n) * 4) = acc;
-    E.L.snap[(size_t)b * V + n] = snap_vertex(make_float4(acc.x, acc.y, acc.z, acc.w), E.d.H, E.d.W);
-}
-
-__device__ __forceinline__ void xfm_vertex(const EngineDev& E, const float F[16], int b, int n, int n_end, int lane)
-{
-    const int V = E.d.V;
-    const int r = lane & 3;
-    const float a0 = r == 0 ? F[0] : (r == 1 ? F[4] : (r == 2 ? F[8] : F[12]));
-    const float a1 = r == 0 ? F[1] : (r == 1 ? F[5] : (r == 2 ? F[9] : F[13]));
-    const float a2 = r == 0 ? F[2] : (r == 1 ? F[6] : (r == 2 ? F[10] : F[14]));
-    const float a3 = r == 0 ? F[3] : (r == 1 ? F[7] : (r == 2 ? F[11] : F[15]));
-    const bool live = n < n_end;
-    const float* p = E.spos + (size_t)(live ? n : 0) * 3;
-    const float px = p[0], py = p[1], pz = p[2];
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, px, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, py, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, pz, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, 1.0f, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[0], px, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[1], py, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[2], pz, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[3], 1.0f, acc, 0, 0, 0);
     if (!live) return;
     *reinterpret_cast<f32x4*>(E.clip + ((size_t)b * V + n) * 4) = acc;
     E.L.snap[(size_t)b * V + n] = snap_vertex(make_float4(acc.x, acc.y, acc.z, acc.w), E.d.H, E.d.W);
@@ -370,12 +365,15 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
     const int b = blockIdx.y, B = E.d.B, V = E.d.V;
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    float q[4], t[3], M[16], F[16];
+    float q[4], t[3], M[16], F[16], pr[4], Fr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = E.b.params[(size_t)i * B + b];
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = E.b.params[(size_t)(4 + i) * B + b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pr[k] = E.b.proj[(lane & 3) * 4 + k];
     pose_matrices(q, t, E.b.proj, M, F);
+    final_row(pr, M, Fr);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int it = E.st->it;
         if (b == 0) E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
@@ -392,7 +390,9 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
             if (logm) logm[i] = M[i];
         }
     }
-    xfm_vertex(E, F, b, n, V, lane);
+    const bool live = n < V;
+    const float* p = E.spos + (size_t)(live ? n : 0) * 3;
+    xfm_vertex_regs(E, Fr, b, n, live, p[0], p[1], p[2]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -727,9 +727,10 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     const float tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
                     TexelSetup ts;
                     tex_setup(tu, tv, d.Th, d.Tw, ts);
-                    const float* TX = E.b.tex;
-                    const float *t00 = TX + ((size_t)ts.y0 * d.Tw + ts.x0) * 3, *t10 = TX + ((size_t)ts.y0 * d.Tw + ts.x1) * 3,
-                                *t01 = TX + ((size_t)ts.y1 * d.Tw + ts.x0) * 3, *t11 = TX + ((size_t)ts.y1 * d.Tw + ts.x1) * 3;
+                    // one 64-byte record = the whole 2x2 footprint (texq): (x0,y0) (x1,y0) (x0,y1) (x1,y1), rgb each
+                    const float4* Q = E.texq + ((size_t)ts.y0 * d.Tw + ts.x0) * 4;
+                    const float4 q0 = Q[0], q1 = Q[1], q2 = Q[2];
+                    const float t00[3] = {q0.x, q0.y, q0.z}, t10[3] = {q0.w, q1.x, q1.y}, t01[3] = {q1.z, q1.w, q2.x}, t11[3] = {q2.y, q2.z, q2.w};
                     const float ux = (a0x - a2x) * (float)d.Tw, uy = (a0y - a2y) * (float)d.Th;  // d(texel x, y) / du
                     const float vx = (a1x - a2x) * (float)d.Tw, vy = (a1y - a2y) * (float)d.Th;  // d(texel x, y) / dv
 #pragma unroll
@@ -1383,22 +1384,32 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         return;
     }
     // ---- transform this slice of the vertices with the NEW pose (next iteration's pose_xfm)
-    float q[4], t[3], M[16], F[16];
+    float q[4], t[3], M[16], pr[4], Fr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = snew[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = snew[4 + i];
-    pose_matrices(q, t, sc + 16, M, F);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pr[k] = sc[16 + (lane & 3) * 4 + k];  // row lane % 4 of proj
+    {   // q / |q| and [R|t] as pose_matrices
+        const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
+        quat_to_matrix(q, t, M);
+    }
+    final_row(pr, M, Fr);
     UPH(6);
-    if (writer && tid == 0) {
-        E.L.bigcount[b] = 0;  // re-arm the hypothesis' list of large triangles
+    if (writer && tid < 4) {  // lanes 0..3 hold rows 0..3 of final; each writes its row of both matrices
+        if (tid == 0) E.L.bigcount[b] = 0;  // re-arm the hypothesis' list of large triangles
         float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
         float* logm = (E.b.mtx_log && it + 1 < d.max_iters) ? E.b.mtx_log + ((size_t)(it + 1) * B + b) * 16 : nullptr;
+        const float Mr[4] = {tid == 0 ? M[0] : (tid == 1 ? M[4] : (tid == 2 ? M[8] : M[12])), tid == 0 ? M[1] : (tid == 1 ? M[5] : (tid == 2 ? M[9] : M[13])),
+                             tid == 0 ? M[2] : (tid == 1 ? M[6] : (tid == 2 ? M[10] : M[14])), tid == 0 ? M[3] : (tid == 1 ? M[7] : (tid == 2 ? M[11] : M[15]))};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dst[i] = M[i];
-            dst[16 + i] = F[i];
-            if (logm) logm[i] = M[i];
+        for (int c = 0; c < 4; ++c) {
+            dst[tid * 4 + c] = Mr[c];
+            dst[16 + tid * 4 + c] = Fr[c];
+            if (logm) logm[tid * 4 + c] = Mr[c];
         }
     }
     // positions of 4 strides are fetched before any is consumed (a load-transform-store loop would pay one
@@ -1415,7 +1426,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int n = n0 + u * 256 + tid;
-            if (n0 + u * 256 < n_end) xfm_vertex_regs(E, F, b, n, n < n_end, lane, px[u], py[u], pz[u]);
+            if (n0 + u * 256 < n_end) xfm_vertex_regs(E, Fr, b, n, n < n_end, px[u], py[u], pz[u]);
         }
     }
     UPH(7);
@@ -1631,6 +1642,24 @@ __global__ void remap_triangles_kernel(EngineDev E)
     for (int i = 0; i < rs; ++i) E.crec[(size_t)t * rs + i] = make_float4(r[i * 4], r[i * 4 + 1], r[i * 4 + 2], r[i * 4 + 3]);
 }
 
+// texq (see EngineDev): one thread per texel
+__global__ __launch_bounds__(256) void build_texq_kernel(EngineDev E)
+{
+    const int Th = E.d.Th, Tw = E.d.Tw;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Th * Tw) return;
+    const int y = (int)(i / Tw), x = (int)(i - (long long)y * Tw);
+    const int x1 = x + 1 >= Tw ? 0 : x + 1, y1 = y + 1 >= Th ? 0 : y + 1;
+    const float* T = E.b.tex;
+    const float *a = T + ((size_t)y * Tw + x) * 3, *b = T + ((size_t)y * Tw + x1) * 3, *c = T + ((size_t)y1 * Tw + x) * 3,
+                *dq = T + ((size_t)y1 * Tw + x1) * 3;
+    float4* Q = E.texq + (size_t)i * 4;
+    Q[0] = make_float4(a[0], a[1], a[2], b[0]);
+    Q[1] = make_float4(b[1], b[2], c[0], c[1]);
+    Q[2] = make_float4(c[2], dq[0], dq[1], dq[2]);
+    Q[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 static int engine_setup(ddx_engine* e, hipStream_t s)
 {
     EngineDev& E = e->dev;
@@ -1640,6 +1669,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
     if (E.d.use_edge) edge_setup_kernel<<<1, 1024, 0, s>>>(E);
+    if (E.texq && E.b.tex) build_texq_kernel<<<ddx_cdiv((long long)E.d.Th * E.d.Tw, 256), 256, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
     // ---- internal sorted mesh (host, once per engine).  (1) Vertices renumbered in Morton order of their object-space
     // position: the vertex data of neighbouring triangles and pixels become neighbours in memory whatever order the mesh

@@ -682,11 +682,15 @@ int raster_run(const float* pos, const int* tri, int B, int V, int T, int H, int
         DDX_HIP(hipMemsetAsync(L.counters, 0, L.zero_bytes, s));
         DDX_HIP(hipMemsetAsync(L.zbuf, 0xFF, L.zbuf_bytes, s));
     }
+#ifndef SCATTER_TPL_DENSE
+#define SCATTER_TPL_DENSE 2  // triangles per lane of the dense-mesh variants
+#endif
+    constexpr int TPLD = SCATTER_TPL_DENSE;
     if ((long long)ddx_cdiv(T, 512) * B >= 1024) {
         // dense meshes: the plain kernel in the micro-polygon regime (64 VGPRs, no LDS); the hybrid (72 VGPRs, 19 KB LDS: 4-20 %
         // slower there) when the caller expects triangles to own more than about one pixel centre each
-        if (L.scatter_exchange) scatter_kernel<2, 256, 2><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
-        else scatter_kernel<2, 256, 0><<<dim3(ddx_cdiv(T, 512), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+        if (L.scatter_exchange) scatter_kernel<TPLD, 256, 2><<<dim3(ddx_cdiv(T, 256 * TPLD), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+        else scatter_kernel<TPLD, 256, 0><<<dim3(ddx_cdiv(T, 256 * TPLD), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
     }
     else scatter_kernel<1, 64, 1><<<dim3(ddx_cdiv(T, 64), B), 64, 0, s>>>(pos, tri, V, T, H, W, L);
     if (ev) DDX_HIP(hipEventRecord(ev[1], s));

@@ -115,6 +115,10 @@ class RefineEngine:
         _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
         self.it += n
 
+    def finish(self):
+        """Wait until everything run() enqueued on the current stream has executed (run() itself is asynchronous)."""
+        torch.cuda.current_stream().synchronize()
+
     def loss_and_grad(self):
         """One evaluation pass at the CURRENT contents of `params`, no optimiser step: returns (losses [4,B] weighted,
         un-LR'd per hypothesis (rgb, depth, mask, edge), grad [7,B] = d loss / d params with

@@ -90,8 +90,9 @@ def test_readers_on_the_original_reference_files():
 def test_example_scene_refines_with_the_reference_defaults():
     """DiffDope(cfg) on the real example with the reference's defaults (configs/diffdope.yaml:20-34: l1_mask only, 60
     iterations of SGD with lr 2.0 -> 0.2, 8 hypotheses with multipliers from random.uniform(0.01, 100)): the mask loss of the
-    arg-min hypothesis goes down monotonically (to fp noise) from the yaml pose, its silhouette overlaps the observed mask
-    better than at the start, the run is reproducible, and fused and op-by-op paths agree on the arg-min pose."""
+    arg-min hypothesis goes down from the yaml pose (not monotonically: with multipliers up to 100 on lr 2.0 the reference's
+    own schedule overshoots and settles as the lr decays), its silhouette overlaps the observed mask better than at the
+    start, the run is reproducible, and fused and op-by-op paths agree on the arg-min hypothesis and pose."""
     import diffdope_amd as dd
 
     runs = []
@@ -105,8 +106,9 @@ def test_example_scene_refines_with_the_reference_defaults():
     assert lv.shape == (61, 8)
     best = int(a.get_argmin())
     curve = lv[:, best]
+    print("mask loss of the arg-min hypothesis:", curve[0], "->", curve[-1], "min", curve.min())
     assert curve[-1] < 0.8 * curve[0]
-    assert np.all(np.diff(curve) < 2e-3 * curve[0])  # monotone decrease up to L1-kink noise
+    assert curve[-10:].max() < 0.9 * curve[0]  # settled below the start over the last iterations, not a lucky last sample
     # silhouette overlap with the observed mask at the first and at the last iteration
     seg = a.gt_tensors["segmentation"][0, ..., 0].cpu() > 0
     iou = lambda m: float(((m > 0.5) & seg).sum()) / float(((m > 0.5) | seg).sum())

@@ -35,7 +35,7 @@ def test_engine_one_iteration_losses_and_gradients(weights, textured):
     lr = 0.5
     eng, params = _engine(sc, weights, [lr])
     eng.run(use_graph=False)
-    torch.cuda.synchronize()
+    eng.finish()
     st = eng.check()
     assert st["active_tiles"] > 0
     g_gpu = (sc["params"] - params.cpu().numpy()) / lr
@@ -61,7 +61,7 @@ def test_engine_graph_replay_equals_stream_launches_and_is_deterministic(w):
     for use_graph in (False, True, True, 4):  # (4: graphs of 4 iterations + 2 iterations launched kernel by kernel)
         eng, params = _engine(sc, w, lrs)
         eng.run(use_graph=use_graph)
-        torch.cuda.synchronize()
+        eng.finish()
         eng.check()
         outs.append((params.cpu().numpy().copy(), eng.losses().cpu().numpy().copy()))
     for o in outs[1:]:
@@ -81,7 +81,7 @@ def test_engine_optimisation_matches_oracle_trajectory():
     p_ref, logs_ref, mtx_ref = R.optimise(sc["params"], sc["lr_mult"], lrs)
     eng, params = _engine(sc, w, lrs)
     eng.run()
-    torch.cuda.synchronize()
+    eng.finish()
     eng.check()
     p_gpu = params.cpu().numpy()
     for b in range(sc["B"]):
@@ -107,7 +107,7 @@ def test_engine_recovers_known_pose():
     lrs = [l * 0.02 for l in orc.lr_schedule(199, 20, 0.1)]
     eng, params = _engine(sc, w, lrs)
     eng.run()
-    torch.cuda.synchronize()
+    eng.finish()
     eng.check()
     lg = eng.losses().cpu().numpy()
     best = int(np.argmin(lg[-1].mean(0)))
@@ -165,7 +165,7 @@ def test_engine_large_triangles_ragged_sizes_single_hypothesis(rows, cols, H, W,
     total, logs, g_ref, r_ref = R.loss_and_grad(sc["params"], sc["lr_mult"])
     eng, params = _engine(sc, w, [0.25])
     eng.run()
-    torch.cuda.synchronize()
+    eng.finish()
     st = eng.check()
     if rows <= 6:
         assert st["big_triangles"] == 1  # the tile pass ran
@@ -188,7 +188,7 @@ def test_engine_hypothesis_leaving_the_frame():
     assert (r_ref["rast"][1, ..., 3] > 0).sum() == 0
     eng, params = _engine(sc, w, [0.25])
     eng.run()
-    torch.cuda.synchronize()
+    eng.finish()
     g = (sc["params"] - params.cpu().numpy()) / 0.25
     np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
     assert abs(g[6, 1]) > 0 and np.abs(g[:6, 1]).max() < 1e-9
@@ -198,7 +198,7 @@ def test_engine_hypothesis_leaving_the_frame():
     # and the engine keeps working on later iterations (tile flags / zbuf re-armed correctly)
     eng2, p2 = _engine(sc, w, [0.01] * 4)
     eng2.run()
-    torch.cuda.synchronize()
+    eng2.finish()
     p_ref, logs_ref, _ = R.optimise(sc["params"], sc["lr_mult"], [0.01] * 4)
     np.testing.assert_allclose(p2.cpu().numpy(), p_ref, rtol=0, atol=2e-5)
 
@@ -216,7 +216,7 @@ def test_engine_with_edge_extension_tracks_oracle_over_iterations():
     p_ref, logs_ref, _ = R.optimise(sc["params"], sc["lr_mult"], lrs)
     eng, params = _engine(sc, w, lrs)
     eng.run()
-    torch.cuda.synchronize()
+    eng.finish()
     eng.check()
     p_gpu = params.cpu().numpy()
     for b in range(sc["B"]):
@@ -251,7 +251,7 @@ def test_engine_full_size_one_hypothesis_against_oracle_and_batch_properties(row
     lr = 0.25
     eng, p = _engine(sc, weights, [lr])
     eng.run()
-    torch.cuda.synchronize()
+    eng.finish()
     eng.check()
     lg = eng.losses()[0].cpu().numpy()
     pn = p.cpu().numpy()
@@ -267,7 +267,7 @@ def test_engine_full_size_one_hypothesis_against_oracle_and_batch_properties(row
     sc1 = dict(sc, params=params[:, 2:3].copy(), lr_mult=lrm[2:3].copy(), B=1)
     eng1, p1 = _engine(sc1, weights, [lr])
     eng1.run()
-    torch.cuda.synchronize()
+    eng1.finish()
     np.testing.assert_allclose(eng1.losses()[0].cpu().numpy()[:, 0], lg[:, 2], rtol=1e-6, atol=0)
     g1 = (params[:, 2] - p1.cpu().numpy()[:, 0]) / lr
     # (gradients are read back as parameter differences: resolution ulp(7.5) / lr = 2e-6, x16 for the batch of one)
@@ -301,7 +301,8 @@ def test_engine_eval_pass_gradient_against_oracle_and_torch_optimizer(weights):
     eng.run(3)
     eng2, params2 = _engine(sc, weights, [0.1] * 30)
     eng2.run(3)
-    torch.cuda.synchronize()
+    eng.finish()
+    eng2.finish()
     assert torch.equal(params, params2) and torch.equal(eng.losses(), eng2.losses())
     # torch.optim on the fused path
     p = torch.tensor(sc["params"], device="cuda", requires_grad=True)
@@ -374,7 +375,7 @@ def test_engine_close_up_dense_mesh_scatter_variants_agree(monkeypatch):
             monkeypatch.setenv("DDX_SCATTER_EXCHANGE", mode)
         eng, p = _engine(sc, weights, lrs)
         eng.run()
-        torch.cuda.synchronize()
+        eng.finish()
         eng.check()
         runs[mode] = (eng.losses().cpu().numpy().copy(), p.cpu().numpy().copy())
     for mode in ("1", None):
@@ -397,7 +398,7 @@ def test_engine_large_batch_not_a_multiple_of_eight():
     lr = 0.25
     eng, p = _engine(sc, weights, [lr])
     eng.run()
-    torch.cuda.synchronize()
+    eng.finish()
     eng.check()
     lg = eng.losses()[0].cpu().numpy()
     pn = p.cpu().numpy()
@@ -431,7 +432,7 @@ def test_forward_backward_pair_and_standalone_optimiser_steps():
     p_manual = p.clone()
     _lib.check(lib.ddx_sgd_step(p_manual.data_ptr(), g.data_ptr(), lrs[0], p_manual.numel(), _lib.stream_ptr()), "sgd")
     eng.run(1)
-    torch.cuda.synchronize()
+    eng.finish()
     assert torch.equal(p_manual, p)
     # Adam against torch.optim.Adam on the same gradients
     x = torch.randn(7, 4, device="cuda")
@@ -446,3 +447,4 @@ def test_forward_backward_pair_and_standalone_optimiser_steps():
                                      _lib.stream_ptr()), "adam")
     torch.cuda.synchronize()
     np.testing.assert_allclose(x.cpu().numpy(), x_t.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
