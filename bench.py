@@ -87,7 +87,7 @@ def cpu_baseline(w, budget_s=12.0):
         kw = dict(uv=npy(w["uv"]), tex=npy(w["tex"])) if w["tex"] is not None else dict(vtx_color=npy(w["vtx_color"]))
         wts = {k: w["weights"].get(k) for k in ("rgb", "depth", "mask", "edge")}
         return orc.RenderOracle(npy(w["pos"]), npy(w["tri"]), npy(w["proj"]), w["H"], w["W"], {k: npy(v) for k, v in w["gt"].items()}, wts,
-                                dtype=np.float32, **kw)
+                                dtype=np.float32, cull_backfaces=True, **kw)
 
     R = oracle_of(w)
     B = w["B"]

@@ -25,8 +25,8 @@ class EngineDesc(ctypes.Structure):
         ("optimizer", ctypes.c_int32),
         ("adam_beta1", ctypes.c_float), ("adam_beta2", ctypes.c_float), ("adam_eps", ctypes.c_float),
         ("max_iters", ctypes.c_int32), ("use_edge", ctypes.c_int32), ("w_edge", ctypes.c_float),
-        ("shade_slices", ctypes.c_int32), ("edge_slices", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("shade_slices", ctypes.c_int32), ("edge_slices", ctypes.c_int32), ("no_backface_cull", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "ddx_sgd_step": (_I, [_P, _P, ctypes.c_float, _I, _P]),
     "ddx_adam_step": (_I, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "ddx_engine_status_ptr": (_P, [_P]),
+    "ddx_engine_cull_sign": (_I, [_P]),
     "ddx_engine_profile": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I, _P]),
     "ddx_engine_destroy": (None, [_P]),
 }

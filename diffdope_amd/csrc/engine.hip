@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 #ifdef DDX_TRACE
@@ -97,6 +98,7 @@ struct EngineDev {
     int4* trisort;    // [T] {v0,v1,v2,id}: triangles in Morton order of their object-space centroids (scatter_kernel's processing order)
     float4* crec;     // [T,4] (textured) or [T,5] (vertex colours): what the colour role needs of a covered triangle, in ONE
                       // record fetched by triangle id: object-space positions of the 3 vertices (9), then uv (6) or colours (9)
+    int* cull_ok;     // [B,8] per vertex slice of the transform: every vertex inside the view volume (RasterScratch::cull_ok)
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     float4* texq;     // [Th*Tw,4] the texture as one 64-byte record per texel (x,y): the 2x2 bilinear footprint whose corner it
                       // is -- (x,y), (x+1,y), (x,y+1), (x+1,y+1) with wrap, rgb each, 4 floats of padding -- or null.  A
@@ -145,6 +147,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_adam = carve((size_t)2 * 14 * d.B * sizeof(float));
     const size_t o_par = carve((size_t)2 * 7 * d.B * sizeof(float));
     const size_t o_etmp = carve((size_t)7 * d.B * sizeof(float));
+    const size_t o_cull = carve((size_t)d.B * 8 * sizeof(int));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_sgd = carve(d.use_depth ? (size_t)d.H * d.W * sizeof(float) : 0);
@@ -173,6 +176,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.adam = (float*)(p + o_adam);
     E.params2 = (float*)(p + o_par);
     E.eval_tmp = (float*)(p + o_etmp);
+    E.cull_ok = (int*)(p + o_cull);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.seg_gd = (float*)(p + o_sgd);
@@ -344,7 +348,7 @@ __device__ __forceinline__ void final_row(const float pr[4], const float M[16], 
 // B = p[k] (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain), then the
 // 1/256-pixel window-coordinate snap.  Must be called by all 64 lanes of a wave.
 __device__ __forceinline__ void xfm_vertex_regs(const EngineDev& E, const float Fr[4] /* row lane % 4 of final */, int b, int n, bool live,
-                                                float px, float py, float pz)
+                                                float px, float py, float pz, bool& inside /* &= vertex inside the view volume */)
 {
     const int V = E.d.V;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -355,16 +359,28 @@ __device__ __forceinline__ void xfm_vertex_regs(const EngineDev& E, const float 
     if (!live) return;
     *reinterpret_cast<f32x4*>(E.clip + ((size_t)b * V + n) * 4) = acc;
     E.L.snap[(size_t)b * V + n] = snap_vertex(make_float4(acc.x, acc.y, acc.z, acc.w), E.d.H, E.d.W);
+    inside = inside && acc.w > 0.f && acc.z >= -acc.w && acc.z <= acc.w;  // (NaN: false)
+}
+
+// cull_ok[b][slice] = every lane of the workgroup kept `inside`.  All 256 threads must call; s_bad was zeroed before an
+// earlier barrier of the caller.
+__device__ __forceinline__ void cull_ok_store(const EngineDev& E, int* s_bad, bool inside, int b, int slice)
+{
+    if (!inside) *s_bad = 1;  // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0) E.cull_ok[(size_t)b * 8 + slice] = *s_bad ? 0 : 1;
 }
 
 // pose -> matrices -> clip-space vertices -> snapped window coordinates for the FIRST iteration of a run
-// (later iterations get theirs from update_xfm_kernel).  Every lane rebuilds its hypothesis' matrices from
-// the 7 parameters (uniform scalar loads, ~150 flops: cheaper than a separate launch + a dependent load).
+// (later iterations get theirs from update_xfm_kernel).  Grid (B, vertex slices): the slicing of update_xfm_kernel, so that
+// both leave the same per-slice view-volume flags (cull_ok).  Every lane rebuilds its hypothesis' matrices from the 7
+// parameters (uniform scalar loads, ~150 flops: cheaper than a separate launch + a dependent load).
 __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
 {
-    const int b = blockIdx.y, B = E.d.B, V = E.d.V;
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x, slice = blockIdx.y, B = E.d.B, V = E.d.V;
+    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
     float q[4], t[3], M[16], F[16], pr[4], Fr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = E.b.params[(size_t)i * B + b];
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
     for (int k = 0; k < 4; ++k) pr[k] = E.b.proj[(lane & 3) * 4 + k];
     pose_matrices(q, t, E.b.proj, M, F);
     final_row(pr, M, Fr);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (slice == 0 && tid == 0) {
         const int it = E.st->it;
         if (b == 0) E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
         E.L.bigcount[b] = 0;              // the hypothesis' list of large triangles, filled again by scatter_kernel
@@ -390,9 +406,18 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
             if (logm) logm[i] = M[i];
         }
     }
-    const bool live = n < V;
-    const float* p = E.spos + (size_t)(live ? n : 0) * 3;
-    xfm_vertex_regs(E, Fr, b, n, live, p[0], p[1], p[2]);
+    const int n_slices = (int)gridDim.y;
+    const int per = (V + n_slices - 1) / n_slices;
+    const int n_begin = slice * per, n_end = min(V, n_begin + per);
+    bool inside = true;
+    for (int n0 = n_begin; n0 < n_end; n0 += 256) {  // (workgroup-uniform trip count: every lane reaches the matrix-core ops)
+        const int n = n0 + tid;
+        const bool live = n < n_end;
+        const float* p = E.spos + (size_t)(live ? n : 0) * 3;
+        xfm_vertex_regs(E, Fr, b, n, live, p[0], p[1], p[2], inside);
+    }
+    __syncthreads();  // (s_bad = 0 is visible)
+    cull_ok_store(E, &s_bad, inside, b, slice);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1145,6 +1170,8 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     __shared__ float sG[16];
     __shared__ float sgrad[8];
     __shared__ int s_tiles[256];
+    __shared__ int s_bad;  // a vertex of this slice left the view volume (cull_ok)
+    if (threadIdx.x == 0) s_bad = 0;
     const int it = E.st->it;
     const int NT = E.L.NT;
     DDX_TRACE_BEGIN();
@@ -1414,6 +1441,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     }
     // positions of 4 strides are fetched before any is consumed (a load-transform-store loop would pay one
     // memory round trip per stride); the first batch was requested at the top of the kernel
+    bool inside = true;
     for (int n0 = n_begin; n0 < n_end; n0 += 4 * 256) {
         if (n0 > n_begin) {
 #pragma unroll
@@ -1426,9 +1454,10 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int n = n0 + u * 256 + tid;
-            if (n0 + u * 256 < n_end) xfm_vertex_regs(E, Fr, b, n, n < n_end, px[u], py[u], pz[u]);
+            if (n0 + u * 256 < n_end) xfm_vertex_regs(E, Fr, b, n, n < n_end, px[u], py[u], pz[u], inside);
         }
     }
+    cull_ok_store(E, &s_bad, inside, b, slice);  // for the next iteration's scatter_kernel
     UPH(7);
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
     if (tid == 0) {
@@ -1488,7 +1517,7 @@ static int run_prologue(ddx_engine* e, int it0, hipStream_t s)
         e->adam_parity = it0 & 1;
     }
     set_it_kernel<<<1, 1, 0, s>>>(E.st, it0);
-    pose_xfm_kernel<<<dim3(ddx_cdiv(E.d.V, 256), E.d.B), 256, 0, s>>>(E);
+    pose_xfm_kernel<<<dim3(E.d.B, upd_slices(E.d)), 256, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -1737,6 +1766,67 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         DDX_LAUNCH_CHECK();
         DDX_HIP(hipStreamSynchronize(s));  // (the host vectors above are the copy sources)
         E.L.trisort = E.trisort;
+        // ---- back-face culling (RasterScratch::cull_sign): only for a CLOSED, consistently oriented surface.  Vertices are
+        // welded by position (bit-equal coordinates: uv seams duplicate vertices), triangles with two welded corners equal are
+        // ignored (they have no area in any view), and every welded edge must then belong to exactly two triangles that run
+        // through it in opposite directions.  Which snapped-area sign is a back face: a triangle p0 p1 p2 in camera space has
+        // det [p0; p1; p2] > 0 exactly when its counter-clockwise normal points away from the camera; the projection maps that
+        // determinant to the screen orientation times det A, A = the x, y, w rows of proj (their 4th column must be zero, as
+        // in any pinhole projection); and counter-clockwise is outward when the signed volume is positive.
+        E.L.cull_sign = 0;
+        E.L.cull_ok = E.cull_ok;
+        DDX_HIP(hipMemsetD32Async((hipDeviceptr_t)E.cull_ok, 1, (size_t)E.d.B * 8, s));
+        bool want = !E.d.no_backface_cull;
+        if (const char* ov = getenv("DDX_NO_CULL")) want = want && !atoi(ov);
+        if (want) {
+            std::vector<unsigned long long> vk((size_t)V);
+            std::vector<int> canon((size_t)V), order((size_t)V);
+            for (int v = 0; v < V; ++v) order[(size_t)v] = v;
+            auto bits = [&](int v, int c) { unsigned u; float f = hpos[(size_t)v * 3 + c] + 0.0f; memcpy(&u, &f, 4); return u; };  // (+0: -0 == 0)
+            std::sort(order.begin(), order.end(), [&](int a, int b) {
+                for (int c = 0; c < 3; ++c) { const unsigned x = bits(a, c), y = bits(b, c); if (x != y) return x < y; }
+                return a < b;
+            });
+            for (int i = 0; i < V; ++i) {
+                const int v = order[(size_t)i];
+                const bool same = i > 0 && bits(v, 0) == bits(order[(size_t)i - 1], 0) && bits(v, 1) == bits(order[(size_t)i - 1], 1) &&
+                                  bits(v, 2) == bits(order[(size_t)i - 1], 2);
+                canon[(size_t)v] = same ? canon[(size_t)order[(size_t)i - 1]] : v;
+            }
+            bool closed = true;
+            double vol6 = 0.0;
+            std::vector<unsigned long long> ek;  // (lo << 32 | hi) << 1 | direction
+            ek.reserve((size_t)T * 3);
+            for (int t = 0; t < T && closed; ++t) {
+                const int i0 = htri[(size_t)t * 3], i1 = htri[(size_t)t * 3 + 1], i2 = htri[(size_t)t * 3 + 2];
+                if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= V || i1 >= V || i2 >= V) { closed = false; break; }
+                const int c[3] = {canon[(size_t)i0], canon[(size_t)i1], canon[(size_t)i2]};
+                if (c[0] == c[1] || c[1] == c[2] || c[0] == c[2]) continue;
+                const double x0 = hpos[(size_t)i0 * 3], y0 = hpos[(size_t)i0 * 3 + 1], z0 = hpos[(size_t)i0 * 3 + 2];
+                const double x1 = hpos[(size_t)i1 * 3], y1 = hpos[(size_t)i1 * 3 + 1], z1 = hpos[(size_t)i1 * 3 + 2];
+                const double x2 = hpos[(size_t)i2 * 3], y2 = hpos[(size_t)i2 * 3 + 1], z2 = hpos[(size_t)i2 * 3 + 2];
+                vol6 += x0 * (y1 * z2 - z1 * y2) - y0 * (x1 * z2 - z1 * x2) + z0 * (x1 * y2 - y1 * x2);
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned a = (unsigned)c[k], bq = (unsigned)c[(k + 1) % 3];
+                    const unsigned lo = a < bq ? a : bq, hi = a < bq ? bq : a;
+                    ek.push_back(((((unsigned long long)lo << 31) | hi) << 1) | (a < bq ? 1u : 0u));  // (V < 2^31)
+                }
+            }
+            if (closed) {
+                std::sort(ek.begin(), ek.end());
+                closed = !ek.empty() && ek.size() % 2 == 0;
+                for (size_t i = 0; closed && i < ek.size(); i += 2)
+                    closed = (ek[i] >> 1) == (ek[i + 1] >> 1) && (ek[i] & 1) != (ek[i + 1] & 1) && (i + 2 >= ek.size() || (ek[i + 2] >> 1) != (ek[i] >> 1));
+            }
+            float hp[16];
+            DDX_HIP(hipMemcpyAsync(hp, E.b.proj, sizeof(hp), hipMemcpyDeviceToHost, s));
+            DDX_HIP(hipStreamSynchronize(s));
+            const double detA = (double)hp[0] * ((double)hp[5] * hp[14] - (double)hp[6] * hp[13]) - (double)hp[1] * ((double)hp[4] * hp[14] - (double)hp[6] * hp[12]) +
+                                (double)hp[2] * ((double)hp[4] * hp[13] - (double)hp[5] * hp[12]);
+            const bool pinhole = hp[3] == 0.f && hp[7] == 0.f && hp[15] == 0.f;
+            if (closed && pinhole && vol6 != 0.0 && detA != 0.0 && std::isfinite(vol6) && std::isfinite(detA))
+                E.L.cull_sign = ((vol6 > 0.0) == (detA > 0.0)) ? 1 : -1;
+        }
     }
     // ---- which scatter variant: expected covered centres per triangle, from the observed segmentation mask (the hypotheses
     // render the object at about the observed size; front and back faces both produce fragments).  Above about one centre per
@@ -1949,6 +2039,8 @@ extern "C" int ddx_adam_step(float* params, const float* grad, float* exp_avg, f
 }
 
 extern "C" const int32_t* ddx_engine_status_ptr(ddx_engine* e) { return e ? &e->dev.st->overflow : nullptr; }
+
+extern "C" int ddx_engine_cull_sign(ddx_engine* e) { return (e && e->setup_done) ? e->dev.L.cull_sign : 0; }
 
 extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_out, const char** names_out, int max_k, void* stream)
 {

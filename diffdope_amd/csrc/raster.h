@@ -21,6 +21,15 @@ struct RasterScratch {
     size_t zper;              // entries per hypothesis = zwb * ceil(H/4) * 16
     int zwb;                  // 4x4 blocks per row = ceil(W/4)
     const int4* trisort;      // [T] or null: the triangles in the processing order of scatter_kernel, {v0, v1, v2, original id}
+    // Back-face culling for CLOSED meshes (fused engine only; the op-level entry draws both faces like nvdiffrast).  A closed,
+    // consistently oriented surface that lies entirely inside the view volume covers every pixel centre with as many front- as
+    // back-facing triangles, and the nearest one is front-facing: skipping the back faces changes nothing in exact arithmetic
+    // (deviation D5) and halves the fragments.  cull_sign: 0 = off; +1 / -1 = triangles whose SNAPPED area
+    // has this sign are back faces (sign(signed volume) * sign(det of proj's x,y,w rows), decided once per engine on the host).
+    // cull_ok [B,8] (null = never): per vertex slice of the transform, 1 when every vertex it produced has w > 0 and
+    // -w <= z <= w; a hypothesis culls only while all its slices say so (else its drawn surface may be open).
+    int cull_sign;
+    const int* cull_ok;
     int scatter_exchange;     // 1: expect more than ~1 covered centre per triangle -- scatter_kernel's fragment-exchange variant
                               // (lane j takes record j; ids in zbuf stay the original ones, so the result does not depend on it)
     size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount)

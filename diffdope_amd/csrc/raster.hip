@@ -65,6 +65,8 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.zper = zper;
     L.zwb = zwb;
     L.trisort = nullptr;
+    L.cull_sign = 0;
+    L.cull_ok = nullptr;
     L.scatter_exchange = 0;
     L.ntx = ntx; L.nty = nty; L.NT = (int)NT;
     L.ndc.xs = 2.0f / (float)W; L.ndc.xo = 1.0f / (float)W - 1.0f;  // as make_pixndc (host float division is IEEE too)
@@ -142,7 +144,7 @@ struct ScatterCov { scatter_mask_t mask; int px0, py0, nxp; };
 #endif
 template <int WALK>
 __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int H, int W, const RasterScratch& L, int b, int t,
-                                                int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c, ScatterCov& cv)
+                                                int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c, ScatterCov& cv, int cull)
 {
     cv.mask = 0; cv.px0 = 0; cv.py0 = 0; cv.nxp = 1;
     unsigned range = ~0u;  // packed tile range of a LARGE triangle
@@ -160,7 +162,7 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
             if (small) {
                 // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
                 const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
-                if (area != 0) {
+                if (area != 0 && !(cull != 0 && (area < 0) == (cull < 0))) {  // (non-degenerate and not a culled back face)
                     const bool flip = area < 0;
                     const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
                     const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
@@ -208,7 +210,7 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                 }
             } else {
                 const long long area = (long long)(bq.x - a.x) * (long long)(c.y - a.y) - (long long)(c.x - a.x) * (long long)(bq.y - a.y);
-                alive = area != 0;
+                alive = area != 0 && !(cull != 0 && (area < 0) == (cull < 0));
             }
             if (alive) {
                 // tiles under bbox + 1 px: every pixel adjacent to a covered pixel lies in an active tile
@@ -327,6 +329,14 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
         va[k] = S[j0]; vb[k] = S[j1]; vc[k] = S[j2];
     }
     SPH(2);
+    // back-face culling of this hypothesis in this pass (see RasterScratch::cull_sign): only while every vertex slice of the
+    // transform reported the whole object inside the view volume (uniform: scalar loads)
+    int cull = 0;
+    if (L.cull_sign != 0 && L.cull_ok) {
+        const int* ck = L.cull_ok + (size_t)b * 8;
+        const bool all_ok = (ck[0] & ck[1] & ck[2] & ck[3] & ck[4] & ck[5] & ck[6] & ck[7]) != 0;
+        cull = all_ok ? L.cull_sign : 0;
+    }
     unsigned range[SCATTER_TPL];
     ScatterCov cv[SCATTER_TPL];
 #pragma unroll
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
         if (t[k] >= T || !ok[k]) continue;
         // (plain variant: triangle by triangle -- coverage of both triangles first and all fragments afterwards measured
         // 2 us slower on cfg2: more atomics in flight at once make the atomicMin stream slower)
-        range[k] = scatter_one<MODE == 0 ? 1 : MODE == 2 ? 2 : 0>(pos, V, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k]);
+        range[k] = scatter_one<MODE == 0 ? 1 : MODE == 2 ? 2 : 0>(pos, V, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k], cull);
     }
     SPH(3);
     // ---- fragments.  A lane owns 0..64 covered centres of its triangle, most lanes none: walked lane by lane the wave runs

@@ -43,11 +43,13 @@ class RefineEngine:
         global_batch: batch size of the whole job when hypotheses are sharded over GPUs
         shade_slices / edge_slices: workgroups per hypothesis of the shading / edge launches (0 = from B).  A shard
             that must reproduce the unsharded run bit for bit passes the unsharded engine's `slices` (ddx.h)
+        cull_backfaces: skip the back faces of a closed mesh while a hypothesis lies inside the view volume (ddx.h
+            no_backface_cull; identical visibility in exact arithmetic).  False = always draw both faces.
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
                  vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True, shade_slices=0,
-                 edge_slices=0):
+                 edge_slices=0, cull_backfaces=True):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":
@@ -87,6 +89,7 @@ class RefineEngine:
         d.adam_beta1, d.adam_beta2, d.adam_eps = adam
         d.max_iters = n_it
         d.shade_slices, d.edge_slices = int(shade_slices), int(edge_slices)
+        d.no_backface_cull = int(not cull_backfaces)
         self.desc = d
         nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))
         if nbytes == 0:
@@ -141,6 +144,11 @@ class RefineEngine:
         """(shade_slices, edge_slices) this engine runs with: what a shard of this batch passes to reproduce it bitwise."""
         auto = lambda grid: max(1, min(64, grid // self.B))
         return (self.desc.shade_slices or auto(1024), self.desc.edge_slices or auto(1792))
+
+    @property
+    def cull_sign(self):
+        """0 = both faces drawn; +-1 = back faces (snapped area of that sign) culled (decided by the first run / eval)."""
+        return int(self.lib.ddx_engine_cull_sign(self.handle))
 
     def rewind(self, it=0):
         self.it = it

@@ -27,6 +27,12 @@ def blob_mesh(rows, cols, seed=0, radius=0.5, noise=0.18):
     x = radius * ax[0] * r * np.sin(TH) * np.cos(PH)
     y = radius * ax[1] * r * np.sin(TH) * np.sin(PH)
     z = radius * ax[2] * r * np.cos(TH)
+    # a CLOSED surface, bit for bit: the uv seam duplicates the first column of vertices (sin / cos of 2 pi are not exactly
+    # those of 0) and every vertex of a pole row is the pole itself -- like the duplicated seam vertices of a textured scan
+    for a in (x, y, z):
+        a[:, -1] = a[:, 0]
+    x[0, :] = 0.0; y[0, :] = 0.0; z[0, :] = z[0, 0]
+    x[-1, :] = 0.0; y[-1, :] = 0.0; z[-1, :] = z[-1, 0]
     pos = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
     uv = np.stack([PH / (2 * math.pi), TH / math.pi], axis=-1).reshape(-1, 2).astype(np.float32)
     idx = np.arange((rows + 1) * (cols + 1)).reshape(rows + 1, cols + 1)

@@ -152,7 +152,12 @@ typedef struct ddx_engine_desc {
      * run BIT FOR BIT passes the unsharded run's counts here (tests/test_gpu_engine.py::test_engine_shard_invariance);
      * with 0 the shards agree with the unsharded run to fp32 rounding of that sum. */
     int32_t shade_slices, edge_slices;
-    int32_t reserved[4];
+    /* != 0: draw both faces of every triangle, always.  0 (default): when the mesh is a closed, consistently oriented surface
+     * (checked once, vertices welded by position) the rasteriser skips back-facing triangles of every hypothesis that lies
+     * entirely inside the view volume -- they are hidden behind front faces there, so this changes nothing in exact
+     * arithmetic (deviation D5) and halves the fragment work.  Environment DDX_NO_CULL=1 also disables. */
+    int32_t no_backface_cull;
+    int32_t reserved[3];
 } ddx_engine_desc;
 
 typedef struct ddx_engine_buffers {
@@ -217,6 +222,10 @@ int ddx_select_best(const float* loss_rows, int row_mask, int B, const float* mt
 /* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
  * iteration, [2] active tiles of the last iteration, [3] next iteration index, [4] pixels with seg != 0 */
 const int32_t* ddx_engine_status_ptr(ddx_engine* e);
+/* 0: the engine draws both faces (mesh not closed, projection not a pinhole, no_backface_cull, or not set up yet: the
+ * decision is taken by the first run / eval); +1 / -1: triangles whose snapped screen area has this sign are culled as back
+ * faces in hypotheses that lie inside the view volume. */
+int ddx_engine_cull_sign(ddx_engine* e);
 /* per-kernel launch durations of the last ddx_engine_profile call are returned in ms (host array
  * of `n_kernels`), measured with hipEvents on `stream`; returns the number of kernels. */
 int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_out, const char** names_out, int max_k,

@@ -126,13 +126,55 @@ def argmin_losses(losses_values):
 
 # --------------------------------------------------------------------------------------------
 # renderer ops (nvdiffrast semantics at diffdope.py:143-231) -- parity unpinned
-def rasterize_fwd(pos, tri, H, W):
+def rasterize_fwd(pos, tri, H, W, cull_sign=0):
     dt = pos.dtype
     pos, tri = _c(pos, dt), _i32(tri)
     B, V = pos.shape[:2]
     rast = np.empty((B, H, W, 4), dt)
-    _lib(dt).orc_rasterize_fwd(_p(pos), B, V, _p(tri), tri.shape[0], H, W, _p(rast))
+    _lib(dt).orc_rasterize_fwd(_p(pos), B, V, _p(tri), tri.shape[0], H, W, _p(rast), int(cull_sign))
     return rast
+
+
+def mesh_cull_sign(pos, tri, proj):
+    """Deviation D5 (fused engine only): the sign of the snapped screen area of BACK-facing triangles when `pos`/`tri` is a closed,
+    consistently oriented surface and `proj` a pinhole projection, else 0 (draw both faces).  Vertices are welded by position
+    (bit-equal float32 coordinates: uv seams duplicate vertices); triangles with two welded corners equal are ignored; every
+    welded edge must belong to exactly two triangles running through it in opposite directions.  A camera-space triangle has
+    det[p0;p1;p2] > 0 exactly when its counter-clockwise normal points away from the camera; the projection multiplies that
+    orientation by det A (A = rows x, y, w of proj, whose 4th column must vanish), and counter-clockwise is outward when the
+    signed volume is positive: sign = sign(volume) * sign(det A)."""
+    pos32 = np.ascontiguousarray(pos, np.float32) + np.float32(0)  # (-0 -> +0)
+    tri = np.asarray(tri, np.int64)
+    V = pos32.shape[0]
+    if tri.size == 0 or tri.min() < 0 or tri.max() >= V:
+        return 0
+    _, canon = np.unique(pos32.view(np.uint32).reshape(V, 3), axis=0, return_inverse=True)
+    c = np.asarray(canon).reshape(-1)[tri]
+    keep = (c[:, 0] != c[:, 1]) & (c[:, 1] != c[:, 2]) & (c[:, 0] != c[:, 2])
+    c, t = c[keep], tri[keep]
+    if len(c) == 0:
+        return 0
+    a = np.concatenate([c[:, 0], c[:, 1], c[:, 2]])
+    b = np.concatenate([c[:, 1], c[:, 2], c[:, 0]])
+    lo, hi, fwd = np.minimum(a, b), np.maximum(a, b), (a < b)
+    key = lo.astype(np.int64) * (V + 1) + hi
+    order = np.argsort(key, kind="stable")
+    key, fwd = key[order], fwd[order]
+    if len(key) % 2:
+        return 0
+    k0, k1, f0, f1 = key[0::2], key[1::2], fwd[0::2], fwd[1::2]
+    if not (np.all(k0 == k1) and np.all(f0 != f1) and np.all(k0[1:] != k0[:-1])):
+        return 0
+    p = np.asarray(pos, np.float64)
+    p0, p1, p2 = p[t[:, 0]], p[t[:, 1]], p[t[:, 2]]
+    vol6 = float(np.einsum("ij,ij->i", p0, np.cross(p1, p2)).sum())
+    P = np.asarray(proj, np.float64)
+    if not (P[0, 3] == 0 and P[1, 3] == 0 and P[3, 3] == 0):
+        return 0
+    detA = float(np.linalg.det(P[[0, 1, 3]][:, :3]))
+    if vol6 == 0 or detA == 0 or not np.isfinite(vol6 * detA):
+        return 0
+    return 1 if (vol6 > 0) == (detA > 0) else -1
 
 
 def rasterize_bwd(pos, tri, rast, drast):
@@ -264,7 +306,7 @@ class RenderOracle:
     build's extension, see orc_loss_edge).
     """
 
-    def __init__(self, pos, tri, proj, H, W, gt, weights, uv=None, tex=None, vtx_color=None, dtype=np.float32):
+    def __init__(self, pos, tri, proj, H, W, gt, weights, uv=None, tex=None, vtx_color=None, dtype=np.float32, cull_backfaces=False):
         self.dt = np.dtype(dtype)
         self.pos = _c(pos, self.dt)
         self.tri = _i32(tri)
@@ -276,6 +318,10 @@ class RenderOracle:
         self.vtx_color = None if vtx_color is None else _c(vtx_color, self.dt)
         self.gt = {k: _c(v, self.dt)[None] for k, v in gt.items()}
         self.weights = weights
+        # cull_backfaces=True: the fused engine's visibility (deviation D5: back faces of a closed mesh skipped while a hypothesis
+        # lies inside the view volume); False: nvdiffrast's (both faces), what the op-level renderer ops implement
+        self.cull_backfaces = cull_backfaces
+        self._cull_sign = None
 
     def render(self, mtx):
         """Forward graph; returns dict of intermediates (all [B,...])."""
@@ -284,7 +330,9 @@ class RenderOracle:
         B = mtx.shape[0]
         final = np.matmul(self.proj[None], mtx).astype(dt)  # diffdope.py:195
         pos_clip = xfm_fwd(self.pos[None], final, True)  # :196
-        rast = rasterize_fwd(pos_clip, self.tri, self.H, self.W)  # :198
+        if self._cull_sign is None:
+            self._cull_sign = mesh_cull_sign(self.pos, self.tri, self.proj)
+        rast = rasterize_fwd(pos_clip, self.tri, self.H, self.W, self._cull_sign if self.cull_backfaces else 0)  # :198
         posw = np.concatenate([self.pos, np.ones((self.pos.shape[0], 1), dt)], axis=1)[None]
         gb_pos = interpolate_fwd(posw, rast, self.tri)  # :203
         gb3 = np.ascontiguousarray(gb_pos[..., :3]).reshape(B, -1, 3)

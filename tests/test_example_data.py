@@ -120,5 +120,9 @@ def test_example_scene_refines_with_the_reference_defaults():
     assert np.linalg.norm(p1[4:] - p0[4:]) < 0.5  # < 5 cm
     # reproducible, and the op-by-op path lands on the same hypothesis and pose
     assert torch.equal(a.object3d.params_tensor(), a2.object3d.params_tensor())
+    # (60 iterations with multipliers up to 100 amplify single-pixel differences between the two paths -- the fused engine culls the
+    # back faces of this closed mesh, the op-level ops draw both -- so the poses agree to a degree or so, not to rounding)
     assert int(b.get_argmin()) == best
-    np.testing.assert_allclose(a.get_pose(), b.get_pose(), atol=5e-3)
+    np.testing.assert_allclose(a.get_pose(), b.get_pose(), atol=5e-2)
+    lb = b.losses_values["mask_selection"].numpy()[-1, best]
+    assert abs(lb - curve[-1]) < 0.1 * curve[-1]

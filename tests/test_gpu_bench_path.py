@@ -22,7 +22,7 @@ def _oracle_for(w):
     kw = dict(uv=npy(w["uv"]), tex=npy(w["tex"])) if w["tex"] is not None else dict(vtx_color=npy(w["vtx_color"]))
     wts = {k: w["weights"].get(k) for k in ("rgb", "depth", "mask", "edge")}
     return orc.RenderOracle(npy(w["pos"]), npy(w["tri"]), npy(w["proj"]), w["H"], w["W"], {k: npy(v) for k, v in w["gt"].items()},
-                            wts, dtype=np.float32, **kw)
+                            wts, dtype=np.float32, cull_backfaces=True, **kw)
 
 
 def _pose_close(pa, pb, tol_rad=1e-3, tol_m=1e-3):

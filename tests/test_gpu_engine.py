@@ -126,6 +126,7 @@ def test_render_texture_batch_autograd_matches_oracle():
     for textured in (True, False):
         sc = make_scene(16, 20, 60, 80, B=2, dist=1.8, textured=textured)
         R = sc["oracle"]
+        R.cull_backfaces = False  # the op-level ops draw both faces, like nvdiffrast
         R.weights = dict(rgb=0.7, depth=1.0, mask=1.0)
         total, logs, g_ref, r_ref = R.loss_and_grad(sc["params"], sc["lr_mult"])
         B = sc["B"]
@@ -448,3 +449,51 @@ def test_forward_backward_pair_and_standalone_optimiser_steps():
     torch.cuda.synchronize()
     np.testing.assert_allclose(x.cpu().numpy(), x_t.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
 
+
+
+def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
+    """Deviation D5: on a closed mesh the engine skips back-facing triangles of hypotheses that lie inside the view volume.
+    (a) culling on / off give the same losses and gradients (bit-identical here: no pixel changes owner); (b) an OPEN mesh
+    (some triangles removed) is never culled; (c) a hypothesis that pokes through the far plane draws both faces again and
+    still matches the oracle, which applies the same rule."""
+    sc = make_scene(16, 20, 60, 80, B=3, dist=1.8)
+    w = dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.8)
+    res = []
+    for cull in (True, False):
+        eng, p = _engine(sc, w, [0.1], cull_backfaces=cull)
+        losses, grad = eng.loss_and_grad()
+        torch.cuda.synchronize()
+        assert eng.cull_sign == (-1 if cull else 0)
+        res.append((losses.cpu().numpy(), grad.cpu().numpy()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-6 * np.abs(res[1][1]).max())
+    # (b) open mesh: drop a band of triangles
+    keep = np.ones(len(sc["tri"]), bool)
+    keep[100:140] = False
+    sc_open = dict(sc, tri=sc["tri"][keep])
+    eng, _ = _engine(sc_open, w, [0.1])
+    l_open, g_open = eng.loss_and_grad()
+    torch.cuda.synchronize()
+    assert eng.cull_sign == 0
+    from oracle import oracle as orc
+
+    kw = dict(uv=sc["uv"], tex=sc["tex"])
+    Ro = orc.RenderOracle(sc["pos"], sc_open["tri"], sc["proj"], sc["H"], sc["W"], sc["gt"], w, dtype=np.float32, cull_backfaces=True, **kw)
+    assert orc.mesh_cull_sign(sc["pos"], sc_open["tri"], sc["proj"]) == 0
+    total, logs, g_ref, _ = Ro.loss_and_grad(sc["params"], sc["lr_mult"])
+    np.testing.assert_allclose(g_open.cpu().numpy(), g_ref, rtol=2e-3, atol=2e-3 * np.abs(g_ref).max())
+    # (c) hypothesis 1 straddles the far plane (zfar = 200): its back faces are drawn again; losses still match the oracle
+    far = sc["params"].copy()
+    far[6, 1] = -200.0
+    sc_far = dict(sc, params=far)
+    eng, _ = _engine(sc_far, w, [0.1])
+    l_far, g_far = eng.loss_and_grad()
+    torch.cuda.synchronize()
+    assert eng.cull_sign == -1
+    R = sc["oracle"]
+    R.weights = {k: w.get(k) for k in ("rgb", "depth", "mask", "edge")}
+    total, logs, g_ref, r_ref = R.loss_and_grad(far, sc["lr_mult"])
+    lg = l_far.cpu().numpy()
+    for i, key in enumerate(KEYS):
+        np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(g_far.cpu().numpy(), g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())

@@ -171,3 +171,51 @@ def test_d4_pixel_centre_exactly_on_an_unshared_edge():
     # and a centre NOT on an edge is decided identically by any rule: nudge the triangle by 1/64 pixel
     r3 = orc.rasterize_fwd(clip_from_pixels(pix + 1 / 64, H, W)[None], np.array([[0, 1, 2]], np.int32), H, W)
     assert not r3[0, 1, 3, 3] and not r3[0, 3, 1, 3] and r3[0, 2, 2, 3] and r3[0, 3, 3, 3]
+
+
+def test_d5_backface_culling_only_on_closed_meshes_and_invisible_there():
+    """D5 (fused engine only): on a CLOSED, consistently oriented mesh, hypotheses that lie entirely inside the view volume skip
+    their back-facing triangles.  nvdiffrast draws both faces; on a closed surface every pixel centre is covered by as many
+    front as back faces and the nearest is a front face, so the drawn image is the same: zero pixels change owner over a
+    sweep of poses here.  The rule switches itself off for open / inconsistently oriented meshes, non-pinhole projections and
+    for any hypothesis with a vertex outside the view volume (where the drawn surface may be open)."""
+    from diffdope_amd import synthetic as syn
+
+    pos, tri, uv = syn.blob_mesh(12, 16, seed=0)
+    H, W = 48, 64
+    proj = orc.projection_matrix(**syn.camera_intrinsics(W, H))
+    assert orc.mesh_cull_sign(pos, tri, proj) == -1  # outward-oriented mesh under the y-up pinhole: back faces snap to negative area
+    assert orc.mesh_cull_sign(pos, tri[:, [0, 2, 1]], proj) == 1  # the same surface oriented inward
+    assert orc.mesh_cull_sign(pos, tri[:-3], proj) == 0  # a hole
+    flipped = tri.copy()
+    flipped[37] = flipped[37][[0, 2, 1]]
+    assert orc.mesh_cull_sign(pos, flipped, proj) == 0  # one triangle wound the other way
+    bad_proj = proj.copy()
+    bad_proj[3, 3] = 1.0  # orthographic-style w row: not the pinhole the sign argument needs
+    assert orc.mesh_cull_sign(pos, tri, bad_proj) == 0
+    rng = np.random.RandomState(3)
+    changed = 0
+    for _ in range(24):
+        q = syn.random_quat(rng)
+        t = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), -rng.uniform(1.2, 3.0)])
+        mtx = orc.pose_fwd(np.concatenate([q, t])[:, None].astype(np.float32))
+        clip = orc.xfm_fwd(pos[None], np.matmul(proj[None].astype(np.float32), mtx), True)
+        a = orc.rasterize_fwd(clip, tri, H, W, 0)
+        b = orc.rasterize_fwd(clip, tri, H, W, -1)
+        assert (a[..., 3] > 0).sum() > 50
+        changed += int((a[..., 3] != b[..., 3]).sum())
+        np.testing.assert_allclose(a[..., 2], b[..., 2], rtol=0, atol=0)  # same depth image
+    assert changed == 0
+    # a hypothesis poking through the near plane is NOT culled (its drawn surface is open: the inside is visible)
+    mtx = orc.pose_fwd(np.array([[0.0], [0.0], [0.0], [1.0], [0.0], [0.0], [-0.3]], np.float32))
+    clip = orc.xfm_fwd(pos[None], np.matmul(proj[None].astype(np.float32), mtx), True)
+    assert (clip[0, :, 3] <= 0).any() or (np.abs(clip[0, :, 2]) > clip[0, :, 3]).any()
+    a = orc.rasterize_fwd(clip, tri, H, W, 0)
+    b = orc.rasterize_fwd(clip, tri, H, W, -1)
+    assert np.array_equal(a, b)
+    # what the rule avoids: FORCING it on an open surface removes what is seen through the hole
+    open_tri = tri[np.linalg.norm(pos[tri].mean(1) - pos[tri].mean(1)[0], axis=1) > 0.35]  # cut a cap off
+    mtx = orc.pose_fwd(np.concatenate([syn.random_quat(np.random.RandomState(0)), [0, 0, -2.0]])[:, None].astype(np.float32))
+    clip = orc.xfm_fwd(pos[None], np.matmul(proj[None].astype(np.float32), mtx), True)
+    both = np.stack([orc.rasterize_fwd(clip, open_tri, H, W, s)[0, ..., 3] > 0 for s in (0, -1)])
+    assert orc.mesh_cull_sign(pos, open_tri, proj) == 0 and both[0].sum() >= both[1].sum()
