@@ -127,6 +127,8 @@ struct ddx_engine {
     int graph_chunk = 1;  // iterations per captured graph
     bool setup_done = false;
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
+    int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
+                             // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1870,6 +1872,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
 extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream)
 {
     DDX_REQUIRE(e, DDX_E_NULL, "engine_run: NULL engine");
+    e->fwd_cached_it = -1;
     DDX_REQUIRE(it0 >= 0 && n >= 0 && it0 + n <= e->dev.d.max_iters, DDX_E_SHAPE, "engine_run: iterations [%d,%d) exceed max_iters=%d", it0,
                 it0 + n, e->dev.d.max_iters);
     hipStream_t s = (hipStream_t)stream;
@@ -1970,6 +1973,7 @@ extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* lo
 {
     DDX_REQUIRE(e && grad_out, DDX_E_NULL, "engine_eval: NULL pointer");
     DDX_REQUIRE(it >= 0 && it < e->dev.d.max_iters, DDX_E_SHAPE, "engine_eval: iteration %d outside [0,%d)", it, e->dev.d.max_iters);
+    e->fwd_cached_it = -1;
     hipStream_t s = (hipStream_t)stream;
     if (!e->setup_done)
         if (int err = engine_setup(e, s)) return err;
@@ -1987,12 +1991,19 @@ extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* lo
 extern "C" int ddx_render_loss_fwd(ddx_engine* e, int it, float* loss_out, void* stream)
 {
     DDX_REQUIRE(e && loss_out, DDX_E_NULL, "render_loss_fwd: NULL pointer");
-    return ddx_engine_eval(e, it, e->dev.eval_tmp, loss_out, stream);
+    const int err = ddx_engine_eval(e, it, e->dev.eval_tmp, loss_out, stream);
+    if (!err) e->fwd_cached_it = it;  // the gradient of this very pass is kept for the backward call of the pair
+    return err;
 }
 
 extern "C" int ddx_render_loss_bwd(ddx_engine* e, int it, float* grad_out, void* stream)
 {
     DDX_REQUIRE(e && grad_out, DDX_E_NULL, "render_loss_bwd: NULL pointer");
+    if (e->fwd_cached_it == it) {  // forward of the same pair ran last: its pass already produced the gradient
+        e->fwd_cached_it = -1;
+        DDX_HIP(hipMemcpyAsync(grad_out, e->dev.eval_tmp, (size_t)7 * e->dev.d.B * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return 0;
+    }
     return ddx_engine_eval(e, it, grad_out, nullptr, stream);
 }
 
@@ -2046,6 +2057,7 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
 {
     DDX_REQUIRE(e && ms_out, DDX_E_NULL, "engine_profile: NULL pointer");
     DDX_REQUIRE(it0 >= 0 && iters >= 1 && it0 + iters <= e->dev.d.max_iters && max_k >= K_COUNT, DDX_E_SHAPE, "engine_profile: bad range");
+    e->fwd_cached_it = -1;
     hipStream_t s = (hipStream_t)stream;
     if (!e->setup_done)
         if (int err = engine_setup(e, s)) return err;

@@ -118,13 +118,13 @@ __global__ __launch_bounds__(XFM_BLOCK) void xfm_bwd_mtx_kernel(const float* __r
                                                                 const float* __restrict__ matrix, int N,
                                                                 const float* __restrict__ dout,
                                                                 float* __restrict__ dpoints,
-                                                                float* __restrict__ dmatrix)
+                                                                float* __restrict__ dmatrix, int pts_per_block)
 {
     constexpr int R = POINTS ? 4 : 3;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n_begin = blockIdx.x * XFM_MTX_PTS_PER_BLOCK;
-    const int n_end = min(N, n_begin + XFM_MTX_PTS_PER_BLOCK);
+    const int n_begin = blockIdx.x * pts_per_block;
+    const int n_end = min(N, n_begin + pts_per_block);
     const float* P = points + (size_t)b * pbs;
     const float* G = dout + (size_t)b * N * R;
     __shared__ float red[4][16];
@@ -263,13 +263,17 @@ static int launch_bwd_mtx(const float* points, long long pbs, const float* matri
                           const float* dout, float* dpoints, float* dmatrix, int variant, hipStream_t s)
 {
     DDX_HIP(hipMemsetAsync(dmatrix, 0, (size_t)B * 16 * sizeof(float), s));
-    dim3 grid(ddx_cdiv(N, XFM_MTX_PTS_PER_BLOCK), B), block(XFM_BLOCK);
-    if (variant == 0) {
-        if (is_points) xfm_bwd_mtx_kernel<true, true, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
-        else xfm_bwd_mtx_kernel<true, false, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
+    // variant bit 1 (value 2): DETERMINISTIC -- one workgroup per hypothesis walks all N points in a fixed order and is the
+    // only one to add into dmatrix[b] (bit-reproducible; ~10x slower at N = 3e5 with few hypotheses).  Default: a workgroup
+    // per 4096 points, 16 fp32 atomicAdd per workgroup -- the sum order over workgroups then depends on scheduling.
+    const int ppb = (variant & 2) ? N : XFM_MTX_PTS_PER_BLOCK;
+    dim3 grid(ddx_cdiv(N, ppb), B), block(XFM_BLOCK);
+    if ((variant & 1) == 0) {
+        if (is_points) xfm_bwd_mtx_kernel<true, true, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix, ppb);
+        else xfm_bwd_mtx_kernel<true, false, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix, ppb);
     } else {
-        if (is_points) xfm_bwd_mtx_kernel<false, true, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
-        else xfm_bwd_mtx_kernel<false, false, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix);
+        if (is_points) xfm_bwd_mtx_kernel<false, true, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix, ppb);
+        else xfm_bwd_mtx_kernel<false, false, WITH_DP><<<grid, block, 0, s>>>(points, pbs, matrix, N, dout, dpoints, dmatrix, ppb);
     }
     DDX_LAUNCH_CHECK();
     return 0;

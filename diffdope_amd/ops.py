@@ -13,6 +13,15 @@ from . import _lib
 XFM_VARIANT = 0
 
 
+def _mtx_variant():
+    """Variant of the d_matrix kernels: + 2 = deterministic (one workgroup per hypothesis in a fixed order instead of fp32
+    atomicAdd across workgroups, ddx.h) when torch.use_deterministic_algorithms(True) or DDX_DETERMINISTIC=1 asks for it."""
+    import os
+
+    det = torch.are_deterministic_algorithms_enabled() or os.environ.get("DDX_DETERMINISTIC", "0") not in ("", "0")
+    return XFM_VARIANT | (2 if det else 0)
+
+
 def _check_tensor(t, name, rank, channels):
     # mirrors CHECK_TENSOR in torch_bindings.cpp:30-31,144-145 (device, dtype, rank, channels)
     if not isinstance(t, torch.Tensor):
@@ -70,7 +79,7 @@ class _Plugin:
         grad = grad.contiguous()
         dm = torch.empty((B, 4, 4), dtype=torch.float32, device=matrix.device)
         _lib.check(self.lib.ddx_xfm_bwd_mtx(_lib.ptr(points), pbs, B, N, int(isPoints), _lib.ptr(grad), _lib.ptr(dm),
-                                             XFM_VARIANT, _lib.stream_ptr()), "ddx_xfm_bwd_mtx")
+                                             _mtx_variant(), _lib.stream_ptr()), "ddx_xfm_bwd_mtx")
         return dm
 
     def xfm_bwd_full(self, points, matrix, grad, isPoints):
@@ -78,8 +87,9 @@ class _Plugin:
         grad = grad.contiguous()
         dp = torch.empty((B, N, 3), dtype=torch.float32, device=matrix.device)
         dm = torch.empty((B, 4, 4), dtype=torch.float32, device=matrix.device)
+        variant = _mtx_variant()
         _lib.check(self.lib.ddx_xfm_bwd_full(_lib.ptr(points), pbs, _lib.ptr(matrix), B, N, int(isPoints),
-                                              _lib.ptr(grad), _lib.ptr(dp), _lib.ptr(dm), XFM_VARIANT,
+                                              _lib.ptr(grad), _lib.ptr(dp), _lib.ptr(dm), variant,
                                               _lib.stream_ptr()), "ddx_xfm_bwd_full")
         return dp, dm
 

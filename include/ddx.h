@@ -50,7 +50,9 @@ const char* ddx_last_error(void);
  *   dout    same shape as out
  *   dpoints [B,N,3] dense (the reference returns a dense [B,N,3] even for broadcast points)
  *   dmatrix [B,4,4], fully written by the call (zero rows/cols where the op has no dependence)
- * variant: 0 = MFMA (v_mfma_f32_4x4x1_16b_f32), 1 = plain VALU fma (for A/B measurements).
+ * variant: bit 0: 0 = MFMA (v_mfma_f32_4x4x1_16b_f32), 1 = plain VALU fma (for A/B measurements); bit 1 (value 2), d_matrix
+ * kernels only: deterministic reduction -- one workgroup per hypothesis in a fixed order instead of one per 4096 points
+ * joined by fp32 atomicAdd (the default, whose sum order over workgroups depends on scheduling).
  * ------------------------------------------------------------------------------------------- */
 int ddx_xfm_fwd(const float* points, long long points_bstride, const float* matrix, int B, int N,
                 int is_points, float* out, int variant, void* stream);
@@ -204,7 +206,9 @@ int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* loss_out, voi
 /* The fused pass under the names of a forward / backward pair (what a torch.autograd.Function around the loss of
  * diffdope.py:1707-1711 binds): ddx_render_loss_fwd writes the weighted per-hypothesis losses [4,B], ddx_render_loss_bwd
  * d loss / d params [7,B] (the 7 nn.Parameters of diffdope.py:1019-1026).  Forward and analytic backward are ONE pass in
- * this engine, so each call runs it (= ddx_engine_eval); a caller that needs both calls ddx_engine_eval once. */
+ * this engine: ddx_render_loss_fwd runs it (= ddx_engine_eval) and keeps the gradient, so that a ddx_render_loss_bwd for the same
+ * iteration that follows it, with no other pass of the engine and no change of `params` in between, is a 7 B-float copy; a
+ * ddx_render_loss_bwd without that forward runs the pass itself.  A caller that wants both at once calls ddx_engine_eval. */
 int ddx_render_loss_fwd(ddx_engine* e, int it, float* loss_out, void* stream);
 int ddx_render_loss_bwd(ddx_engine* e, int it, float* grad_out, void* stream);
 /* Stand-alone optimiser steps over n floats (params [7,B] -> n = 7 B), for callers that run the evaluation pass and step

@@ -497,3 +497,46 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
     for i, key in enumerate(KEYS):
         np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
     np.testing.assert_allclose(g_far.cpu().numpy(), g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+
+
+@pytest.mark.parametrize("deg,frac,tol_rad", [(1.0, 0.01, 1e-3), (10.0, 0.04, 5e-3), (40.0, 0.16, None)])
+def test_pose_recovery_on_the_perturbation_tiers_of_the_dataset(deg, frac, tol_rad):
+    """K7 on the three perturbation tiers the reference's dataset files are named after
+    (data/*/*/scene_error_deg_{001,010,040}_trans_{001,004,016}.json, examples/run_bop_scene.py:27-89): the observation is rendered
+    from a known pose, ONE initial guess is that pose rotated by `deg` about a random axis and moved by `frac` of its distance,
+    and -- as in the reference -- every hypothesis starts from that same guess and differs only in its learning-rate
+    multiplier (here 32 of them, log-spaced over 0.05 .. 500, the spread of the reference's learning_rates_bound [0.01, 100];
+    SGD, the reference's decayed schedule, rgb + depth + mask).  On
+    the 1 deg / 1 % tier the arg-min hypothesis must come back to the generating pose within 1e-3 rad / 1e-3 m (north_star
+    tolerance); on the 10 deg / 4 % tier within 5e-3 rad / 1e-3 m (measured 3.4e-3 rad / 3e-4 m: the winner there is a x150
+    multiplier, whose last steps are still coarse at the end of the 10x decay); the 40 deg / 16 % tier is outside the basin
+    of a local method (measured: it settles in a neighbouring minimum with a lower loss, rotation error unchanged) -- only the
+    loss decrease and a finite pose are asserted."""
+    from oracle import oracle as orc
+
+    sc = make_scene(40, 64, 120, 160, B=1, dist=4.0, tex_size=64)
+    rng = np.random.RandomState(11)
+    q0, t0 = syn.perturb_pose(sc["q_gt"], sc["t_gt"], deg, frac, rng)
+    B = 32
+    params = np.tile(np.concatenate([q0, t0])[:, None], (1, B)).astype(np.float32)
+    lrm = np.geomspace(0.05, 500.0, B).astype(np.float32)
+    sc = dict(sc, params=params, lr_mult=lrm, B=B)
+    w = dict(rgb=0.7, depth=1.0, mask=1.0)
+    lrs = [l * 0.02 for l in orc.lr_schedule(299, 20, 0.1)]
+    eng, p = _engine(sc, w, lrs)
+    eng.run()
+    eng.finish()
+    eng.check()
+    lg = eng.losses().cpu().numpy()
+    best = int(np.argmin(lg[-1].mean(0)))
+    pb = p.cpu().numpy()[:, best]
+    ang0, dt0 = syn.rotation_geodesic(q0, sc["q_gt"]), float(np.linalg.norm(t0 - sc["t_gt"])) * 0.1
+    ang, dt = syn.rotation_geodesic(pb[:4], sc["q_gt"]), float(np.linalg.norm(pb[4:] - sc["t_gt"])) * 0.1
+    print(f"tier {deg} deg / {100 * frac:.0f} %: start {ang0:.4f} rad {dt0:.4f} m -> arg-min hypothesis {best} (x{lrm[best]:.2f}): {ang:.2e} rad {dt:.2e} m, "
+          f"loss {lg[0].sum(0)[best]:.4f} -> {lg[-1].sum(0)[best]:.4f}")
+    assert abs(ang0 - np.radians(deg)) < 1e-6
+    assert lg[-1].sum(0)[best] < lg[0].sum(0)[best]
+    if tol_rad is not None:
+        assert ang < tol_rad and dt < 1e-3, (ang, dt)
+    else:
+        assert np.all(np.isfinite(pb)) and ang < 1.2 * ang0

@@ -71,6 +71,33 @@ def test_xfm_backward_dispatch_matches_use_python(dd):
             torch.testing.assert_close(m.grad, m2.grad, rtol=1e-4, atol=2e-3)
 
 
+def test_xfm_backward_deterministic_mode(dd, monkeypatch):
+    """DDX_DETERMINISTIC=1 / torch.use_deterministic_algorithms(True): d_matrix from one workgroup per hypothesis in a fixed order
+    (no cross-workgroup atomicAdd) -- repeated runs are bit-identical at the hot path's size (N = 640*480), and equal to the
+    default (atomic) kernels to rounding."""
+    torch.manual_seed(2)
+    p = torch.randn(3, 640 * 480, 3, device="cuda")
+    m = torch.randn(3, 4, 4, device="cuda", requires_grad=True)
+    g = torch.randn(3, 640 * 480, 4, device="cuda")
+
+    def grad_m():
+        m.grad = None
+        dd.xfm_points(p, m).backward(g)
+        return m.grad.clone()
+
+    base = grad_m()
+    monkeypatch.setenv("DDX_DETERMINISTIC", "1")
+    runs = [grad_m() for _ in range(4)]
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    torch.testing.assert_close(runs[0], base, rtol=1e-4, atol=1e-2)
+    monkeypatch.delenv("DDX_DETERMINISTIC")
+    torch.use_deterministic_algorithms(True)
+    try:
+        assert torch.equal(grad_m(), runs[0])
+    finally:
+        torch.use_deterministic_algorithms(False)
+
+
 def test_xfm_large_n_linearity_property(dd):
     # size-independent property at the hot path's full size (N = 640*480): linearity in the matrix
     torch.manual_seed(1)
