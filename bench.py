@@ -50,15 +50,15 @@ def compulsory_bytes(V, T, HW, B, active_tiles, covered_px, textured, n_roles, s
                 atomics 8 B x 2 fragments per covered pixel (front + back faces) as 64-B sectors of the 4x4-pixel blocks
                 => active_tiles x 256 x 8 B read-modify-write
       shade   : zbuf 8 B x 256 per active tile (read once; both roles hit the same lines), triangle records 64 B x T
-                (static table, shared), observed rgb + seg 24 B/px of the tiles one hypothesis touches (shared), texels: a
-                2x2 bilinear footprint = 2 texture rows x 24 B, 1.375 sectors of 64 B per row on average => 176 B per
-                covered pixel (no reuse across hypotheses: 3 500 samples spread over a 50 MB texture), partial rows written
+                (static table, shared), observed rgb + seg 24 B/px of the tiles one hypothesis touches (shared), texels: ONE
+                64-byte record per covered pixel (the engine's texq layout: the whole 2x2 bilinear footprint in one sector;
+                no reuse across hypotheses: 3 500 samples spread over a 268 MB table), partial rows written
       update  : partial rows read, spos 12 B x V read once per hypothesis, clip 16 B + snap 8 B per vertex written, zbuf
                 re-arm 8 B x 256 per active tile written
     """
     tiles_one = active_tiles / max(B, 1)
     part = B * shade_slices * 4 * n_roles * 96.0
-    tex = 176.0 * covered_px if (textured and (uses["rgb"] or uses["edge"])) else 0.0
+    tex = 64.0 * covered_px if (textured and (uses["rgb"] or uses["edge"])) else 0.0
     gt = tiles_one * 256 * (12.0 + (12.0 if uses["rgb"] else 0.0) + (4.0 if uses["depth"] else 0.0))
     out = {
         "scatter_kernel": (8.0 + 16.0) * V * B + 16.0 * T + 2 * active_tiles * 256 * 8.0,

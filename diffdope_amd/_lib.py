@@ -45,6 +45,8 @@ _SIGNATURES = {
     "ddx_xfm_bwd_points": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_xfm_bwd_mtx": (_I, [_P, _LL, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_xfm_bwd_full": (_I, [_P, _LL, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "ddx_pose_matrix_fwd": (_I, [_P, _P, _I, _P, _P]),
+    "ddx_pose_matrix_bwd": (_I, [_P, _P, _I, _P, _P, _P]),
     "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "ddx_rasterize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
     "ddx_rasterize_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -55,6 +57,8 @@ _SIGNATURES = {
     "ddx_topology_build": (_I, [_P, _I, _P]),
     "ddx_antialias_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ddx_antialias_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ddx_gbuffer_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ddx_gbuffer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "ddx_masked_l1_fwd": (_I, [_P, _P, _P, _I, _I, _LL, _P, _P, _P]),
     "ddx_masked_l1_bwd": (_I, [_P, _P, _P, _I, _P, _I, _LL, _P, _P]),
     "ddx_engine_scratch_bytes": (_SZ, [ctypes.POINTER(EngineDesc)]),

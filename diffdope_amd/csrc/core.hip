@@ -54,3 +54,51 @@ extern "C" int ddx_topology_build(const int32_t* tri, int T, int32_t* opp)
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// matrix_batch_44_from_position_quat (diffdope/diffdope.py:46-89) as one kernel each way: the reference builds the matrix
+// from ~30 framework ops (and autograd adds ~60 for the backward).  q is used as given (the caller normalises it,
+// diffdope.py:1091), same row formulas as :57-80.
+__global__ void pose_matrix_fwd_kernel(const float* __restrict__ q, const float* __restrict__ p, int B, float* __restrict__ M)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float x = q[b * 4 + 0], y = q[b * 4 + 1], z = q[b * 4 + 2], w = q[b * 4 + 3];
+    float* m = M + (size_t)b * 16;
+    m[0] = 1.f - 2.f * y * y - 2.f * z * z; m[1] = 2.f * x * y - 2.f * z * w; m[2] = 2.f * x * z + 2.f * y * w; m[3] = p[b * 3 + 0];
+    m[4] = 2.f * x * y + 2.f * z * w; m[5] = 1.f - 2.f * x * x - 2.f * z * z; m[6] = 2.f * y * z - 2.f * x * w; m[7] = p[b * 3 + 1];
+    m[8] = 2.f * x * z - 2.f * y * w; m[9] = 2.f * y * z + 2.f * x * w; m[10] = 1.f - 2.f * x * x - 2.f * y * y; m[11] = p[b * 3 + 2];
+    m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
+}
+
+__global__ void pose_matrix_bwd_kernel(const float* __restrict__ q, const float* __restrict__ dM, int B, float* __restrict__ dq,
+                                       float* __restrict__ dp)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float x = q[b * 4 + 0], y = q[b * 4 + 1], z = q[b * 4 + 2], w = q[b * 4 + 3];
+    const float* G = dM + (size_t)b * 16;
+    dq[b * 4 + 0] = G[1] * 2 * y + G[2] * 2 * z + G[4] * 2 * y + G[5] * (-4 * x) + G[6] * (-2 * w) + G[8] * 2 * z + G[9] * 2 * w + G[10] * (-4 * x);
+    dq[b * 4 + 1] = G[0] * (-4 * y) + G[1] * 2 * x + G[2] * 2 * w + G[4] * 2 * x + G[6] * 2 * z + G[8] * (-2 * w) + G[9] * 2 * z + G[10] * (-4 * y);
+    dq[b * 4 + 2] = G[0] * (-4 * z) + G[1] * (-2 * w) + G[2] * 2 * x + G[4] * 2 * w + G[5] * (-4 * z) + G[6] * 2 * y + G[8] * 2 * x + G[9] * 2 * y;
+    dq[b * 4 + 3] = G[1] * (-2 * z) + G[2] * 2 * y + G[4] * 2 * z + G[6] * (-2 * x) + G[8] * (-2 * y) + G[9] * 2 * x;
+    dp[b * 3 + 0] = G[3]; dp[b * 3 + 1] = G[7]; dp[b * 3 + 2] = G[11];
+}
+
+extern "C" int ddx_pose_matrix_fwd(const float* q, const float* p, int B, float* mtx, void* stream)
+{
+    DDX_REQUIRE(q && p && mtx, DDX_E_NULL, "pose_matrix_fwd: NULL pointer");
+    DDX_REQUIRE(B >= 1, DDX_E_SHAPE, "pose_matrix_fwd: B=%d", B);
+    pose_matrix_fwd_kernel<<<ddx_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(q, p, B, mtx);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_pose_matrix_bwd(const float* q, const float* dmtx, int B, float* dq, float* dp, void* stream)
+{
+    DDX_REQUIRE(q && dmtx && dq && dp, DDX_E_NULL, "pose_matrix_bwd: NULL pointer");
+    DDX_REQUIRE(B >= 1, DDX_E_SHAPE, "pose_matrix_bwd: B=%d", B);
+    pose_matrix_bwd_kernel<<<ddx_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(q, dmtx, B, dq, dp);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}

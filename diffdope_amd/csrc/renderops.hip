@@ -369,3 +369,225 @@ extern "C" int ddx_masked_l1_bwd(const float* x, const float* y, const float* m,
     DDX_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// gbuffer: the per-pixel middle of render_texture_batch (diffdope/diffdope.py:203-231) as ONE forward and ONE backward pass
+// over the frame -- interpolate(pos) -> pose transform -> depth; interpolate(uv) -> texture(linear) (or interpolate(vertex
+// colour)) -> * clamp(id, 0, 1) -> rgb; interpolate(ones) -> coverage (the input of antialias) -- instead of three
+// interpolate, one texture, two xfm launches and ~15 framework elementwise kernels each way, every one a pass over 80-300 MB.
+// Same arithmetic, in the same order, as the individual ops above (the tests hold both against the oracle).  The backward
+// turns d rgb / d depth straight into d clip (x, y, w of the pixel's triangle: what rasterize_bwd would produce from the
+// (u, v) gradients the individual ops hand it; a clamped barycentric passes none) and d mtx (row 2: depth reads the pose).
+// Gradients with respect to the mesh attributes or the texture are not produced: callers that need them take the op-by-op ops.
+template <bool TEXTURED>
+__global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restrict__ rast, const float* __restrict__ mtx,
+                                                          const float* __restrict__ pos, const int* __restrict__ tri,
+                                                          const float* __restrict__ uv, const float* __restrict__ tex, int Th, int Tw,
+                                                          const float* __restrict__ vcol, int V, int T, long long HW, long long n,
+                                                          float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ cover)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float4 r = ld4(rast + i * 4);
+        const int t = (int)r.w - 1;
+        const int b = (int)(i / HW);
+        const float* M = mtx + (size_t)b * 16;
+        float col[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f}, cv = 0.f;
+        int i0 = 0, i1 = 0, i2 = 0;
+        bool in = t >= 0 && t < T;
+        if (in) {
+            i0 = tri[t * 3 + 0]; i1 = tri[t * 3 + 1]; i2 = tri[t * 3 + 2];
+            in = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
+        }
+        if (in) {
+            const float u = r.x, v = r.y, w2 = (1.0f - u) - v;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gb[c] = __fmaf_rn(w2, pos[(size_t)i2 * 3 + c], __fmaf_rn(v, pos[(size_t)i1 * 3 + c], u * pos[(size_t)i0 * 3 + c]));
+            cv = __fmaf_rn(w2, 1.0f, __fmaf_rn(v, 1.0f, u * 1.0f));  // interpolate of a tensor of ones (diffdope.py:212)
+            if (TEXTURED) {
+                const float tu = __fmaf_rn(w2, uv[(size_t)i2 * 2], __fmaf_rn(v, uv[(size_t)i1 * 2], u * uv[(size_t)i0 * 2]));
+                const float tv = __fmaf_rn(w2, uv[(size_t)i2 * 2 + 1], __fmaf_rn(v, uv[(size_t)i1 * 2 + 1], u * uv[(size_t)i0 * 2 + 1]));
+                TexelSetup s;
+                tex_setup(tu, tv, Th, Tw, s);
+                const float *t00 = tex + ((size_t)s.y0 * Tw + s.x0) * 3, *t10 = tex + ((size_t)s.y0 * Tw + s.x1) * 3,
+                            *t01 = tex + ((size_t)s.y1 * Tw + s.x0) * 3, *t11 = tex + ((size_t)s.y1 * Tw + s.x1) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float a = __fmaf_rn(s.fx, t10[c] - t00[c], t00[c]);
+                    const float bq = __fmaf_rn(s.fx, t11[c] - t01[c], t01[c]);
+                    col[c] = __fmaf_rn(s.fy, bq - a, a);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    col[c] = __fmaf_rn(w2, vcol[(size_t)i2 * 3 + c], __fmaf_rn(v, vcol[(size_t)i1 * 3 + c], u * vcol[(size_t)i0 * 3 + c]));
+            }
+        }
+        // depth = -(mtx . [gb; 1])_z, the k-ordered fma chain of xfm_points (a background pixel interpolates to the origin: -mtx[2][3])
+        float zc = __fmaf_rn(M[8], gb[0], 0.f);
+        zc = __fmaf_rn(M[9], gb[1], zc);
+        zc = __fmaf_rn(M[10], gb[2], zc);
+        zc = __fmaf_rn(M[11], 1.0f, zc);
+        depth[i] = -zc;
+        const float k = r.w < 0.f ? 0.f : (r.w > 1.f ? 1.f : r.w);  // clamp(rast[..., -1:], 0, 1) (diffdope.py:228,231)
+        rgb[i * 3 + 0] = col[0] * k; rgb[i * 3 + 1] = col[1] * k; rgb[i * 3 + 2] = col[2] * k;
+        cover[i * 3 + 0] = cv; cover[i * 3 + 1] = cv; cover[i * 3 + 2] = cv;
+    }
+}
+
+template <bool TEXTURED>
+__global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restrict__ rast, const float* __restrict__ clip,
+                                                          const float* __restrict__ mtx, const float* __restrict__ pos,
+                                                          const int* __restrict__ tri, const float* __restrict__ uv,
+                                                          const float* __restrict__ tex, int Th, int Tw, const float* __restrict__ vcol,
+                                                          int V, int T, int H, int W, long long n, const float* __restrict__ drgb,
+                                                          const float* __restrict__ ddepth, float* __restrict__ dclip,
+                                                          float* __restrict__ dmtx)
+{
+    const long long HW = (long long)H * W;
+    __shared__ float s_dm[4][4];
+    // this workgroup's pixels of ONE hypothesis contribute to d mtx[b][2][:]; a grid-stride step may cross into the next
+    // hypothesis, so the four sums are flushed whenever b changes (and at the end)
+    float dm[4] = {0.f, 0.f, 0.f, 0.f};
+    int b_cur = -1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto flush = [&](int b) {  // all 256 threads
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float sum = wave_sum(dm[c]);
+            if (lane == 0) s_dm[wave][c] = sum;
+            dm[c] = 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4 && b >= 0) {
+            const float tot = (s_dm[0][threadIdx.x] + s_dm[1][threadIdx.x]) + (s_dm[2][threadIdx.x] + s_dm[3][threadIdx.x]);
+            if (tot != 0.f) atomicAdd(dmtx + (size_t)b * 16 + 8 + threadIdx.x, tot);
+        }
+        __syncthreads();
+    };
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long base = (long long)blockIdx.x * 256; base < n; base += stride) {  // (workgroup-uniform trip count)
+        const int b_blk = (int)(base / HW), b_end = (int)(min(base + 255, n - 1) / HW);
+        if (b_cur >= 0 && b_blk != b_cur) flush(b_cur);
+        b_cur = b_blk;
+        for (int bb = b_blk; bb <= b_end; ++bb) {  // (a 256-pixel block straddles at most two hypotheses)
+            const long long i = base + threadIdx.x;
+            const bool mine = i < n && (int)(i / HW) == bb;
+            if (mine) {
+                const float4 r = ld4(rast + i * 4);
+                const int t = (int)r.w - 1;
+                const float gd = ddepth ? ddepth[i] : 0.f;
+                const float* M = mtx + (size_t)bb * 16;
+                int i0 = 0, i1 = 0, i2 = 0;
+                bool in = t >= 0 && t < T;
+                if (in) {
+                    i0 = tri[t * 3 + 0]; i1 = tri[t * 3 + 1]; i2 = tri[t * 3 + 2];
+                    in = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
+                }
+                if (!in) {
+                    dm[3] += -gd;  // depth of a background pixel = -mtx[2][3]
+                } else {
+                    const float u = r.x, v = r.y, w2 = (1.0f - u) - v;
+                    float p0[3], p1[3], p2[3], gb[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        p0[c] = pos[(size_t)i0 * 3 + c]; p1[c] = pos[(size_t)i1 * 3 + c]; p2[c] = pos[(size_t)i2 * 3 + c];
+                        gb[c] = __fmaf_rn(w2, p2[c], __fmaf_rn(v, p1[c], u * p0[c]));
+                    }
+                    float gu = 0.f, gv = 0.f;
+                    // depth = -(M2 . [gb;1]):  d/d M2 = -g [gb;1],  d/d gb = -g M2[0..2]
+                    dm[0] += -gd * gb[0]; dm[1] += -gd * gb[1]; dm[2] += -gd * gb[2]; dm[3] += -gd;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float ggb = -gd * M[8 + c];
+                        gu = __fmaf_rn(ggb, p0[c] - p2[c], gu);
+                        gv = __fmaf_rn(ggb, p1[c] - p2[c], gv);
+                    }
+                    if (drgb) {
+                        const float k = r.w < 0.f ? 0.f : (r.w > 1.f ? 1.f : r.w);
+                        const float g[3] = {drgb[i * 3 + 0] * k, drgb[i * 3 + 1] * k, drgb[i * 3 + 2] * k};
+                        if (TEXTURED) {
+                            const float a0x = uv[(size_t)i0 * 2], a0y = uv[(size_t)i0 * 2 + 1], a1x = uv[(size_t)i1 * 2], a1y = uv[(size_t)i1 * 2 + 1],
+                                        a2x = uv[(size_t)i2 * 2], a2y = uv[(size_t)i2 * 2 + 1];
+                            const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x)), tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
+                            TexelSetup s;
+                            tex_setup(tu, tv, Th, Tw, s);
+                            const float *t00 = tex + ((size_t)s.y0 * Tw + s.x0) * 3, *t10 = tex + ((size_t)s.y0 * Tw + s.x1) * 3,
+                                        *t01 = tex + ((size_t)s.y1 * Tw + s.x0) * 3, *t11 = tex + ((size_t)s.y1 * Tw + s.x1) * 3;
+                            float gtu = 0.f, gtv = 0.f;  // d loss / d (tu, tv), as texture_bwd_kernel
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
+                                gtu = __fmaf_rn(g[c], __fmaf_rn(s.fy, (c11 - c01) - (c10 - c00), c10 - c00), gtu);
+                                gtv = __fmaf_rn(g[c], __fmaf_rn(s.fx, (c11 - c10) - (c01 - c00), c01 - c00), gtv);
+                            }
+                            gtu *= (float)Tw; gtv *= (float)Th;
+                            gu = __fmaf_rn(gtu, a0x - a2x, gu); gu = __fmaf_rn(gtv, a0y - a2y, gu);
+                            gv = __fmaf_rn(gtu, a1x - a2x, gv); gv = __fmaf_rn(gtv, a1y - a2y, gv);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float c0 = vcol[(size_t)i0 * 3 + c], c1 = vcol[(size_t)i1 * 3 + c], c2 = vcol[(size_t)i2 * 3 + c];
+                                gu = __fmaf_rn(g[c], c0 - c2, gu);
+                                gv = __fmaf_rn(g[c], c1 - c2, gv);
+                            }
+                        }
+                    }
+                    if (gu != 0.f || gv != 0.f) {
+                        const int px = (int)(i % W), py = (int)((i / W) % H);
+                        const float* P = clip + (size_t)bb * V * 4;
+                        const float4 c0 = ld4(P + (size_t)i0 * 4), c1 = ld4(P + (size_t)i1 * 4), c2 = ld4(P + (size_t)i2 * 4);
+                        Bary bc;
+                        if (pixel_bary(c0, c1, c2, px, py, H, W, bc)) {
+                            float gx[3], gy[3], gw[3];
+                            bary_backward(bc, gu, gv, gx, gy, gw);
+                            float* D = dclip + (size_t)bb * V * 4;
+                            const int vi[3] = {i0, i1, i2};
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) {
+                                atomicAdd(D + (size_t)vi[q] * 4 + 0, gx[q]);
+                                atomicAdd(D + (size_t)vi[q] * 4 + 1, gy[q]);
+                                atomicAdd(D + (size_t)vi[q] * 4 + 3, gw[q]);
+                            }
+                        }
+                    }
+                }
+            }
+            if (bb < b_end) { flush(bb); b_cur = bb + 1; }
+        }
+    }
+    if (b_cur >= 0) flush(b_cur);
+}
+
+extern "C" int ddx_gbuffer_fwd(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv,
+                               const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, float* rgb,
+                               float* depth, float* cover, void* stream)
+{
+    DDX_REQUIRE(rast && mtx && pos && tri && rgb && depth && cover, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
+    DDX_REQUIRE((uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_fwd: needs (uv, tex) or vtx_color");
+    DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "gbuffer_fwd: bad shape");
+    DDX_REQUIRE(((uintptr_t)rast & 15) == 0, DDX_E_ALIGN, "gbuffer_fwd: rast must be 16-byte aligned");
+    const long long n = (long long)B * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    if (uv && tex) gbuffer_fwd_kernel<true><<<PIX_GRID(n), 256, 0, s>>>(rast, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, (long long)H * W, n, rgb, depth, cover);
+    else gbuffer_fwd_kernel<false><<<PIX_GRID(n), 256, 0, s>>>(rast, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, (long long)H * W, n, rgb, depth, cover);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_gbuffer_bwd(const float* rast, const float* clip, const float* mtx, const float* pos, const int32_t* tri,
+                               const float* uv, const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
+                               const float* drgb, const float* ddepth, float* dclip, float* dmtx, void* stream)
+{
+    DDX_REQUIRE(rast && clip && mtx && pos && tri && dclip && dmtx, DDX_E_NULL, "gbuffer_bwd: NULL pointer");
+    DDX_REQUIRE((uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_bwd: needs (uv, tex) or vtx_color");
+    DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "gbuffer_bwd: bad shape");
+    DDX_REQUIRE(((uintptr_t)rast & 15) == 0 && ((uintptr_t)clip & 15) == 0, DDX_E_ALIGN, "gbuffer_bwd: rast / clip must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    DDX_HIP(hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s));
+    DDX_HIP(hipMemsetAsync(dmtx, 0, (size_t)B * 16 * sizeof(float), s));
+    const long long n = (long long)B * H * W;
+    if (uv && tex) gbuffer_bwd_kernel<true><<<PIX_GRID(n), 256, 0, s>>>(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H, W, n, drgb, ddepth, dclip, dmtx);
+    else gbuffer_bwd_kernel<false><<<PIX_GRID(n), 256, 0, s>>>(rast, clip, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H, W, n, drgb, ddepth, dclip, dmtx);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}

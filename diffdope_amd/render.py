@@ -247,27 +247,22 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="aut
 _topology_cache = {}
 
 
-def _tri_fingerprint(tri):
-    """Two independent 64-bit position-weighted sums of the index buffer, computed on its device (one small
-    reduction + one host read): what a cache hit is validated with."""
-    t = tri.reshape(-1).to(torch.int64)
-    i = torch.arange(t.numel(), device=t.device, dtype=torch.int64)
-    a = (t * (i * 2654435761 % 4294967291 + 1)).sum()
-    b = ((t + 40503) * ((i ^ (i >> 5)) * 2246822519 % 4294967279 + 7)).sum()
-    return tuple(torch.stack([a, b]).tolist())
+def _buffer_key(t):
+    """Identity of an index buffer for the caches below: address, layout and the autograd version counter (bumped by every
+    in-place write, shared by views).  The cache entries keep the buffer's storage alive, so the caching allocator cannot hand
+    its block to a different mesh of the same size while an entry exists -- no device-side fingerprint (and no host
+    synchronisation) is needed to trust the address."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device), t._version)
 
 
 def build_topology(tri, cached=True):
-    """opp [T,3] int32 on tri's device (ddx_topology_build on the host).  cached=True keeps the result per index
-    buffer; a hit is validated against a fingerprint of the CONTENTS, because the address alone says nothing: the
-    caching allocator hands the block of a freed index buffer to the next one of the same size (a different mesh
-    with the same triangle count would silently get the old mesh's edges)."""
-    fp = key = None
+    """opp [T,3] int32 on tri's device (ddx_topology_build on the host).  cached=True keeps the result per index buffer (see
+    _buffer_key); the first call for a buffer copies it to the host, later calls cost a dictionary lookup."""
+    key = None
     if cached:
-        key = (tri.data_ptr(), tuple(tri.shape), str(tri.device))
-        fp = _tri_fingerprint(tri)
+        key = _buffer_key(tri)
         hit = _topology_cache.get(key)
-        if hit is not None and hit[0] == fp:
+        if hit is not None:
             return hit[1]
     tri_h = np.ascontiguousarray(tri.detach().cpu().numpy().astype(np.int32))
     opp_h = np.empty_like(tri_h)
@@ -276,7 +271,7 @@ def build_topology(tri, cached=True):
     if cached:
         if len(_topology_cache) > 16:
             _topology_cache.clear()
-        _topology_cache[key] = (fp, opp)
+        _topology_cache[key] = (tri.untyped_storage(), opp)  # (the storage reference pins the address)
     return opp
 
 
@@ -365,20 +360,113 @@ def masked_l1_mean(x, y, mask=None, mask_channel0=False):
     return _masked_l1_func.apply(x.contiguous(), y1.contiguous(), None if m1 is None else m1.contiguous(), 3 if mask_channel0 else 1)
 
 
+class _gbuffer_func(torch.autograd.Function):
+    """rgb, depth, cover from (clip, mtx) and a finished rasterisation: ddx_gbuffer_fwd / ddx_gbuffer_bwd (one pass over the
+    frame each way).  pos / uv / tex / vtx_color are ONE copy each ([V,3], [V,2], [Th,Tw,3], [V,3]); they get no gradient."""
+
+    @staticmethod
+    def forward(ctx, clip, mtx, rast, pos, tri, uv, tex, vtx_color):
+        lib = _lib.load()
+        clip, mtx, rast = _f32c(clip, "clip"), _f32c(mtx, "mtx"), _f32c(rast, "rast")
+        B, H, W = rast.shape[:3]
+        V, T = pos.shape[0], tri.shape[0]
+        Th, Tw = (tex.shape[0], tex.shape[1]) if tex is not None else (0, 0)
+        dev = rast.device
+        rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        cover = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        _lib.check(lib.ddx_gbuffer_fwd(_lib.ptr(rast), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv), _lib.ptr(tex), Th, Tw,
+                                       _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(cover), _lib.stream_ptr()),
+                   "ddx_gbuffer_fwd")
+        ctx.save_for_backward(clip, mtx, rast, pos, tri, uv, tex, vtx_color)
+        ctx.set_materialize_grads(False)  # (an unused output arrives as None instead of a zero-filled 80-240 MB tensor)
+        ctx.mark_non_differentiable(cover)  # (the interpolation of a tensor of ones does not depend on the barycentrics)
+        return rgb, depth, cover
+
+    @staticmethod
+    def backward(ctx, drgb, ddepth, _dcover):
+        clip, mtx, rast, pos, tri, uv, tex, vtx_color = ctx.saved_tensors
+        if drgb is None and ddepth is None:
+            return (None,) * 8
+        B, H, W = rast.shape[:3]
+        V, T = pos.shape[0], tri.shape[0]
+        Th, Tw = (tex.shape[0], tex.shape[1]) if tex is not None else (0, 0)
+        drgb = None if drgb is None else _f32c(drgb, "drgb")
+        ddepth = None if ddepth is None else _f32c(ddepth, "ddepth")
+        dclip = torch.empty_like(clip)
+        dmtx = torch.empty_like(mtx)
+        _lib.check(_lib.load().ddx_gbuffer_bwd(_lib.ptr(rast), _lib.ptr(clip), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv),
+                                               _lib.ptr(tex), Th, Tw, _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(drgb), _lib.ptr(ddepth),
+                                               _lib.ptr(dclip), _lib.ptr(dmtx), _lib.stream_ptr()), "ddx_gbuffer_bwd")
+        return dclip, dmtx, None, None, None, None, None, None
+
+
+_same_index_cache = {}
+
+
+def _same_indices(a, b):
+    """uv_idx is pos_idx: the same buffer, or equal contents -- compared once per pair of buffers (the comparison synchronises;
+    the entry pins both storages, see _buffer_key)."""
+    if a.shape != b.shape:
+        return False
+    if a.data_ptr() == b.data_ptr():
+        return True
+    key = (_buffer_key(a), _buffer_key(b))
+    hit = _same_index_cache.get(key)
+    if hit is None:
+        if len(_same_index_cache) > 64:
+            _same_index_cache.clear()
+        hit = (a.untyped_storage(), b.untyped_storage(), bool(torch.equal(a, b)))
+        _same_index_cache[key] = hit
+    return hit[2]
+
+
+def _one_copy(t):
+    """The single copy behind a batch of identical rows ([B,...] with batch stride 0, or a batch of one), else None."""
+    if t is None:
+        return None
+    if t.shape[0] == 1 or t.stride(0) == 0:
+        return t[0]
+    return None
+
+
 def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None, uv_idx=None, tex=None, vtx_color=None,
-                         return_rast_out=False):
+                         return_rast_out=False, fused=None):
     """The materialising render of diffdope.py:156-234 (same signature and outputs), for user loss functions that read
     ddope.renders; the built-in losses take the fused engine (diffdope_amd.engine) instead.
 
     Args as the reference: proj_cam [B,4,4], mtx [B,4,4], pos [B,V,3], pos_idx [B,T,3] or [T,3] int32, resolution int or
     [H,W], and either (uv [B,V,2], uv_idx, tex [B,Th,Tw,3]) or vtx_color [B,V,3].
     Returns dict(rgb [B,H,W,3], depth [B,H,W], rast_out [B,H,W,4] or None, mask [B,H,W,3]).
+
+    fused=None (default): when the mesh attributes and the texture are one copy shared by the batch (what Mesh.set_batchsize
+    makes) and none of them needs a gradient, everything between rasterize and antialias runs as ONE kernel each way
+    (ddx_gbuffer_fwd / _bwd); otherwise -- or with fused=False -- op by op through interpolate / texture / xfm_points, like the
+    reference.  Both are held to the same oracle.
     """
     H, W = (resolution if isinstance(resolution, (list, tuple)) else (resolution, resolution))
     faces = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
     # clip-space vertices and visibility (:195-200)
     clip = dd_ops.xfm_points(pos.contiguous(), torch.matmul(proj_cam, mtx))
     rast, _ = rasterize(glctx, clip, faces, resolution=[H, W])
+    textured = vtx_color is None
+    attrs = (pos, uv, tex) if textured else (pos, vtx_color)
+    uv_faces = None if not textured else (uv_idx[0] if uv_idx.dim() == 3 else uv_idx)
+    can_fuse = (all(_one_copy(a) is not None and not a.requires_grad for a in attrs) and clip.is_cuda
+                and (not textured or _same_indices(uv_faces, faces)))
+    if fused is None:
+        fused = can_fuse
+    elif fused and not can_fuse:
+        raise RuntimeError("render_texture_batch(fused=True) needs batch-shared (stride-0 or batch-1) pos / uv / tex / vtx_color without "
+                           "gradients and uv_idx == pos_idx")
+    if fused:
+        p1 = _f32c(_one_copy(pos), "pos")
+        kw = dict(uv=_f32c(_one_copy(uv), "uv"), tex=_f32c(_one_copy(tex), "tex"), vtx_color=None) if textured else \
+            dict(uv=None, tex=None, vtx_color=_f32c(_one_copy(vtx_color), "vtx_color"))
+        rgb, depth, cover = _gbuffer_func.apply(clip, mtx, rast.detach(), p1, _i32c(faces, "pos_idx"), kw["uv"], kw["tex"], kw["vtx_color"])
+        mask = antialias(cover, rast.detach(), clip, faces)  # (detached: antialias has no gradient for rast, and an attached one
+        #                                                      would still make autograd run rasterize's backward on zeros)
+        return {"rgb": rgb, "depth": depth, "rast_out": rast if return_rast_out else None, "mask": mask}
     covered = rast[..., 3:].clamp(0, 1)
     # depth: object-space position under each pixel, through the pose, camera z negated (:203-209); a background pixel
     # interpolates to the origin, so its depth is -mtx[2,3], as in the reference
@@ -391,8 +479,7 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
     cover, _ = interpolate(torch.ones((1, faces.shape[0], 3), device=pos.device), rast, faces)
     mask = antialias(cover, rast, clip, faces)
     # colour: bilinear texture lookup at the interpolated uv, or interpolated vertex colours; background zeroed (:216-231)
-    if vtx_color is None:
-        uv_faces = uv_idx[0] if uv_idx.dim() == 3 else uv_idx
+    if textured:
         tc, _ = interpolate(uv, rast, uv_faces)
         rgb = texture(tex, tc, filter_mode="linear") * covered
     else:

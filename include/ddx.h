@@ -64,6 +64,11 @@ int ddx_xfm_bwd_full(const float* points, long long points_bstride, const float*
                      int is_points, const float* dout, float* dpoints, float* dmatrix, int variant,
                      void* stream);
 
+/* matrix_batch_44_from_position_quat (diffdope.py:46-89) and its backward as one kernel each: q [B,4] xyzw (used as given: the
+ * caller normalises, diffdope.py:1091), p [B,3] -> mtx [B,4,4] row-major; dmtx [B,4,4] -> dq [B,4], dp [B,3], fully written. */
+int ddx_pose_matrix_fwd(const float* q, const float* p, int B, float* mtx, void* stream);
+int ddx_pose_matrix_bwd(const float* q, const float* dmtx, int B, float* dq, float* dp, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * rasterize: replaces dr.rasterize(glctx, pos, tri, resolution) at diffdope.py:198-200 and its
  * backward.  Software rasteriser: per-vertex 1/256-pixel snap, per-triangle scatter with a 64-bit
@@ -117,6 +122,24 @@ int ddx_antialias_fwd(const float* color, int C, const float* rast, const float*
 int ddx_antialias_bwd(const float* color, int C, const float* rast, const float* pos, const int32_t* tri,
                       const int32_t* opp, int B, int V, int T, int H, int W, const float* dout,
                       float* dcolor, float* dpos, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * gbuffer: everything of render_texture_batch (diffdope.py:203-231) between dr.rasterize and dr.antialias in ONE pass each way:
+ * interpolate(pos) -> xfm_points(., mtx) -> depth (:203-209); interpolate(uv) -> texture linear (or interpolate(vtx_color)) ->
+ * * clamp(rast[..., 3], 0, 1) -> rgb (:218-231); interpolate(ones) -> cover, the input of antialias (:212).  One copy of the
+ * mesh attributes and of the texture serves every hypothesis.
+ *   rast [B,H,W,4] from ddx_rasterize_fwd; mtx [B,4,4]; pos [V,3]; tri [T,3]; uv [V,2] + tex [Th,Tw,3], or vtx_color [V,3]
+ *   rgb [B,H,W,3], depth [B,H,W] (background: -mtx[2][3]), cover [B,H,W,3]
+ * Backward: drgb / ddepth (either may be NULL) -> dclip [B,V,4] (x, y, w; what ddx_rasterize_bwd makes of the (u, v) gradients
+ * the separate ops would hand it) and dmtx [B,4,4] (row 2), both fully written; clip [B,V,4] = the positions rasterized.
+ * No gradient with respect to pos / uv / tex / vtx_color is produced (use the separate ops for that).
+ * ------------------------------------------------------------------------------------------- */
+int ddx_gbuffer_fwd(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv, const float* tex,
+                    int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, float* rgb, float* depth, float* cover,
+                    void* stream);
+int ddx_gbuffer_bwd(const float* rast, const float* clip, const float* mtx, const float* pos, const int32_t* tri, const float* uv,
+                    const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, const float* drgb,
+                    const float* ddepth, float* dclip, float* dmtx, void* stream);
 
 /* Image-space part of the built-in losses for the op-by-op path (diffdope.py:547-613: l1_rgb_with_mask :547-562,
  * l1_depth_with_mask :565-580, l1_mask :583-613): out[b] = mean_i |(x[b,i] - y[i]) * m[i * m_stride]|, with the observed image y [N]

@@ -119,11 +119,12 @@ def test_engine_recovers_known_pose():
 
 
 def test_render_texture_batch_autograd_matches_oracle():
-    """The drop-in op-by-op path (render_texture_batch + torch losses + autograd) against the oracle."""
+    """The materialising path (render_texture_batch + torch losses + autograd) against the oracle: fused (ddx_gbuffer_fwd / _bwd
+    between rasterize and antialias) and op by op (interpolate / texture / xfm_points like the reference)."""
     import diffdope_amd as dd
     from oracle import oracle as orc
 
-    for textured in (True, False):
+    for textured, fused in ((True, True), (False, True), (True, False), (False, False)):
         sc = make_scene(16, 20, 60, 80, B=2, dist=1.8, textured=textured)
         R = sc["oracle"]
         R.cull_backfaces = False  # the op-level ops draw both faces, like nvdiffrast
@@ -139,7 +140,7 @@ def test_render_texture_batch_autograd_matches_oracle():
         kw = dict(uv=ex(sc["uv"]), uv_idx=ex(sc["tri"]), tex=ex(sc["tex"])) if textured else dict(vtx_color=ex(sc["vtx_color"]))
         ctx = dd.RasterizeGLContext()
         out = dd.render_texture_batch(ctx, ex(sc["proj"]), mtx, ex(sc["pos"]), ex(sc["tri"]), [sc["H"], sc["W"]],
-                                      return_rast_out=True, **kw)
+                                      return_rast_out=True, fused=fused, **kw)  # fused: one gbuffer pass each way; else op by op
         assert np.array_equal(out["rast_out"][..., 3].detach().cpu().numpy(), r_ref["rast"][..., 3])
         for k in ("rgb", "depth", "mask"):
             np.testing.assert_allclose(out[k].detach().cpu().numpy(), r_ref[k], rtol=1e-4, atol=2e-5)

@@ -216,8 +216,10 @@ def test_topology_matches_oracle():
 
 def test_topology_cache_is_validated_by_content_not_by_address():
     """The op-level antialias keeps the edge topology per index buffer.  A freed index buffer's block is handed to the
-    next tensor of the same size by the caching allocator: a different mesh with the same triangle count at the same
-    address must not get the old mesh's edges (regression: the cache used to be keyed by address and shape only)."""
+    next tensor of the same size by the caching allocator: a different mesh with the same triangle count must not get the
+    old mesh's edges (regression: the cache used to be keyed by address and shape only).  The cache entry now pins the
+    buffer's storage (so its address cannot be reused while the entry lives) and records the tensor's version counter
+    (in-place edits invalidate it) -- no device-side fingerprint, no host synchronisation per call."""
     import gc
 
     from diffdope_amd.render import build_topology
