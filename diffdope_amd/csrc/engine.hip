@@ -60,7 +60,9 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int it;          // iteration index of the running iteration
     int n_seg;       // entries in the compact seg list
     int it_next;     // written by update_xfm_kernel (one lane), copied into `it` by the next shade_kernel (one lane)
-    int pad[2];
+    int outside;     // hypotheses of the last iteration with a vertex outside the view volume (w <= 0 or |z| > w): their triangles
+                     // at w <= 0 were dropped (deviation D1) and their back faces drawn (D5 off)
+    int pad[1];
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
     double c_edge;   // sum over the frame of |Gx| + |Gy| of the observed, masked image (edge extension)
@@ -1393,12 +1395,17 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
         if (writer && b == 0) {
             // iteration bookkeeping without atomics (kernel boundaries order these single-lane updates):
             // shade_kernel of the next iteration copies it_next into `it`, which this kernel reads.
-            int tot = 0;
-            for (int i = lane; i < B; i += 64) tot += E.L.b_count[i];
+            int tot = 0, out = 0;
+            for (int i = lane; i < B; i += 64) {
+                tot += E.L.b_count[i];
+                const int* ck = E.cull_ok + (size_t)i * 8;  // (the flags the transform of the previous iteration left for this one)
+                out += (ck[0] & ck[1] & ck[2] & ck[3] & ck[4] & ck[5] & ck[6] & ck[7]) == 0;
+            }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, 64); out += __shfl_xor(out, o, 64); }
             if (lane == 0) {
                 E.st->last_active = tot;
+                E.st->outside = out;
                 E.st->last_pairs = E.L.counters[3];
                 E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
                 E.st->it_next = E.eval_grad ? it : it + 1;

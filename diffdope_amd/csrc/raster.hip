@@ -172,12 +172,16 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                     // (v > 0 || (v == 0 && own)) is folded into the start value: v + own - 1 >= 0
                     const int b0 = e0.e00 + (int)e0.own - 1, b1 = e1.e00 + (int)e1.own - 1, b2 = e2.e00 + (int)e2.own - 1;
                     scatter_mask_t mask = 0;
-                    int idx = 0;
-                    int r0 = b0, r1 = b1, r2 = b2;
-                    for (int j = 0; j < nyp; ++j, r0 += e0.sy, r1 += e1.sy, r2 += e2.sy) {
-                        int v0 = r0, v1 = r1, v2 = r2;
-                        for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
-                            mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
+                    {
+                        // (a branch-free path for boxes of at most 2x2 centres -- nearly every triangle of the dense meshes -- that lets
+                        // whole waves skip this loop was measured: +-0.5 % on cfg2 / cfg3 / cfg50k64: the kernel waits on its memory levels)
+                        int idx = 0;
+                        int r0 = b0, r1 = b1, r2 = b2;
+                        for (int j = 0; j < nyp; ++j, r0 += e0.sy, r1 += e1.sy, r2 += e2.sy) {
+                            int v0 = r0, v1 = r1, v2 = r2;
+                            for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
+                                mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
+                        }
                     }
                     alive = mask != 0;  // a small triangle that covers no centre draws nothing: no tile to flag
                     bool walk = WALK == 1;
