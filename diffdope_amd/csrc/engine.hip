@@ -61,7 +61,7 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int n_seg;       // entries in the compact seg list
     int it_next;     // written by update_xfm_kernel (one lane), copied into `it` by the next shade_kernel (one lane)
     int outside;     // hypotheses of the last iteration with a vertex outside the view volume (w <= 0 or |z| > w): their triangles
-                     // at w <= 0 were dropped (deviation D1) and their back faces drawn (D5 off)
+                     // at w <= 0 were clipped at the near plane by the tile pass and their back faces drawn (D5 off)
     int pad[1];
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|

@@ -133,7 +133,7 @@ typedef unsigned scatter_mask_t;
 // Coverage of one triangle (integer only, no memory reads): flags its tiles; for a SMALL triangle the bit mask of the covered
 // pixel centres of its bbox (bit k = j * nxp + i  <=>  pixel (px0 + i, py0 + j)) goes to `cv`; returns the packed tile range
 // of a LARGE triangle (resolved later by the tile pass), ~0u otherwise.
-struct ScatterCov { scatter_mask_t mask; int px0, py0, nxp; };
+struct ScatterCov { scatter_mask_t mask; int px0, py0, nxp; int clipped; };  // clipped: a near-plane straddler, resolved by the tile pass
 
 // WALK: the lane resolves its covered centres itself, right here (the plain variant of the kernel; kept inside this function,
 // in the scope that computed the mask, because hoisting it out costs 2-3 % of the kernel in the compiler's schedule).
@@ -146,7 +146,7 @@ template <int WALK>
 __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int H, int W, const RasterScratch& L, int b, int t,
                                                 int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c, ScatterCov& cv, int cull)
 {
-    cv.mask = 0; cv.px0 = 0; cv.py0 = 0; cv.nxp = 1;
+    cv.mask = 0; cv.px0 = 0; cv.py0 = 0; cv.nxp = 1; cv.clipped = 0;
     unsigned range = ~0u;  // packed tile range of a LARGE triangle
     if (a.x != INT_MIN && bq.x != INT_MIN && c.x != INT_MIN) {
         const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
@@ -237,6 +237,23 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
                     L.counters[3] = 1;  // plain store: "the batch has a large triangle"
                 }
             }
+        }
+    } else {
+        // a vertex at w <= 0 (rare: a hypothesis that dives through the camera).  If any corner lies in front of the near plane the
+        // triangle is a straddler: the tile pass clips it (clip_near) and draws the visible part.  Where that part lands cannot
+        // be bounded from the snapped corners, so it is listed for the whole frame.  (Kept to a few instructions on purpose:
+        // with the clipping arithmetic inlined here the kernel's hot path lost 2x to instruction fetch, cfg2 12.5 -> 23-33 us.)
+        const float* P = pos + (size_t)b * V * 4;
+        const float2 zw0 = *reinterpret_cast<const float2*>(P + (size_t)i0 * 4 + 2), zw1 = *reinterpret_cast<const float2*>(P + (size_t)i1 * 4 + 2),
+                     zw2 = *reinterpret_cast<const float2*>(P + (size_t)i2 * 4 + 2);
+        if (zw0.x + zw0.y >= 0.f || zw1.x + zw1.y >= 0.f || zw2.x + zw2.y >= 0.f) {
+            int* flag = L.tile_flag + (size_t)b * L.NT;
+            int* big = L.tile_big + (size_t)b * L.NT;
+#pragma clang loop unroll(disable) vectorize(disable)
+            for (int i = 0; i < L.NT; ++i) { flag[i] = 1; big[i] = 1; }
+            range = ((unsigned)(L.ntx - 1) << 16) | ((unsigned)(L.nty - 1) << 24);
+            L.counters[3] = 1;
+            cv.clipped = 1;
         }
     }
     return range;
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < SCATTER_TPL; ++k) {
         range[k] = ~0u;
-        cv[k].mask = 0; cv[k].px0 = 0; cv[k].py0 = 0; cv[k].nxp = 1;
+        cv[k].mask = 0; cv[k].px0 = 0; cv[k].py0 = 0; cv[k].nxp = 1; cv[k].clipped = 0;
         if (t[k] >= T || !ok[k]) continue;
         // (plain variant: triangle by triangle -- coverage of both triangles first and all fragments afterwards measured
         // 2 us slower on cfg2: more atomics in flight at once make the atomicMin stream slower)
@@ -421,7 +438,8 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
         int base = 0;
         if (lane == __ffsll((long long)m) - 1) base = atomicAdd(L.bigcount + b, __popcll(m));
         base = __shfl(base, __ffsll((long long)m) - 1, 64);
-        if (range[k] != ~0u) L.biglist[(size_t)b * T + base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)t[k], range[k]);
+        if (range[k] != ~0u)  // (bit 31 of the id: a near-plane straddler, clipped again by the tile pass)
+            L.biglist[(size_t)b * T + base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)t[k] | (cv[k].clipped ? 0x80000000u : 0u), range[k]);
     }
 #if defined(DDX_TRACE) && defined(DDX_PHASES)
     if (threadIdx.x == 0 && L.trace) {
@@ -578,20 +596,38 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
             // clip-space vertices) is staged in LDS by the lane that found the hit -- parallel gathers instead of one
             // dependent gather chain per triangle and pixel loop step
             const int idx = r0 + lane;
-            bool hit = idx < ncand;
-            uint2 ent = make_uint2(hit ? (unsigned)s_cand[wave][idx] : 0u, 0u);
+            const bool cand = idx < ncand;
+            const unsigned ent_id = cand ? (unsigned)s_cand[wave][idx] : 0u;  // bit 31: a near-plane straddler (see scatter_one)
+            const int t_id = (int)(ent_id & 0x7fffffffu);
+            // the snapped triangle(s) of the candidate: its own three vertices, or -- for a triangle with a vertex at w <= 0 --
+            // the one or two triangles of its near-clipped polygon (clip_near; fragments still come from the original triangle)
+            int i0 = 0, i1 = 0, i2 = 0;
+            SnapTri stv[2];
+            stv[0].ok = false; stv[1].ok = false;
+            int nst = 0;
+            float4 cp0 = make_float4(0.f, 0.f, 0.f, 0.f), cp1 = cp0, cp2 = cp0;
+            if (cand) {
+                i0 = tri[t_id * 3 + 0]; i1 = tri[t_id * 3 + 1]; i2 = tri[t_id * 3 + 2];
+                if (ent_id >> 31) {
+                    cp0 = ld4(P + (size_t)i0 * 4); cp1 = ld4(P + (size_t)i1 * 4); cp2 = ld4(P + (size_t)i2 * 4);
+                    nst = clip_near(cp0, cp1, cp2, H, W, stv);
+                } else {
+                    const int2 sa = S[i0], sb = S[i1], sc = S[i2];
+                    snap_from_vertices(sa, sb, sc, stv[0]);
+                    nst = stv[0].ok ? 1 : 0;
+                }
+            }
+            const bool any_second = __ballot(nst > 1) != 0ull;
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+            if (sub == 1 && !any_second) break;  // (wave-uniform)
+            bool hit = cand && sub < nst;
+            const SnapTri& st = sub == 0 ? stv[0] : stv[1];
             // the packed range is the triangle's bbox in tiles: refine with the exact edge predicate at the four corner
             // pixel centres of the tile -- all four outside one edge => no centre of the tile can be covered
-            int i0 = 0, i1 = 0, i2 = 0;
             int4 es[3] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
             if (hit) {
-                const int t = (int)ent.x;
-                i0 = tri[t * 3 + 0]; i1 = tri[t * 3 + 1]; i2 = tri[t * 3 + 2];
-                const int2 sa = S[i0], sb = S[i1], sc = S[i2];
-                SnapTri st;
-                snap_from_vertices(sa, sb, sc, st);
-                hit = st.ok;
-                if (hit) {
+                {
                     const int cx0 = (tcx * DDX_TILE) * DDX_SUBPIX + DDX_SUBPIX / 2, cy0 = (tcy * DDX_TILE) * DDX_SUBPIX + DDX_SUBPIX / 2;
                     const int cx1 = (min(tcx * DDX_TILE + DDX_TILE, W) - 1) * DDX_SUBPIX + DDX_SUBPIX / 2;
                     const int cy1 = (min(tcy * DDX_TILE + DDX_TILE, H) - 1) * DDX_SUBPIX + DDX_SUBPIX / 2;
@@ -621,10 +657,11 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
             if (hit) {
                 const int slot = __popcll(m & ((1ull << lane) - 1ull));
                 s_e0[wave][slot] = es[0]; s_e1[wave][slot] = es[1]; s_e2[wave][slot] = es[2];
-                s_t[wave][slot] = (int)ent.x;
-                s_p0[wave][slot] = ld4(P + (size_t)i0 * 4);
-                s_p1[wave][slot] = ld4(P + (size_t)i1 * 4);
-                s_p2[wave][slot] = ld4(P + (size_t)i2 * 4);
+                s_t[wave][slot] = t_id;
+                const bool have = (ent_id >> 31) != 0u;  // (a straddler's clip-space vertices are already here)
+                s_p0[wave][slot] = have ? cp0 : ld4(P + (size_t)i0 * 4);
+                s_p1[wave][slot] = have ? cp1 : ld4(P + (size_t)i1 * 4);
+                s_p2[wave][slot] = have ? cp2 : ld4(P + (size_t)i2 * 4);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -647,6 +684,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // (the staging arrays are rewritten by the next round)
+          }
         }
         }
 #pragma unroll

@@ -63,6 +63,70 @@ __device__ __forceinline__ void snap_from_vertices(const int2& a, const int2& b,
     s.ok = s.area != 0;
 }
 
+// Near-plane clipping of a triangle with a vertex at w <= 0 (dr.rasterize clips against the view volume): the part with
+// z + w >= 0 is a polygon of 3 or 4 corners (Sutherland-Hodgman over the edges 0->1->2->0; an intersection is always
+// computed from the inside end of its edge towards the outside end, so two triangles sharing the edge get the same point),
+// snapped like vertices and cut into a fan of one or two triangles.  Fragments take barycentrics and depth from the
+// ORIGINAL triangle (the homogeneous form of pixel_bary holds for any w).  Same operations, in the same order, as the
+// oracle's clip_near.  Returns the number of triangles written to out[] (0: nothing in front of the near plane).
+__device__ __forceinline__ int clip_near(const float4& p0, const float4& p1, const float4& p2, int H, int W, SnapTri out[2])
+{
+    const float4 p[3] = {p0, p1, p2};
+    float d[3];
+    bool in[3];
+    int nin = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        d[i] = p[i].z + p[i].w;
+        in[i] = d[i] >= 0.f;
+        nin += in[i];
+    }
+    out[0].ok = false; out[1].ok = false;
+    if (nin == 0) return 0;
+    int QX[4] = {0, 0, 0, 0}, QY[4] = {0, 0, 0, 0};
+    int n = 0;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3;
+        if (in[i]) {
+            if (!(p[i].w > 0.f)) bad = true;
+            const float iw = __fdiv_rn(1.0f, p[i].w);
+            const int qx = snap_coord(p[i].x * iw, W), qy = snap_coord(p[i].y * iw, H);
+            if (n == 0) { QX[0] = qx; QY[0] = qy; } else if (n == 1) { QX[1] = qx; QY[1] = qy; } else if (n == 2) { QX[2] = qx; QY[2] = qy; } else { QX[3] = qx; QY[3] = qy; }
+            ++n;
+        }
+        if (in[i] != in[j]) {
+            const float4 a = in[i] ? p[i] : p[j], b = in[i] ? p[j] : p[i];  // a inside, b outside
+            const float da = in[i] ? d[i] : d[j], db = in[i] ? d[j] : d[i];
+            const float t = __fdiv_rn(da, da - db);
+            const float x = __fmaf_rn(t, b.x - a.x, a.x), y = __fmaf_rn(t, b.y - a.y, a.y), w = __fmaf_rn(t, b.w - a.w, a.w);
+            if (!(w > 0.f)) bad = true;
+            const float iw = __fdiv_rn(1.0f, w);
+            const int qx = snap_coord(x * iw, W), qy = snap_coord(y * iw, H);
+            if (n == 0) { QX[0] = qx; QY[0] = qy; } else if (n == 1) { QX[1] = qx; QY[1] = qy; } else if (n == 2) { QX[2] = qx; QY[2] = qy; } else { QX[3] = qx; QY[3] = qy; }
+            ++n;
+        }
+    }
+    if (bad) return 0;
+    int m = 0;
+#pragma unroll
+    for (int k = 1; k <= 2; ++k) {
+        if (k + 1 >= n) break;
+        SnapTri s;
+        s.X[0] = QX[0]; s.Y[0] = QY[0];
+        s.X[1] = k == 1 ? QX[1] : QX[2]; s.Y[1] = k == 1 ? QY[1] : QY[2];
+        s.X[2] = k == 1 ? QX[2] : QX[3]; s.Y[2] = k == 1 ? QY[2] : QY[3];
+        s.area = (long long)(s.X[1] - s.X[0]) * (long long)(s.Y[2] - s.Y[0]) - (long long)(s.X[2] - s.X[0]) * (long long)(s.Y[1] - s.Y[0]);
+        s.ok = s.area != 0;
+        if (s.ok) {
+            if (m == 0) out[0] = s; else out[1] = s;
+            ++m;
+        }
+    }
+    return m;
+}
+
 // pixel-centre range [px0,px1] x [py0,py1] whose centres can lie inside the snapped bbox (unclamped)
 __device__ __forceinline__ void snap_bbox(const SnapTri& s, int& px0, int& py0, int& px1, int& py1)
 {

@@ -155,7 +155,7 @@ class RefineEngine:
 
     def status(self):
         """dict(overflow (always 0), big_triangles (0/1: the tile pass ran), active_tiles, it, n_seg, outside_view_volume (hypotheses
-        of the last iteration with a vertex at w <= 0 or |z| > w: such triangles are dropped, not clipped)) -- synchronises."""
+        of the last iteration with a vertex at w <= 0 or |z| > w: near-plane clipping and two-sided drawing for those)) -- synchronises."""
         p = self.lib.ddx_engine_status_ptr(self.handle)
         off = p - self.scratch.data_ptr()
         st = self.scratch[off:off + 32].view(torch.int32).cpu().tolist()

@@ -541,3 +541,28 @@ def test_pose_recovery_on_the_perturbation_tiers_of_the_dataset(deg, frac, tol_r
         assert ang < tol_rad and dt < 1e-3, (ang, dt)
     else:
         assert np.all(np.isfinite(pb)) and ang < 1.2 * ang0
+
+
+def test_engine_hypothesis_cut_by_the_camera_plane_is_clipped_like_the_oracle():
+    """One hypothesis of the batch sits so close that the camera plane cuts the object (vertices at w <= 0): its straddling
+    triangles are clipped at the near plane (tile pass), its back faces are drawn (D5 off for it), the status reports it, and
+    losses and pose gradients of the whole batch match the oracle."""
+    sc = make_scene(6, 8, 96, 128, B=3, dist=1.6, tex_size=16)
+    near = sc["params"].copy()
+    near[4:, 1] = [0.05, -0.02, -0.35]
+    sc = dict(sc, params=near)
+    w = dict(rgb=0.7, depth=1.0, mask=1.0)
+    R = sc["oracle"]
+    R.weights = {k: w.get(k) for k in ("rgb", "depth", "mask", "edge")}
+    total, logs, g_ref, r_ref = R.loss_and_grad(near, sc["lr_mult"])
+    assert (r_ref["pos_clip"][1, :, 3] <= 0).any() and (r_ref["rast"][1, ..., 3] > 0).mean() > 0.3
+    eng, _ = _engine(sc, w, [0.1])
+    losses, grad = eng.loss_and_grad()
+    torch.cuda.synchronize()
+    st = eng.status()
+    assert st["outside_view_volume"] == 1 and st["big_triangles"] == 1
+    lg = losses.cpu().numpy()
+    for i, key in enumerate(KEYS):
+        if key in logs:
+            np.testing.assert_allclose(lg[i], logs[key], rtol=5e-5, atol=1e-7)
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())

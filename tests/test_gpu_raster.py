@@ -272,3 +272,33 @@ def test_reference_call_pattern_with_pixel_derivative_placeholders():
         rast_db[..., 0]
     with pytest.raises(RuntimeError, match="linear"):
         dr.texture(T(sc["tex"])[None], texc, texd, filter_mode="linear-mipmap-linear")
+
+
+def test_near_plane_clipping_matches_oracle():
+    """Triangles with a vertex behind the camera (w <= 0) are clipped at the near plane by the tile pass (round 1 dropped them):
+    the hand-built straddlers of tests/test_oracle_deviations.py and a low-poly mesh the camera plane cuts through, ids
+    bit-identical to the f32 oracle, u / v / z-w to 2e-6."""
+    import diffdope_amd as dd
+    from oracle import oracle as orc
+
+    H, W = 48, 64
+    proj = orc.projection_matrix(**syn.camera_intrinsics(W, H))
+    cam = np.array([[-0.6, -0.4, -1.0, 1.0], [-0.6, 0.4, -1.0, 1.0], [0.5, 0.0, 0.3, 1.0], [0.45, 0.9, 0.3, 1.0], [-0.2, -0.9, 0.1, 1.0]])
+    P = (proj @ cam.T).T.astype(np.float32)[None]
+    tri = np.array([[0, 1, 2], [1, 3, 2], [0, 2, 4], [2, 3, 4]], np.int32)
+    ref = orc.rasterize_fwd(P, tri, H, W)
+    assert (ref[..., 3] > 0).mean() > 0.3 and len(np.unique(ref[..., 3])) >= 2
+    rast, _ = dd.rasterize(dd.RasterizeGLContext(), T(P), T(tri), [H, W])
+    _check_rast(rast.cpu().numpy(), ref)
+    # a closed low-poly mesh with the camera inside its bounding sphere: many straddlers, large on screen
+    pos, tri2, _ = syn.blob_mesh(6, 8, seed=0)
+    H, W = 96, 128
+    proj = orc.projection_matrix(**syn.camera_intrinsics(W, H)).astype(np.float32)
+    params = np.array([[0.1, 0.3], [0.2, -0.1], [0.05, 0.4], [0.97, 0.85], [0.05, -0.1], [0.0, 0.05], [-0.1, -0.2]], np.float32)
+    mtx = orc.pose_fwd(params)
+    clip = orc.xfm_fwd(pos[None], np.matmul(proj[None], mtx).astype(np.float32), True)
+    assert ((clip[..., 3] <= 0).sum(1) > 3).all() and ((clip[..., 3] > 0).sum(1) > 3).all()
+    ref = orc.rasterize_fwd(clip, tri2, H, W)
+    assert (ref[..., 3] > 0).mean() > 0.2
+    rast, _ = dd.rasterize(dd.RasterizeGLContext(), T(clip), T(tri2), [H, W])
+    _check_rast(rast.cpu().numpy(), ref)

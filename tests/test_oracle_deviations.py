@@ -3,7 +3,7 @@ un-vendored and un-pinned).  Each test states, for a hand-built case,
 yields and what this build yields, so the size and the trigger of every deviation is on record.  CPU only (the HIP
 kernels are held to this oracle bit-for-bit / to tolerance by the -m gpu tests).
 
-  D1  a triangle with a vertex at clip w <= 0 is dropped, nvdiffrast (GL) clips it against the view volume
+  D1  (closed in round 2) a triangle with a vertex at clip w <= 0 was dropped; it is now clipped at the near plane as GL does
   D2  rasterize backward: a barycentric saturated by the [0,1] clamp passes no gradient, nvdiffrast differentiates
       the unclamped expression
   D3  antialias: of two triangle edges that cross the pixel-pair segment the one with the LARGER crossing parameter is
@@ -32,28 +32,46 @@ def _homogeneous_inside(P, px, py, H, W):
     return w > 0 and -w <= z <= w
 
 
-def test_d1_triangle_straddling_the_camera_plane_is_dropped_not_clipped():
+def test_d1_triangle_straddling_the_camera_plane_is_clipped_at_the_near_plane():
+    """Round 1 dropped any triangle with a vertex at w <= 0; since round 2 it is clipped against the near plane like
+    dr.rasterize does: the drawn pixels are exactly those of homogeneous rasterisation (no clipping needed there: Olano & Greer),
+    and (u, v, z/w) are the perspective-correct values of the ORIGINAL triangle."""
+    from diffdope_amd import synthetic as syn
+
     H, W = 16, 16
-    # two vertices in front of the camera (w = 1) on the left of the frame, the third behind it (w = -0.5)
-    P = np.array([[-0.9, -0.8, 0.0, 1.0], [-0.9, 0.8, 0.0, 1.0], [0.6, 0.0, 0.2, -0.5]], np.float64)
+    proj = orc.projection_matrix(**syn.camera_intrinsics(W, H))
+    cam = np.array([[-0.6, -0.4, -1.0, 1.0], [-0.6, 0.4, -1.0, 1.0], [0.5, 0.0, 0.3, 1.0]])  # the third vertex is BEHIND the camera
+    P = (proj @ cam.T).T
+    assert P[2, 3] < 0 < P[0, 3]
     tri = np.array([[0, 1, 2]], np.int32)
     want = np.array([[_homogeneous_inside(P, x, y, H, W) for x in range(W)] for y in range(H)])
-    assert 20 < want.sum() < H * W  # nvdiffrast (GL clipping): the visible part of the triangle is drawn
-    rast = orc.rasterize_fwd(P[None], tri, H, W)
-    assert np.all(rast[0, ..., 3] == 0)  # this build: the whole triangle is dropped (snap_triangle: any w <= 0)
-    # with the third vertex moved just in front of the camera the same triangle IS drawn, covering the pixels the
-    # homogeneous test predicts (so the deviation is confined to w <= 0 triangles)
-    P2 = P.copy()
-    P2[2] = [0.6, 0.0, 0.2, 0.5]
-    want2 = np.array([[_homogeneous_inside(P2, x, y, H, W) for x in range(W)] for y in range(H)])
-    got2 = orc.rasterize_fwd(P2[None], tri, H, W)[0, ..., 3] > 0
-    assert want2.sum() > 20 and (got2 != want2).sum() <= 2  # (edge-centre ties only)
+    for dt in (np.float64, np.float32):
+        rast = orc.rasterize_fwd(P[None].astype(dt), tri, H, W)
+        got = rast[0, ..., 3] > 0
+        assert want.sum() > 100 and np.array_equal(got, want)
+        for y, x in ((0, 1), (8, 1), (15, 15), (3, 9)):
+            u, v, zw = (float(c) for c in rast[0, y, x, :3])
+            c = u * P[0] + v * P[1] + (1 - u - v) * P[2]  # the point of the original triangle's plane these weights name
+            fx, fy = (x + 0.5) / W * 2 - 1, (y + 0.5) / H * 2 - 1
+            tol = 1e-9 if dt is np.float64 else 2e-5
+            assert abs(c[0] / c[3] - fx) < tol and abs(c[1] / c[3] - fy) < tol and abs(c[2] / c[3] - zw) < tol
+    # all three vertices behind the near plane: nothing; the same triangle reversed: the same pixels (no culling at this level)
+    behind = (proj @ np.array([[-0.6, -0.4, 0.2, 1.0], [-0.6, 0.4, 0.2, 1.0], [0.5, 0.0, 0.3, 1.0]]).T).T
+    assert not orc.rasterize_fwd(behind[None], tri, H, W)[..., 3].any()
+    assert np.array_equal(orc.rasterize_fwd(P[None], tri[:, [0, 2, 1]], H, W)[0, ..., 3] > 0, want)
+    # two straddlers sharing an edge whose ends are on opposite sides of the near plane: the clipped polygons meet without
+    # gap or overlap (the intersection is computed from the inside end of the edge in both)
+    cam4 = np.array([[-0.6, -0.4, -1.0, 1.0], [-0.6, 0.4, -1.0, 1.0], [0.5, 0.0, 0.3, 1.0], [0.45, 0.9, 0.3, 1.0]])
+    P4 = (proj @ cam4.T).T
+    r2 = orc.rasterize_fwd(P4[None], np.array([[0, 1, 2], [1, 3, 2]], np.int32), H, W)[0, ..., 3]
+    a = np.array([[_homogeneous_inside(P4[[0, 1, 2]], x, y, H, W) for x in range(W)] for y in range(H)])
+    bq = np.array([[_homogeneous_inside(P4[[1, 3, 2]], x, y, H, W) for x in range(W)] for y in range(H)])
+    assert np.array_equal(r2 > 0, a | bq) and (r2[a & ~bq] == 1).all() and (r2[bq & ~a] == 2).all()
 
 
 def test_d1_pose_gradient_when_part_of_a_mesh_crosses_the_camera_plane():
-    """Characterises the trigger on a whole mesh: a hypothesis so close that the camera plane cuts the object loses the
-    straddling triangles; loss and pose gradient stay finite, and the analytic gradient is still the derivative of what is
-    drawn (finite differences, float64)."""
+    """On a whole mesh: a hypothesis so close that the camera plane cuts the object; the straddling triangles are clipped, loss
+    and pose gradient stay finite, and the analytic gradient is the derivative of what is drawn (finite differences, float64)."""
     from diffdope_amd import synthetic as syn
 
     pos, tri, uv = syn.blob_mesh(6, 8, seed=0)
