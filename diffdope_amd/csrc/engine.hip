@@ -1804,6 +1804,15 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             }
             bool closed = true;
             double vol6 = 0.0;
+            // shells (connected components over welded vertices) must all be oriented the same way: one inside-out shell next
+            // to a regular one would lose its visible faces
+            std::vector<int> shell((size_t)V);
+            for (int i = 0; i < V; ++i) shell[(size_t)i] = i;
+            auto root = [&](int v) {
+                while (shell[(size_t)v] != v) { shell[(size_t)v] = shell[(size_t)shell[(size_t)v]]; v = shell[(size_t)v]; }
+                return v;
+            };
+            std::vector<double> tvol((size_t)T, 0.0);
             std::vector<unsigned long long> ek;  // (lo << 32 | hi) << 1 | direction
             ek.reserve((size_t)T * 3);
             for (int t = 0; t < T && closed; ++t) {
@@ -1814,7 +1823,10 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
                 const double x0 = hpos[(size_t)i0 * 3], y0 = hpos[(size_t)i0 * 3 + 1], z0 = hpos[(size_t)i0 * 3 + 2];
                 const double x1 = hpos[(size_t)i1 * 3], y1 = hpos[(size_t)i1 * 3 + 1], z1 = hpos[(size_t)i1 * 3 + 2];
                 const double x2 = hpos[(size_t)i2 * 3], y2 = hpos[(size_t)i2 * 3 + 1], z2 = hpos[(size_t)i2 * 3 + 2];
-                vol6 += x0 * (y1 * z2 - z1 * y2) - y0 * (x1 * z2 - z1 * x2) + z0 * (x1 * y2 - y1 * x2);
+                tvol[(size_t)t] = x0 * (y1 * z2 - z1 * y2) - y0 * (x1 * z2 - z1 * x2) + z0 * (x1 * y2 - y1 * x2);
+                vol6 += tvol[(size_t)t];
+                { const int ra = root(c[0]), rb = root(c[1]); if (ra != rb) shell[(size_t)ra] = rb; }
+                { const int ra = root(c[1]), rb = root(c[2]); if (ra != rb) shell[(size_t)ra] = rb; }
                 for (int k = 0; k < 3; ++k) {
                     const unsigned a = (unsigned)c[k], bq = (unsigned)c[(k + 1) % 3];
                     const unsigned lo = a < bq ? a : bq, hi = a < bq ? bq : a;
@@ -1827,12 +1839,21 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
                 for (size_t i = 0; closed && i < ek.size(); i += 2)
                     closed = (ek[i] >> 1) == (ek[i + 1] >> 1) && (ek[i] & 1) != (ek[i + 1] & 1) && (i + 2 >= ek.size() || (ek[i + 2] >> 1) != (ek[i] >> 1));
             }
+            if (getenv("DDX_DEBUG_CULL")) fprintf(stderr, "ddx cull: edges paired %d\n", (int)closed);
+            if (closed) {
+                std::vector<double> svol((size_t)V, 0.0);
+                for (int t = 0; t < T; ++t)
+                    if (tvol[(size_t)t] != 0.0) svol[(size_t)root(canon[(size_t)htri[(size_t)t * 3]])] += tvol[(size_t)t];
+                for (int v = 0; v < V && closed; ++v)
+                    if (svol[(size_t)v] != 0.0 && (svol[(size_t)v] > 0.0) != (vol6 > 0.0)) closed = false;
+            }
             float hp[16];
             DDX_HIP(hipMemcpyAsync(hp, E.b.proj, sizeof(hp), hipMemcpyDeviceToHost, s));
             DDX_HIP(hipStreamSynchronize(s));
             const double detA = (double)hp[0] * ((double)hp[5] * hp[14] - (double)hp[6] * hp[13]) - (double)hp[1] * ((double)hp[4] * hp[14] - (double)hp[6] * hp[12]) +
                                 (double)hp[2] * ((double)hp[4] * hp[13] - (double)hp[5] * hp[12]);
             const bool pinhole = hp[3] == 0.f && hp[7] == 0.f && hp[15] == 0.f;
+            if (getenv("DDX_DEBUG_CULL")) fprintf(stderr, "ddx cull: closed %d pinhole %d vol6 %g detA %g edges %zu\n", (int)closed, (int)pinhole, vol6, detA, ek.size());
             if (closed && pinhole && vol6 != 0.0 && detA != 0.0 && std::isfinite(vol6) && std::isfinite(detA))
                 E.L.cull_sign = ((vol6 > 0.0) == (detA > 0.0)) ? 1 : -1;
         }

@@ -64,16 +64,17 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = loss_rows.shape[1]
-    table = torch.zeros((world, 18), dtype=torch.float32, device=loss_rows.device)
+    # (one rank: its row is fully written by the kernel, no zero fill needed)
+    table = (torch.zeros if world > 1 else torch.empty)((world, 18), dtype=torch.float32, device=loss_rows.device)
     _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table[rank].data_ptr(),
                                    _lib.stream_ptr()), "ddx_select_best")
     if dist.is_initialized():
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
-    t = table.cpu()  # the one synchronisation
+    t = table.cpu().numpy()  # the one synchronisation (device -> host copy of world x 18 floats)
     losses, gidx = t[:, 0], t[:, 1]
-    cand = torch.where(losses == losses.min(), gidx, torch.full_like(gidx, float("inf")))
-    row = int(torch.argmin(cand))
-    return int(t[row, 1]), float(t[row, 0]), t[row, 2:].reshape(4, 4).to(mtx.device)
+    cand = [(gidx[r], r) for r in range(world) if losses[r] == losses.min()]  # ties -> lowest global index
+    row = min(cand)[1]
+    return int(t[row, 1]), float(t[row, 0]), table[row, 2:].reshape(4, 4)  # (the pose stays on the device: a view of the table)
 
 
 def merge_object_tables(table, group=None):

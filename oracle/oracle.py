@@ -139,7 +139,8 @@ def mesh_cull_sign(pos, tri, proj):
     """Deviation D5 (fused engine only): the sign of the snapped screen area of BACK-facing triangles when `pos`/`tri` is a closed,
     consistently oriented surface and `proj` a pinhole projection, else 0 (draw both faces).  Vertices are welded by position
     (bit-equal float32 coordinates: uv seams duplicate vertices); triangles with two welded corners equal are ignored; every
-    welded edge must belong to exactly two triangles running through it in opposite directions.  A camera-space triangle has
+    welded edge must belong to exactly two triangles running through it in opposite directions, and every connected shell must
+    have the sign of volume of the whole.  A camera-space triangle has
     det[p0;p1;p2] > 0 exactly when its counter-clockwise normal points away from the camera; the projection multiplies that
     orientation by det A (A = rows x, y, w of proj, whose 4th column must vanish), and counter-clockwise is outward when the
     signed volume is positive: sign = sign(volume) * sign(det A)."""
@@ -167,7 +168,17 @@ def mesh_cull_sign(pos, tri, proj):
         return 0
     p = np.asarray(pos, np.float64)
     p0, p1, p2 = p[t[:, 0]], p[t[:, 1]], p[t[:, 2]]
-    vol6 = float(np.einsum("ij,ij->i", p0, np.cross(p1, p2)).sum())
+    tvol = np.einsum("ij,ij->i", p0, np.cross(p1, p2))
+    vol6 = float(tvol.sum())
+    # every shell (connected component over welded vertices) must be oriented like the whole
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    nc = int(np.asarray(canon).max()) + 1
+    g = coo_matrix((np.ones(len(a), np.int8), (a, b)), shape=(nc, nc))
+    _, label = connected_components(g, directed=False)
+    svol = np.bincount(label[c[:, 0]], weights=tvol)
+    if np.any((svol != 0) & ((svol > 0) != (vol6 > 0))):
+        return 0
     P = np.asarray(proj, np.float64)
     if not (P[0, 3] == 0 and P[1, 3] == 0 and P[3, 3] == 0):
         return 0

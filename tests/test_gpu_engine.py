@@ -498,6 +498,17 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
     for i, key in enumerate(KEYS):
         np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
     np.testing.assert_allclose(g_far.cpu().numpy(), g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    # (d) two shells: culled when both are outward, not when the second is inside-out (same decision as the oracle's rule)
+    n = len(sc["pos"])
+    pos2 = np.concatenate([sc["pos"], sc["pos"] * np.float32(0.25) + np.float32(0.02)]).astype(np.float32)
+    uv2 = np.concatenate([sc["uv"], sc["uv"]]) if sc["textured"] else None
+    for second, want in ((sc["tri"] + n, -1), ((sc["tri"] + n)[:, [0, 2, 1]], 0)):
+        tri2 = np.concatenate([sc["tri"], second]).astype(np.int32)
+        sc2 = dict(sc, pos=pos2, tri=tri2, uv=uv2)
+        eng, _ = _engine(sc2, w, [0.1])
+        eng.loss_and_grad()  # (the mesh is analysed by the first run)
+        torch.cuda.synchronize()
+        assert eng.cull_sign == want == orc.mesh_cull_sign(pos2, tri2, sc["proj"])
 
 
 @pytest.mark.parametrize("deg,frac,tol_rad", [(1.0, 0.01, 1e-3), (10.0, 0.04, 5e-3), (40.0, 0.16, None)])

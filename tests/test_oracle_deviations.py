@@ -208,6 +208,11 @@ def test_d5_backface_culling_only_on_closed_meshes_and_invisible_there():
     flipped = tri.copy()
     flipped[37] = flipped[37][[0, 2, 1]]
     assert orc.mesh_cull_sign(pos, flipped, proj) == 0  # one triangle wound the other way
+    # two shells: fine when both are outward, refused when the smaller one is inside-out (its visible faces would go)
+    two_pos = np.concatenate([pos, pos * 0.5 + np.float32(2.0)]).astype(np.float32)
+    small = tri + len(pos)
+    assert orc.mesh_cull_sign(two_pos, np.concatenate([tri, small]), proj) == -1
+    assert orc.mesh_cull_sign(two_pos, np.concatenate([tri, small[:, [0, 2, 1]]]), proj) == 0
     bad_proj = proj.copy()
     bad_proj[3, 3] = 1.0  # orthographic-style w row: not the pinhole the sign argument needs
     assert orc.mesh_cull_sign(pos, tri, bad_proj) == 0
