@@ -59,6 +59,8 @@ _SIGNATURES = {
     "ddx_antialias_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_gbuffer_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_gbuffer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "ddx_silhouette_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "ddx_silhouette_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "ddx_masked_l1_fwd": (_I, [_P, _P, _P, _I, _I, _LL, _P, _P, _P]),
     "ddx_masked_l1_bwd": (_I, [_P, _P, _P, _I, _P, _I, _LL, _P, _P]),
     "ddx_engine_scratch_bytes": (_SZ, [ctypes.POINTER(EngineDesc)]),

@@ -705,12 +705,22 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
 __global__ __launch_bounds__(256) void emit_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
                                                    int B, int H, int W, RasterScratch L, float* __restrict__ rast)
 {
-    const long long n = (long long)B * H * W;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int px = (int)(i % W);
-        const int py = (int)((i / W) % H);
-        const int b = (int)(i / ((long long)W * H));
-        const unsigned long long key = L.zbuf[(size_t)b * L.zper + zaddr(px, py, L.zwb)];
+    // blockIdx.y = hypothesis, 1024 consecutive pixels of it per workgroup: 32-bit pixel arithmetic (H, W <= 4096)
+    const int b = blockIdx.y, HW = H * W;
+    unsigned long long keys[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        const int py = p / W, px = p - py * W;
+        keys[k] = p < HW ? L.zbuf[(size_t)b * L.zper + zaddr(px, py, L.zwb)] : ~0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (p >= HW) continue;
+        const int py = p / W, px = p - py * W;
+        const long long i = (long long)b * HW + p;
+        const unsigned long long key = keys[k];
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (key != ~0ull) {
             const int t = (int)(unsigned)(key & 0xffffffffull);
@@ -772,8 +782,7 @@ extern "C" int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, in
     hipStream_t s = (hipStream_t)stream;
     if (int e = raster_snap(pos, B, V, H, W, L, s)) return e;
     if (int e = raster_run(pos, tri, B, V, T, H, W, L, s, true, nullptr)) return e;
-    const long long n = (long long)B * H * W;
-    emit_kernel<<<(n + 255) / 256 > 8192 ? 8192 : (int)((n + 255) / 256), 256, 0, s>>>(pos, tri, V, B, H, W, L, rast);
+    emit_kernel<<<dim3((unsigned)((H * W + 1023) / 1024), (unsigned)B), 256, 0, s>>>(pos, tri, V, B, H, W, L, rast);
     DDX_LAUNCH_CHECK();
     return 0;
 }

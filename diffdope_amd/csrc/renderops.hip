@@ -3,10 +3,18 @@
 // interpolate, texture(linear, wrap), antialias -- forward and backward.  These are the
 // compatibility path (user loss functions that need materialised renders); the timed path is the
 // fused engine (engine.hip), which shares raster_math.h with these kernels.
-// All kernels: one lane per pixel, 256-thread workgroups, grid-stride over B*H*W.
+// All kernels: one lane per pixel, 256-thread workgroups.  The full-frame passes of render_texture_batch (antialias, gbuffer,
+// masked L1) launch per hypothesis -- blockIdx.y = hypothesis, a workgroup takes PIX_PER_WG consecutive pixels of it -- so
+// all pixel arithmetic is 32-bit: with a flat B*H*W index the 64-bit divisions (x, y, hypothesis of a pixel) cost more VALU
+// issue than the kernels' memory traffic takes time (antialias 136 -> 60 us on 64 x 640x480).  The remaining ops grid-stride.
 #include "raster.h"
 
 #define PIX_GRID(n) ((n + 255) / 256 > 16384 ? 16384 : (int)((n + 255) / 256))
+#define PIX_ROUNDS 4
+#define PIX_PER_WG (256 * PIX_ROUNDS)
+static inline dim3 pix_grid2(long long HW, int B) { return dim3((unsigned)((HW + PIX_PER_WG - 1) / PIX_PER_WG), (unsigned)B); }
+#define DDX_REQUIRE_FRAME(B, H, W, what) \
+    DDX_REQUIRE((long long)(H) * (W) < (1ll << 30) && (W) <= 65535 && (B) <= 65535, DDX_E_SHAPE, what ": frame of %d x %d pixels / %d hypotheses exceeds the launch limits", H, W, B)
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rasterize_bwd_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
@@ -214,42 +222,65 @@ extern "C" int ddx_texture_linear_bwd(const float* tex, long long tbs, int Th, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// antialias: one lane per pixel analyses the pairs to its right (d=0) and above (d=1, row+1)
-template <bool BWD>
+// antialias: one lane per pixel analyses the pairs to its right (d=0) and above (d=1, row+1).
+// COVERAGE: the colour is the coverage image itself -- interpolate(ones) of the pixel's rast entry, three equal channels
+// (diffdope.py:212-214) -- recomputed from rast instead of read: the forward adds its blends IN PLACE onto the coverage image
+// gbuffer_fwd wrote (no copy of the frame), the backward produces d pos only (coverage has no gradient path: no d colour).
+static __device__ __forceinline__ float coverage_of(const float4& r, int T)
+{
+    const int t = (int)r.w - 1;
+    if (t < 0 || t >= T) return 0.f;
+    const float w2 = (1.0f - r.x) - r.y;
+    return __fmaf_rn(w2, 1.0f, __fmaf_rn(r.y, 1.0f, r.x * 1.0f));  // == gbuffer_fwd_kernel's cv
+}
+
+#define AA_ROWS 4
+#define AA_QUEUE 4096
+template <bool BWD, bool COVERAGE>
 __global__ __launch_bounds__(256) void antialias_kernel(const float* __restrict__ color, int C,
                                                         const float* __restrict__ rast, const float* __restrict__ pos,
-                                                        const int* __restrict__ tri, const int* __restrict__ opp, int B,
+                                                        const int* __restrict__ tri, const int* __restrict__ opp,
                                                         int V, int T, int H, int W, const float* __restrict__ dout,
                                                         float* __restrict__ out /* fwd: out ; bwd: dcolor */,
                                                         float* __restrict__ dpos)
 {
-    const long long n = (long long)B * H * W;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int px = (int)(i % W), py = (int)((i / W) % H), b = (int)(i / ((long long)W * H));
-        const float4 r0 = ld4(rast + i * 4);
-        const int t0 = (int)r0.w - 1;
-        const float* P = pos + (size_t)b * V * 4;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const int qx = px + (d == 0), qy = py + (d == 1);
-            if (qx >= W || qy >= H) continue;
-            const long long j = i + (d == 0 ? 1 : W);
-            const float4 r1 = ld4(rast + j * 4);
-            const int t1 = (int)r1.w - 1;
-            if (t0 == t1 || t0 >= T || t1 >= T) continue;
+    // A workgroup takes AA_ROWS full rows of one hypothesis (blockIdx.y), 256 columns at a time.
+    // (1) streaming: each lane reads the triangle ids of its column in those rows plus the row above -- the upper neighbour of
+    // a row is the next row's own id, the right neighbour comes from the next lane -- and queues the pairs whose ids differ (a
+    // few per cent of a row that crosses the object, none elsewhere).  (2) the queued pairs are analysed with all lanes busy:
+    // a pair is a chain of dependent loads (triangle, vertices, neighbour triangle, ...) that should be walked once per
+    // workgroup, not once per row and direction.
+    // Measured on 64 x 640x480 (silhouette forward): flat B*H*W index with 64-bit divisions 136 us; 32-bit indices 120; own /
+    // right / upper id loaded separately 102 (own ids alone 52 = the 315 MB of rast lines at 6 TB/s; each extra id load
+    // +25..30 us of address processing although it hits the cache); tiles of 8x8 or 64x16 pixels per wave: 155 / 135.
+    __shared__ unsigned s_pair[AA_QUEUE];
+    __shared__ int s_n;
+    const int b = blockIdx.y, y0 = blockIdx.x * AA_ROWS, lane = threadIdx.x & 63;
+    const long long ib = (long long)b * H * W;
+    const float* P = pos + (size_t)b * V * 4;
+    auto drain = [&]() {  // all 256 threads
+        __syncthreads();
+        const int n_pair = s_n;
+        for (int q = threadIdx.x; q < n_pair; q += 256) {
+            const unsigned e = s_pair[q];
+            const int d = (int)(e & 1u), px = (int)((e >> 1) & 0xffffu), py = y0 + (int)(e >> 17);
+            const long long i = ib + (long long)py * W + px, j = i + (d == 0 ? 1 : W);
+            const float4 r0 = ld4(rast + i * 4), r1 = ld4(rast + j * 4);
+            const int t0 = (int)r0.w - 1, t1 = (int)r1.w - 1;
             AAPair pr;
             aa_eval_pair(P, tri, opp, H, W, px, py, d, t0, t1, r0.z, r1.z, pr);
             if (!pr.valid) continue;
             const long long tg = pr.alpha > 0.f ? i : j;
+            const float cdiff = COVERAGE ? coverage_of(r1, T) - coverage_of(r0, T) : 0.f;
             if (!BWD) {
                 for (int c = 0; c < C; ++c)
-                    atomicAdd(out + tg * C + c, pr.alpha * (color[j * C + c] - color[i * C + c]));
+                    atomicAdd(out + tg * C + c, pr.alpha * (COVERAGE ? cdiff : color[j * C + c] - color[i * C + c]));
             } else {
                 float galpha = 0.f;
                 for (int c = 0; c < C; ++c) {
                     const float g = dout[tg * C + c];
-                    galpha = __fmaf_rn(g, color[j * C + c] - color[i * C + c], galpha);
-                    if (g != 0.f) {
+                    galpha = __fmaf_rn(g, COVERAGE ? cdiff : color[j * C + c] - color[i * C + c], galpha);
+                    if (!COVERAGE && g != 0.f) {
                         atomicAdd(out + j * C + c, pr.alpha * g);
                         atomicAdd(out + i * C + c, -pr.alpha * g);
                     }
@@ -266,18 +297,51 @@ __global__ __launch_bounds__(256) void antialias_kernel(const float* __restrict_
                 atomicAdd(D + (size_t)pr.vb * 4 + 3, g[1][2]);
             }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    };
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int x0 = 0; x0 < W; x0 += 256) {  // (workgroup-uniform)
+        if (s_n > AA_QUEUE - 2 * AA_ROWS * 256) drain();  // (uniform: s_n only changes between barriers)
+        const int px = x0 + threadIdx.x;
+        const bool inx = px < W;
+        float id[AA_ROWS + 1];  // own rows and the row above the last
+#pragma unroll
+        for (int r = 0; r <= AA_ROWS; ++r) id[r] = (inx && y0 + r < H) ? rast[(ib + (long long)(y0 + r) * W + px) * 4 + 3] : 0.f;
+#pragma unroll
+        for (int r = 0; r < AA_ROWS; ++r) {
+            float right = __shfl_down(id[r], 1);
+            if (lane == 63 && px + 1 < W && y0 + r < H) right = rast[(ib + (long long)(y0 + r) * W + px + 1) * 4 + 3];
+            if (!inx || y0 + r >= H) continue;
+            const int t0 = (int)id[r] - 1;
+            if (px + 1 < W) {
+                const int t1 = (int)right - 1;
+                if (t0 != t1 && t0 < T && t1 < T) s_pair[atomicAdd(&s_n, 1)] = ((unsigned)r << 17) | ((unsigned)px << 1);
+            }
+            if (y0 + r + 1 < H) {
+                const int t1 = (int)id[r + 1] - 1;
+                if (t0 != t1 && t0 < T && t1 < T) s_pair[atomicAdd(&s_n, 1)] = ((unsigned)r << 17) | ((unsigned)px << 1) | 1u;
+            }
+        }
+        __syncthreads();
     }
+    drain();
 }
+
+static inline dim3 aa_grid(int H, int B) { return dim3((unsigned)((H + AA_ROWS - 1) / AA_ROWS), (unsigned)B); }
 
 extern "C" int ddx_antialias_fwd(const float* color, int C, const float* rast, const float* pos, const int32_t* tri,
                                  const int32_t* opp, int B, int V, int T, int H, int W, float* out, void* stream)
 {
     DDX_REQUIRE(color && rast && pos && tri && opp && out, DDX_E_NULL, "antialias_fwd: NULL pointer");
     DDX_REQUIRE(C >= 1 && C <= 64 && B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "antialias_fwd: bad shape");
+    DDX_REQUIRE_FRAME(B, H, W, "antialias_fwd");
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * H * W;
     DDX_HIP(hipMemcpyAsync(out, color, (size_t)n * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-    antialias_kernel<false><<<PIX_GRID(n), 256, 0, s>>>(color, C, rast, pos, tri, opp, B, V, T, H, W, nullptr, out, nullptr);
+    antialias_kernel<false, false><<<aa_grid(H, B), 256, 0, s>>>(color, C, rast, pos, tri, opp, V, T, H, W, nullptr, out, nullptr);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -288,11 +352,39 @@ extern "C" int ddx_antialias_bwd(const float* color, int C, const float* rast, c
 {
     DDX_REQUIRE(color && rast && pos && tri && opp && dout && dcolor && dpos, DDX_E_NULL, "antialias_bwd: NULL pointer");
     DDX_REQUIRE(C >= 1 && C <= 64 && B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "antialias_bwd: bad shape");
+    DDX_REQUIRE_FRAME(B, H, W, "antialias_bwd");
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * H * W;
     DDX_HIP(hipMemcpyAsync(dcolor, dout, (size_t)n * C * sizeof(float), hipMemcpyDeviceToDevice, s));
     DDX_HIP(hipMemsetAsync(dpos, 0, (size_t)B * V * 4 * sizeof(float), s));
-    antialias_kernel<true><<<PIX_GRID(n), 256, 0, s>>>(color, C, rast, pos, tri, opp, B, V, T, H, W, dout, dcolor, dpos);
+    antialias_kernel<true, false><<<aa_grid(H, B), 256, 0, s>>>(color, C, rast, pos, tri, opp, V, T, H, W, dout, dcolor, dpos);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+// The silhouette of render_texture_batch (diffdope.py:212-214: antialias of the interpolation of a tensor of ones) without a
+// colour operand.  Forward: `mask` [B,H,W,3] holds the coverage image (ddx_gbuffer_fwd's `cover`) on entry and the antialiased
+// silhouette on return.  Backward: d pos [B,V,4] from d mask.  Bit-identical to ddx_antialias_fwd / _bwd on that colour.
+extern "C" int ddx_silhouette_fwd(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
+                                  int H, int W, float* mask, void* stream)
+{
+    DDX_REQUIRE(rast && pos && tri && opp && mask, DDX_E_NULL, "silhouette_fwd: NULL pointer");
+    DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "silhouette_fwd: bad shape");
+    DDX_REQUIRE_FRAME(B, H, W, "silhouette_fwd");
+    antialias_kernel<false, true><<<aa_grid(H, B), 256, 0, (hipStream_t)stream>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, nullptr, mask, nullptr);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_silhouette_bwd(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
+                                  int H, int W, const float* dmask, float* dpos, void* stream)
+{
+    DDX_REQUIRE(rast && pos && tri && opp && dmask && dpos, DDX_E_NULL, "silhouette_bwd: NULL pointer");
+    DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "silhouette_bwd: bad shape");
+    DDX_REQUIRE_FRAME(B, H, W, "silhouette_bwd");
+    hipStream_t s = (hipStream_t)stream;
+    DDX_HIP(hipMemsetAsync(dpos, 0, (size_t)B * V * 4 * sizeof(float), s));
+    antialias_kernel<true, true><<<aa_grid(H, B), 256, 0, s>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, dmask, nullptr, dpos);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -315,7 +407,10 @@ __global__ __launch_bounds__(256) void masked_l1_partial_kernel(const float* __r
     float acc = 0.f;
     for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
         const float mk = m ? m[i * m_stride] : 1.0f;
-        acc += fabsf((xb[i] - y[i]) * mk);
+        // (x is not read where the mask is exactly zero: the observed segmentation covers a few per cent of the frame, and a
+        // wave whose 64 elements are all masked out issues no load for them.  0 * finite = 0 either way; a NaN / Inf render
+        // under a zero mask contributes 0 here and NaN in the torch expression)
+        if (mk != 0.f) acc += fabsf((xb[i] - y[i]) * mk);
     }
     acc = wave_sum(acc);
     __shared__ float red[4];
@@ -337,15 +432,95 @@ __global__ __launch_bounds__(ML1_CHUNKS) void masked_l1_final_kernel(const float
 
 __global__ __launch_bounds__(256) void masked_l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ m, int m_stride, const float* __restrict__ gout,
-                                                            long long N, long long total, float* __restrict__ dx)
+                                                            long long N, float* __restrict__ dx)
 {
-    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long long)gridDim.x * 256) {
-        const long long b = j / N, i = j - b * N;
+    const int b = blockIdx.y;
+    const float scale = gout[b] / (float)N;
+    const float* xb = x + (size_t)b * N;
+    float* db = dx + (size_t)b * N;
+#pragma unroll
+    for (int k = 0; k < PIX_ROUNDS; ++k) {
+        const long long i = (long long)blockIdx.x * PIX_PER_WG + k * 256 + threadIdx.x;
+        if (i >= N) continue;
         const float mk = m ? m[i * m_stride] : 1.0f;
-        const float d = (x[j] - y[i]) * mk;
-        const float sg = (float)((d > 0.f) - (d < 0.f));
-        dx[j] = sg * mk * (gout[b] / (float)N);
+        float g = 0.f;
+        if (mk != 0.f) {  // (as the forward: x is only read where the mask lets it through)
+            const float d = (xb[i] - y[i]) * mk;
+            g = (float)((d > 0.f) - (d < 0.f)) * mk * scale;
+        }
+        db[i] = g;
     }
+}
+
+// Four consecutive elements per lane (N % 4 == 0, 16-byte aligned operands): 1 KB per wave instruction instead of 256 B, a
+// quarter of the loop trips.  The terms of a group are added pairwise before they join the lane's sum (fixed order).
+template <bool STRIDE1>
+static __device__ __forceinline__ float4 mask4(const float* __restrict__ m, int m_stride, long long i4)
+{
+    if (!m) return make_float4(1.f, 1.f, 1.f, 1.f);
+    if (STRIDE1) return ld4(m + i4 * 4);
+    const long long e = i4 * 4;
+    return make_float4(m[e * m_stride], m[(e + 1) * m_stride], m[(e + 2) * m_stride], m[(e + 3) * m_stride]);
+}
+
+template <bool STRIDE1>
+__global__ __launch_bounds__(256) void masked_l1_partial4_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                 const float* __restrict__ m, int m_stride, long long N,
+                                                                 float* __restrict__ partial)
+{
+    const int b = blockIdx.y, c = blockIdx.x;
+    const long long N4 = N >> 2, per = (N4 + ML1_CHUNKS - 1) / ML1_CHUNKS;
+    const long long i0 = (long long)c * per, i1 = i0 + per < N4 ? i0 + per : N4;
+    const float* xb = x + (size_t)b * N;
+    float acc = 0.f;
+#pragma unroll 2
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float4 mk = mask4<STRIDE1>(m, m_stride, i);
+        if (mk.x != 0.f || mk.y != 0.f || mk.z != 0.f || mk.w != 0.f) {  // (see masked_l1_partial_kernel)
+            const float4 xv = ld4(xb + i * 4), yv = ld4(y + i * 4);
+            acc += (fabsf((xv.x - yv.x) * mk.x) + fabsf((xv.y - yv.y) * mk.y)) + (fabsf((xv.z - yv.z) * mk.z) + fabsf((xv.w - yv.w) * mk.w));
+        }
+    }
+    acc = wave_sum(acc);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * ML1_CHUNKS + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <bool STRIDE1>
+__global__ __launch_bounds__(256) void masked_l1_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ m, int m_stride, const float* __restrict__ gout,
+                                                             long long N, float* __restrict__ dx)
+{
+    const int b = blockIdx.y;
+    const float scale = gout[b] / (float)N;
+    const float* xb = x + (size_t)b * N;
+    float* db = dx + (size_t)b * N;
+    const long long N4 = N >> 2;
+    auto one = [&](float xv, float yv, float mk) {
+        const float d = (xv - yv) * mk;
+        return (float)((d > 0.f) - (d < 0.f)) * mk * scale;
+    };
+#pragma unroll
+    for (int k = 0; k < PIX_ROUNDS; ++k) {
+        const long long i = (long long)blockIdx.x * PIX_PER_WG + k * 256 + threadIdx.x;
+        if (i >= N4) continue;
+        const float4 mk = mask4<STRIDE1>(m, m_stride, i);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mk.x != 0.f || mk.y != 0.f || mk.z != 0.f || mk.w != 0.f) {
+            const float4 xv = ld4(xb + i * 4), yv = ld4(y + i * 4);
+            g = make_float4(mk.x != 0.f ? one(xv.x, yv.x, mk.x) : 0.f, mk.y != 0.f ? one(xv.y, yv.y, mk.y) : 0.f,
+                            mk.z != 0.f ? one(xv.z, yv.z, mk.z) : 0.f, mk.w != 0.f ? one(xv.w, yv.w, mk.w) : 0.f);
+        }
+        *reinterpret_cast<float4*>(db + i * 4) = g;
+    }
+}
+
+static inline bool ml1_vec_ok(const void* x, const void* y, const void* m, int m_stride, const void* dx, long long N)
+{
+    auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    return (N & 3) == 0 && al(x) && al(y) && (!dx || al(dx)) && (!m || m_stride != 1 || al(m));
 }
 
 extern "C" int ddx_masked_l1_fwd(const float* x, const float* y, const float* m, int m_stride, int B, long long N, float* partial,
@@ -353,7 +528,11 @@ extern "C" int ddx_masked_l1_fwd(const float* x, const float* y, const float* m,
 {
     DDX_REQUIRE(x && y && partial && out, DDX_E_NULL, "masked_l1_fwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && m_stride >= 1, DDX_E_SHAPE, "masked_l1_fwd: bad shape B=%d N=%lld stride=%d", B, N, m_stride);
-    masked_l1_partial_kernel<<<dim3(ML1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, N, partial);
+    if (ml1_vec_ok(x, y, m, m_stride, nullptr, N)) {
+        if (!m || m_stride == 1) masked_l1_partial4_kernel<true><<<dim3(ML1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, N, partial);
+        else masked_l1_partial4_kernel<false><<<dim3(ML1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, N, partial);
+    } else
+        masked_l1_partial_kernel<<<dim3(ML1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, N, partial);
     masked_l1_final_kernel<<<B, ML1_CHUNKS, 0, (hipStream_t)stream>>>(partial, N, out);
     DDX_LAUNCH_CHECK();
     return 0;
@@ -364,8 +543,12 @@ extern "C" int ddx_masked_l1_bwd(const float* x, const float* y, const float* m,
 {
     DDX_REQUIRE(x && y && gout && dx, DDX_E_NULL, "masked_l1_bwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && N >= 1 && m_stride >= 1, DDX_E_SHAPE, "masked_l1_bwd: bad shape");
-    const long long total = (long long)B * N;
-    masked_l1_bwd_kernel<<<PIX_GRID(total), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, gout, N, total, dx);
+    DDX_REQUIRE(B <= 65535 && N < (1ll << 40), DDX_E_SHAPE, "masked_l1_bwd: B=%d N=%lld exceed the launch limits", B, N);
+    if (ml1_vec_ok(x, y, m, m_stride, dx, N)) {
+        if (!m || m_stride == 1) masked_l1_bwd4_kernel<true><<<pix_grid2(N >> 2, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, gout, N, dx);
+        else masked_l1_bwd4_kernel<false><<<pix_grid2(N >> 2, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, gout, N, dx);
+    } else
+        masked_l1_bwd_kernel<<<pix_grid2(N, B), 256, 0, (hipStream_t)stream>>>(x, y, m, m_stride, gout, N, dx);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -383,14 +566,18 @@ template <bool TEXTURED>
 __global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restrict__ rast, const float* __restrict__ mtx,
                                                           const float* __restrict__ pos, const int* __restrict__ tri,
                                                           const float* __restrict__ uv, const float* __restrict__ tex, int Th, int Tw,
-                                                          const float* __restrict__ vcol, int V, int T, long long HW, long long n,
+                                                          const float* __restrict__ vcol, int V, int T, int HW,
                                                           float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ cover)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int b = blockIdx.y;
+    const float* M = mtx + (size_t)b * 16;
+#pragma unroll
+    for (int rd = 0; rd < PIX_ROUNDS; ++rd) {
+        const int p = blockIdx.x * PIX_PER_WG + rd * 256 + threadIdx.x;
+        if (p >= HW) continue;
+        const long long i = (long long)b * HW + p;
         const float4 r = ld4(rast + i * 4);
         const int t = (int)r.w - 1;
-        const int b = (int)(i / HW);
-        const float* M = mtx + (size_t)b * 16;
         float col[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f}, cv = 0.f;
         int i0 = 0, i1 = 0, i2 = 0;
         bool in = t >= 0 && t < T;
@@ -439,123 +626,119 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mtx, const float* __restrict__ pos,
                                                           const int* __restrict__ tri, const float* __restrict__ uv,
                                                           const float* __restrict__ tex, int Th, int Tw, const float* __restrict__ vcol,
-                                                          int V, int T, int H, int W, long long n, const float* __restrict__ drgb,
+                                                          int V, int T, int H, int W, const float* __restrict__ drgb,
                                                           const float* __restrict__ ddepth, float* __restrict__ dclip,
                                                           float* __restrict__ dmtx)
 {
-    const long long HW = (long long)H * W;
+    const int HW = H * W;
     __shared__ float s_dm[4][4];
-    // this workgroup's pixels of ONE hypothesis contribute to d mtx[b][2][:]; a grid-stride step may cross into the next
-    // hypothesis, so the four sums are flushed whenever b changes (and at the end)
+    // the pixels of this workgroup belong to ONE hypothesis (blockIdx.y): their contributions to d mtx[b][2][:] are summed over
+    // the workgroup and added with four atomics at the end
     float dm[4] = {0.f, 0.f, 0.f, 0.f};
-    int b_cur = -1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto flush = [&](int b) {  // all 256 threads
+    const int bb = blockIdx.y;
+    float4 rr[PIX_ROUNDS];  // (all rounds' visibility records in flight before the first is used)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float sum = wave_sum(dm[c]);
-            if (lane == 0) s_dm[wave][c] = sum;
-            dm[c] = 0.f;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4 && b >= 0) {
-            const float tot = (s_dm[0][threadIdx.x] + s_dm[1][threadIdx.x]) + (s_dm[2][threadIdx.x] + s_dm[3][threadIdx.x]);
-            if (tot != 0.f) atomicAdd(dmtx + (size_t)b * 16 + 8 + threadIdx.x, tot);
-        }
-        __syncthreads();
-    };
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long base = (long long)blockIdx.x * 256; base < n; base += stride) {  // (workgroup-uniform trip count)
-        const int b_blk = (int)(base / HW), b_end = (int)(min(base + 255, n - 1) / HW);
-        if (b_cur >= 0 && b_blk != b_cur) flush(b_cur);
-        b_cur = b_blk;
-        for (int bb = b_blk; bb <= b_end; ++bb) {  // (a 256-pixel block straddles at most two hypotheses)
-            const long long i = base + threadIdx.x;
-            const bool mine = i < n && (int)(i / HW) == bb;
-            if (mine) {
-                const float4 r = ld4(rast + i * 4);
-                const int t = (int)r.w - 1;
-                const float gd = ddepth ? ddepth[i] : 0.f;
-                const float* M = mtx + (size_t)bb * 16;
-                int i0 = 0, i1 = 0, i2 = 0;
-                bool in = t >= 0 && t < T;
-                if (in) {
-                    i0 = tri[t * 3 + 0]; i1 = tri[t * 3 + 1]; i2 = tri[t * 3 + 2];
-                    in = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
+    for (int rd = 0; rd < PIX_ROUNDS; ++rd) {
+        const int p = blockIdx.x * PIX_PER_WG + rd * 256 + threadIdx.x;
+        rr[rd] = p < HW ? ld4(rast + ((long long)bb * HW + p) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int rd = 0; rd < PIX_ROUNDS; ++rd) {
+        const int p = blockIdx.x * PIX_PER_WG + rd * 256 + threadIdx.x;
+        const bool mine = p < HW;
+        const long long i = (long long)bb * HW + p;
+        if (mine) {
+            const float4 r = rr[rd];
+            const int t = (int)r.w - 1;
+            const float gd = ddepth ? ddepth[i] : 0.f;
+            const float* M = mtx + (size_t)bb * 16;
+            int i0 = 0, i1 = 0, i2 = 0;
+            bool in = t >= 0 && t < T;
+            if (in) {
+                i0 = tri[t * 3 + 0]; i1 = tri[t * 3 + 1]; i2 = tri[t * 3 + 2];
+                in = (unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V;
+            }
+            if (!in) {
+                dm[3] += -gd;  // depth of a background pixel = -mtx[2][3]
+            } else {
+                const float u = r.x, v = r.y, w2 = (1.0f - u) - v;
+                float p0[3], p1[3], p2[3], gb[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    p0[c] = pos[(size_t)i0 * 3 + c]; p1[c] = pos[(size_t)i1 * 3 + c]; p2[c] = pos[(size_t)i2 * 3 + c];
+                    gb[c] = __fmaf_rn(w2, p2[c], __fmaf_rn(v, p1[c], u * p0[c]));
                 }
-                if (!in) {
-                    dm[3] += -gd;  // depth of a background pixel = -mtx[2][3]
-                } else {
-                    const float u = r.x, v = r.y, w2 = (1.0f - u) - v;
-                    float p0[3], p1[3], p2[3], gb[3];
+                float gu = 0.f, gv = 0.f;
+                // depth = -(M2 . [gb;1]):  d/d M2 = -g [gb;1],  d/d gb = -g M2[0..2]
+                dm[0] += -gd * gb[0]; dm[1] += -gd * gb[1]; dm[2] += -gd * gb[2]; dm[3] += -gd;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        p0[c] = pos[(size_t)i0 * 3 + c]; p1[c] = pos[(size_t)i1 * 3 + c]; p2[c] = pos[(size_t)i2 * 3 + c];
-                        gb[c] = __fmaf_rn(w2, p2[c], __fmaf_rn(v, p1[c], u * p0[c]));
-                    }
-                    float gu = 0.f, gv = 0.f;
-                    // depth = -(M2 . [gb;1]):  d/d M2 = -g [gb;1],  d/d gb = -g M2[0..2]
-                    dm[0] += -gd * gb[0]; dm[1] += -gd * gb[1]; dm[2] += -gd * gb[2]; dm[3] += -gd;
+                for (int c = 0; c < 3; ++c) {
+                    const float ggb = -gd * M[8 + c];
+                    gu = __fmaf_rn(ggb, p0[c] - p2[c], gu);
+                    gv = __fmaf_rn(ggb, p1[c] - p2[c], gv);
+                }
+                if (drgb) {
+                    const float k = r.w < 0.f ? 0.f : (r.w > 1.f ? 1.f : r.w);
+                    const float g[3] = {drgb[i * 3 + 0] * k, drgb[i * 3 + 1] * k, drgb[i * 3 + 2] * k};
+                    if (TEXTURED) {
+                        const float a0x = uv[(size_t)i0 * 2], a0y = uv[(size_t)i0 * 2 + 1], a1x = uv[(size_t)i1 * 2], a1y = uv[(size_t)i1 * 2 + 1],
+                                    a2x = uv[(size_t)i2 * 2], a2y = uv[(size_t)i2 * 2 + 1];
+                        const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x)), tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
+                        TexelSetup s;
+                        tex_setup(tu, tv, Th, Tw, s);
+                        const float *t00 = tex + ((size_t)s.y0 * Tw + s.x0) * 3, *t10 = tex + ((size_t)s.y0 * Tw + s.x1) * 3,
+                                    *t01 = tex + ((size_t)s.y1 * Tw + s.x0) * 3, *t11 = tex + ((size_t)s.y1 * Tw + s.x1) * 3;
+                        float gtu = 0.f, gtv = 0.f;  // d loss / d (tu, tv), as texture_bwd_kernel
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float ggb = -gd * M[8 + c];
-                        gu = __fmaf_rn(ggb, p0[c] - p2[c], gu);
-                        gv = __fmaf_rn(ggb, p1[c] - p2[c], gv);
-                    }
-                    if (drgb) {
-                        const float k = r.w < 0.f ? 0.f : (r.w > 1.f ? 1.f : r.w);
-                        const float g[3] = {drgb[i * 3 + 0] * k, drgb[i * 3 + 1] * k, drgb[i * 3 + 2] * k};
-                        if (TEXTURED) {
-                            const float a0x = uv[(size_t)i0 * 2], a0y = uv[(size_t)i0 * 2 + 1], a1x = uv[(size_t)i1 * 2], a1y = uv[(size_t)i1 * 2 + 1],
-                                        a2x = uv[(size_t)i2 * 2], a2y = uv[(size_t)i2 * 2 + 1];
-                            const float tu = __fmaf_rn(w2, a2x, __fmaf_rn(v, a1x, u * a0x)), tv = __fmaf_rn(w2, a2y, __fmaf_rn(v, a1y, u * a0y));
-                            TexelSetup s;
-                            tex_setup(tu, tv, Th, Tw, s);
-                            const float *t00 = tex + ((size_t)s.y0 * Tw + s.x0) * 3, *t10 = tex + ((size_t)s.y0 * Tw + s.x1) * 3,
-                                        *t01 = tex + ((size_t)s.y1 * Tw + s.x0) * 3, *t11 = tex + ((size_t)s.y1 * Tw + s.x1) * 3;
-                            float gtu = 0.f, gtv = 0.f;  // d loss / d (tu, tv), as texture_bwd_kernel
+                        for (int c = 0; c < 3; ++c) {
+                            const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
+                            gtu = __fmaf_rn(g[c], __fmaf_rn(s.fy, (c11 - c01) - (c10 - c00), c10 - c00), gtu);
+                            gtv = __fmaf_rn(g[c], __fmaf_rn(s.fx, (c11 - c10) - (c01 - c00), c01 - c00), gtv);
+                        }
+                        gtu *= (float)Tw; gtv *= (float)Th;
+                        gu = __fmaf_rn(gtu, a0x - a2x, gu); gu = __fmaf_rn(gtv, a0y - a2y, gu);
+                        gv = __fmaf_rn(gtu, a1x - a2x, gv); gv = __fmaf_rn(gtv, a1y - a2y, gv);
+                    } else {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float c00 = t00[c], c10 = t10[c], c01 = t01[c], c11 = t11[c];
-                                gtu = __fmaf_rn(g[c], __fmaf_rn(s.fy, (c11 - c01) - (c10 - c00), c10 - c00), gtu);
-                                gtv = __fmaf_rn(g[c], __fmaf_rn(s.fx, (c11 - c10) - (c01 - c00), c01 - c00), gtv);
-                            }
-                            gtu *= (float)Tw; gtv *= (float)Th;
-                            gu = __fmaf_rn(gtu, a0x - a2x, gu); gu = __fmaf_rn(gtv, a0y - a2y, gu);
-                            gv = __fmaf_rn(gtu, a1x - a2x, gv); gv = __fmaf_rn(gtv, a1y - a2y, gv);
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const float c0 = vcol[(size_t)i0 * 3 + c], c1 = vcol[(size_t)i1 * 3 + c], c2 = vcol[(size_t)i2 * 3 + c];
-                                gu = __fmaf_rn(g[c], c0 - c2, gu);
-                                gv = __fmaf_rn(g[c], c1 - c2, gv);
-                            }
+                        for (int c = 0; c < 3; ++c) {
+                            const float c0 = vcol[(size_t)i0 * 3 + c], c1 = vcol[(size_t)i1 * 3 + c], c2 = vcol[(size_t)i2 * 3 + c];
+                            gu = __fmaf_rn(g[c], c0 - c2, gu);
+                            gv = __fmaf_rn(g[c], c1 - c2, gv);
                         }
                     }
-                    if (gu != 0.f || gv != 0.f) {
-                        const int px = (int)(i % W), py = (int)((i / W) % H);
-                        const float* P = clip + (size_t)bb * V * 4;
-                        const float4 c0 = ld4(P + (size_t)i0 * 4), c1 = ld4(P + (size_t)i1 * 4), c2 = ld4(P + (size_t)i2 * 4);
-                        Bary bc;
-                        if (pixel_bary(c0, c1, c2, px, py, H, W, bc)) {
-                            float gx[3], gy[3], gw[3];
-                            bary_backward(bc, gu, gv, gx, gy, gw);
-                            float* D = dclip + (size_t)bb * V * 4;
-                            const int vi[3] = {i0, i1, i2};
+                }
+                if (gu != 0.f || gv != 0.f) {
+                    const int py = p / W, px = p - py * W;
+                    const float* P = clip + (size_t)bb * V * 4;
+                    const float4 c0 = ld4(P + (size_t)i0 * 4), c1 = ld4(P + (size_t)i1 * 4), c2 = ld4(P + (size_t)i2 * 4);
+                    Bary bc;
+                    if (pixel_bary(c0, c1, c2, px, py, H, W, bc)) {
+                        float gx[3], gy[3], gw[3];
+                        bary_backward(bc, gu, gv, gx, gy, gw);
+                        float* D = dclip + (size_t)bb * V * 4;
+                        const int vi[3] = {i0, i1, i2};
 #pragma unroll
-                            for (int q = 0; q < 3; ++q) {
-                                atomicAdd(D + (size_t)vi[q] * 4 + 0, gx[q]);
-                                atomicAdd(D + (size_t)vi[q] * 4 + 1, gy[q]);
-                                atomicAdd(D + (size_t)vi[q] * 4 + 3, gw[q]);
-                            }
+                        for (int q = 0; q < 3; ++q) {
+                            atomicAdd(D + (size_t)vi[q] * 4 + 0, gx[q]);
+                            atomicAdd(D + (size_t)vi[q] * 4 + 1, gy[q]);
+                            atomicAdd(D + (size_t)vi[q] * 4 + 3, gw[q]);
                         }
                     }
                 }
             }
-            if (bb < b_end) { flush(bb); b_cur = bb + 1; }
         }
     }
-    if (b_cur >= 0) flush(b_cur);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float sum = wave_sum(dm[c]);
+        if (lane == 0) s_dm[wave][c] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float tot = (s_dm[0][threadIdx.x] + s_dm[1][threadIdx.x]) + (s_dm[2][threadIdx.x] + s_dm[3][threadIdx.x]);
+        if (tot != 0.f) atomicAdd(dmtx + (size_t)bb * 16 + 8 + threadIdx.x, tot);
+    }
 }
 
 extern "C" int ddx_gbuffer_fwd(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv,
@@ -566,10 +749,10 @@ extern "C" int ddx_gbuffer_fwd(const float* rast, const float* mtx, const float*
     DDX_REQUIRE((uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_fwd: needs (uv, tex) or vtx_color");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "gbuffer_fwd: bad shape");
     DDX_REQUIRE(((uintptr_t)rast & 15) == 0, DDX_E_ALIGN, "gbuffer_fwd: rast must be 16-byte aligned");
-    const long long n = (long long)B * H * W;
+    DDX_REQUIRE_FRAME(B, H, W, "gbuffer_fwd");
     hipStream_t s = (hipStream_t)stream;
-    if (uv && tex) gbuffer_fwd_kernel<true><<<PIX_GRID(n), 256, 0, s>>>(rast, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, (long long)H * W, n, rgb, depth, cover);
-    else gbuffer_fwd_kernel<false><<<PIX_GRID(n), 256, 0, s>>>(rast, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, (long long)H * W, n, rgb, depth, cover);
+    if (uv && tex) gbuffer_fwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H * W, rgb, depth, cover);
+    else gbuffer_fwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H * W, rgb, depth, cover);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -582,12 +765,12 @@ extern "C" int ddx_gbuffer_bwd(const float* rast, const float* clip, const float
     DDX_REQUIRE((uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_bwd: needs (uv, tex) or vtx_color");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "gbuffer_bwd: bad shape");
     DDX_REQUIRE(((uintptr_t)rast & 15) == 0 && ((uintptr_t)clip & 15) == 0, DDX_E_ALIGN, "gbuffer_bwd: rast / clip must be 16-byte aligned");
+    DDX_REQUIRE_FRAME(B, H, W, "gbuffer_bwd");
     hipStream_t s = (hipStream_t)stream;
     DDX_HIP(hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(dmtx, 0, (size_t)B * 16 * sizeof(float), s));
-    const long long n = (long long)B * H * W;
-    if (uv && tex) gbuffer_bwd_kernel<true><<<PIX_GRID(n), 256, 0, s>>>(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H, W, n, drgb, ddepth, dclip, dmtx);
-    else gbuffer_bwd_kernel<false><<<PIX_GRID(n), 256, 0, s>>>(rast, clip, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H, W, n, drgb, ddepth, dclip, dmtx);
+    if (uv && tex) gbuffer_bwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H, W, drgb, ddepth, dclip, dmtx);
+    else gbuffer_bwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H, W, drgb, ddepth, dclip, dmtx);
     DDX_LAUNCH_CHECK();
     return 0;
 }

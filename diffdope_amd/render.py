@@ -308,6 +308,33 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
     return out
 
 
+class _silhouette_func(torch.autograd.Function):
+    """antialias of the coverage image, in place on the `cover` output of _gbuffer_func (ddx_silhouette_fwd / _bwd): no colour
+    operand, no copy of the frame, gradient for the clip-space positions only."""
+
+    @staticmethod
+    def forward(ctx, cover, rast, pos, tri, opp):
+        rast, pos, tri = _f32c(rast, "rast"), _f32c(pos, "pos"), _i32c(tri, "tri")
+        B, H, W = rast.shape[:3]
+        V, T = pos.shape[1], tri.shape[0]
+        _lib.check(_lib.load().ddx_silhouette_fwd(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(cover),
+                                                  _lib.stream_ptr()), "ddx_silhouette_fwd")
+        ctx.mark_dirty(cover)
+        ctx.save_for_backward(rast, pos, tri, opp)
+        return cover
+
+    @staticmethod
+    def backward(ctx, dmask):
+        rast, pos, tri, opp = ctx.saved_tensors
+        B, H, W = rast.shape[:3]
+        V, T = pos.shape[1], tri.shape[0]
+        dmask = _f32c(dmask, "dmask")
+        dpos = torch.empty_like(pos)
+        _lib.check(_lib.load().ddx_silhouette_bwd(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(dmask),
+                                                  _lib.ptr(dpos), _lib.stream_ptr()), "ddx_silhouette_bwd")
+        return None, None, dpos, None, None
+
+
 def antialias_construct_topology_hash(tri):
     return build_topology(tri)
 
@@ -464,8 +491,9 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
         kw = dict(uv=_f32c(_one_copy(uv), "uv"), tex=_f32c(_one_copy(tex), "tex"), vtx_color=None) if textured else \
             dict(uv=None, tex=None, vtx_color=_f32c(_one_copy(vtx_color), "vtx_color"))
         rgb, depth, cover = _gbuffer_func.apply(clip, mtx, rast.detach(), p1, _i32c(faces, "pos_idx"), kw["uv"], kw["tex"], kw["vtx_color"])
-        mask = antialias(cover, rast.detach(), clip, faces)  # (detached: antialias has no gradient for rast, and an attached one
-        #                                                      would still make autograd run rasterize's backward on zeros)
+        # the silhouette: antialias blends added in place onto the coverage image (rast detached: antialias has no gradient for
+        # it, and an attached one would still make autograd run rasterize's backward on zeros)
+        mask = _silhouette_func.apply(cover, rast.detach(), clip, _i32c(faces, "pos_idx"), build_topology(faces))
         return {"rgb": rgb, "depth": depth, "rast_out": rast if return_rast_out else None, "mask": mask}
     covered = rast[..., 3:].clamp(0, 1)
     # depth: object-space position under each pixel, through the pose, camera z negated (:203-209); a background pixel

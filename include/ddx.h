@@ -141,6 +141,16 @@ int ddx_gbuffer_bwd(const float* rast, const float* clip, const float* mtx, cons
                     const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, const float* drgb,
                     const float* ddepth, float* dclip, float* dmtx, void* stream);
 
+/* The silhouette of render_texture_batch -- dr.antialias applied to the interpolation of a tensor of ones (diffdope.py:212-214) --
+ * without a colour operand: the colour IS the coverage (recomputed from rast), so the forward blends IN PLACE on the `cover` image
+ * ddx_gbuffer_fwd wrote (mask [B,H,W,3]: coverage on entry, antialiased silhouette on return; no copy of the frame) and the
+ * backward produces dpos [B,V,4] (fully written) from dmask alone -- coverage has no gradient path, so there is no d colour.
+ * Bit-identical to ddx_antialias_fwd / _bwd called with that coverage image as colour. */
+int ddx_silhouette_fwd(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
+                       float* mask, void* stream);
+int ddx_silhouette_bwd(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
+                       const float* dmask, float* dpos, void* stream);
+
 /* Image-space part of the built-in losses for the op-by-op path (diffdope.py:547-613: l1_rgb_with_mask :547-562,
  * l1_depth_with_mask :565-580, l1_mask :583-613): out[b] = mean_i |(x[b,i] - y[i]) * m[i * m_stride]|, with the observed image y [N]
  * and mask m shared by the B hypotheses (m NULL = no mask; m_stride 3 reads channel 0 of a [H,W,3] mask for a [H,W] depth image).

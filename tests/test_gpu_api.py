@@ -175,7 +175,8 @@ def test_deferred_runs_on_separate_streams_equal_blocking_runs():
         assert set(d.losses_values) == set(lv) and all(torch.equal(d.losses_values[k], lv[k]) for k in lv)
 
 
-def test_masked_l1_mean_matches_the_torch_expression():
+@pytest.mark.parametrize("H,W", [(37, 53), (36, 52)])  # (element counts not divisible / divisible by 4: scalar and 4-wide kernels)
+def test_masked_l1_mean_matches_the_torch_expression(H, W):
     """render.masked_l1_mean (one forward + one backward kernel) against the reference's torch expressions
     (diffdope.py:547-613), values and gradients, incl. batched stride-0 views of the observed image and the
     channel-0 mask of the depth term."""
@@ -186,7 +187,7 @@ def test_masked_l1_mean_matches_the_torch_expression():
     orig = render._masked_l1_func.apply
     monkey = lambda *a: (hits.append(a[3]), orig(*a))[1]
     g = torch.Generator(device="cuda").manual_seed(0)
-    B, H, W = 5, 37, 53
+    B = 5
     seg = (torch.rand(1, H, W, 3, device="cuda", generator=g) > 0.4).float()
     render._masked_l1_func.apply = monkey
     try:

@@ -203,6 +203,23 @@ def test_renderer_ops_forward_backward_vs_oracle():
     dcol, dpos = orc.antialias_bwd(col, ref, pc, tri, go)
     np.testing.assert_allclose(c_t.grad.cpu().numpy(), dcol, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(p_t.grad.cpu().numpy(), dpos, rtol=5e-3, atol=5e-3 * np.abs(dpos).max())
+    # the silhouette ops (antialias of the coverage image, in place, no colour operand): against the oracle's antialias of
+    # interpolate(ones), and against the general op on the same colour
+    from diffdope_amd.render import _silhouette_func, build_topology
+
+    ones = np.ones((1, sc["pos"].shape[0], 3), np.float32)
+    cover = orc.interpolate_fwd(ones, ref, tri)
+    mref = orc.antialias_fwd(cover, ref, pc, tri)
+    assert np.abs(mref - cover).max() > 1e-2
+    p_t = T(pc, requires_grad=True)
+    mask = _silhouette_func.apply(T(cover), rast, p_t, tri_t, build_topology(tri_t))
+    np.testing.assert_allclose(mask.detach().cpu().numpy(), mref, rtol=1e-5, atol=2e-5)
+    mask.backward(T(go))
+    _, dpos = orc.antialias_bwd(cover, ref, pc, tri, go)
+    np.testing.assert_allclose(p_t.grad.cpu().numpy(), dpos, rtol=5e-3, atol=5e-3 * np.abs(dpos).max())
+    p2 = T(pc, requires_grad=True)
+    dd.antialias(T(cover), rast, p2, tri_t).backward(T(go))
+    np.testing.assert_allclose(p_t.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * np.abs(dpos).max())
 
 
 def test_topology_matches_oracle():
