@@ -442,12 +442,52 @@ class Scene:
             t.cuda()
 
 
+class _LossLog(dict):
+    """losses_values of the op-by-op path: {key: [iterations, B] CPU tensor} like the reference's (diffdope.py:1600-1616), but
+    the rows a loss function logs stay on the device until somebody reads the log -- a host copy per loss term and iteration
+    is a synchronisation per term and iteration, and the host could never run ahead of the GPU."""
+
+    def __init__(self):
+        super().__init__()
+        self._pending = {}
+
+    def add(self, key, row):
+        self._pending.setdefault(key, []).append(row)
+
+    def _flush(self):
+        if not self._pending:
+            return
+        pending, self._pending = self._pending, {}
+        for key, rows in pending.items():
+            v = torch.stack(rows, dim=0).cpu()
+            dict.__setitem__(self, key, v if not dict.__contains__(self, key) else torch.cat((dict.__getitem__(self, key), v), dim=0))
+
+    def _reader(name):
+        def f(self, *a, **k):
+            self._flush()
+            return getattr(dict, name)(self, *a, **k)
+        f.__name__ = name
+        return f
+
+    for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "keys", "values", "items", "get", "copy", "pop"):
+        locals()[_n] = _reader(_n)
+    del _n, _reader
+
+
 class _LazyResult(dict):
-    """optimization_results entry: "mtx" is stored; "rgb"/"depth"/"mask" are rendered on first access."""
+    """optimization_results entry: "mtx" is stored (moved to the host on first access); "rgb"/"depth"/"mask" are rendered on
+    first access."""
 
     def __init__(self, mtx, render_fn):
         super().__init__(mtx=mtx)
         self._render_fn = render_fn
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if key == "mtx" and v.is_cuda:
+            v = v.cpu()
+            dict.__setitem__(self, key, v)
+        return v
 
     def __missing__(self, key):
         if key in ("rgb", "depth", "mask"):
@@ -485,7 +525,7 @@ class DiffDope:
         self.gt_tensors = {}
         self._refresh_gt()
         self.set_batchsize(self.batchsize)
-        self.losses_values = {}
+        self.losses_values = _LossLog()
         self.loss_functions = []
         if self.cfg.losses.l1_rgb_with_mask:
             self.loss_functions.append(l1_rgb_with_mask)
@@ -530,8 +570,11 @@ class DiffDope:
         return self.optimization_results[-1]["mtx"][batch_index].numpy()
 
     def add_loss_value(self, key, values, values_weighted=None):
-        v = values.detach().cpu().unsqueeze(0)
-        self.losses_values[key] = v if key not in self.losses_values else torch.cat((self.losses_values[key], v), dim=0)
+        """diffdope.py:1600-1616 (the copy to the host is deferred to the first read of losses_values, see _LossLog)."""
+        if not isinstance(self.losses_values, _LossLog):  # (a caller replaced the log by a plain dict)
+            log_, self.losses_values = self.losses_values, _LossLog()
+            self.losses_values.update(log_)
+        self.losses_values.add(key, values.detach().clone())
 
     # ---- rendering -------------------------------------------------------------------------------
     def _render(self, mtx):
@@ -608,7 +651,7 @@ class DiffDope:
         wait=False (fused path only) enqueues the whole optimisation on the current stream and returns; call
         finish_optimization() to synchronise and fetch the results -- several objects can then run on one stream each
         and fill each other's launch tails (bop.refine_frame)."""
-        self.losses_values = {}
+        self.losses_values = _LossLog()
         self.optimization_results = []
         self._refresh_gt()
         builtin = all(f in _BUILTIN_LOSSES for f in self.loss_functions) and len(self.loss_functions) > 0
@@ -668,7 +711,7 @@ class DiffDope:
             result = self.object3d()
             mtx_gu = matrix_batch_44_from_position_quat(p=result["trans"], q=result["quat"])
             self.renders = self._render(mtx_gu)
-            entry = _LazyResult(mtx_gu.detach().cpu(), self._render_cpu)
+            entry = _LazyResult(mtx_gu.detach(), self._render_cpu)  # (copied to the host when read)
             self.optimization_results.append(entry)
             loss = torch.zeros(1, device=mtx_gu.device)
             for loss_function in self.loss_functions:

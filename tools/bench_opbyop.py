@@ -50,3 +50,30 @@ n = 20
 for _ in range(n): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f'{cfg} ({"fused masked-L1 losses" if FUSED_LOSS else "torch loss expressions"}): op-by-op path {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s  (peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB)')
+
+if '--api' in sys.argv:
+    # the same workload through DiffDope.run_optimization(fused=False): Object3D / Mesh modules, the built-in loss functions
+    # with their per-iteration logs, torch SGD -- what a user loss function forces (api._run_autograd)
+    import numpy as np
+    nb = 40
+    tex_kw = dict(uv=w['uv'].cpu().numpy(), tex=w['tex'].cpu().numpy()) if w['uv'] is not None else dict(vtx_color=w['vtx_color'].cpu().numpy())
+    mesh = dd.Mesh.from_arrays(w['pos'].cpu().numpy(), w['tri'].cpu().numpy(), **tex_kw)
+    p0 = w['params0'][:, 0].cpu().numpy()
+    obj = dd.Object3D(position=list(p0[4:]), rotation=list(p0[:4] / np.linalg.norm(p0[:4])), batchsize=B, opencv2opengl=False, scale=1, mesh=mesh)
+    g = {k: v.cpu() for k, v in w['gt'].items()}
+    scene = dd.Scene(tensor_rgb=dd.Image(img_tensor=g['rgb']), tensor_depth=dd.Image(img_tensor=g['depth']),
+                     tensor_segmentation=dd.Image(img_tensor=g['segmentation']))
+    cam = dd.Camera(fx=1, fy=1, cx=0, cy=0, im_width=W, im_height=H)
+    cam.cam_proj = w['proj'].double().cpu()
+    cfg_d = dict(losses=dict(l1_rgb_with_mask=wt.get('rgb') is not None, weight_rgb=wt.get('rgb') or 1.0,
+                             l1_depth_with_mask=wt.get('depth') is not None, weight_depth=wt.get('depth') or 1.0,
+                             l1_mask=wt.get('mask') is not None, weight_mask=wt.get('mask') or 1.0),
+                 hyperparameters=dict(nb_iterations=nb, batchsize=B, base_lr=1e-3, learning_rates_bound=[0.5, 2.0], learning_rate_base=1,
+                                      lr_decay=0.1, seed=3))
+    d = dd.DiffDope(cfg=cfg_d, camera=cam, object3d=obj, scene=scene)
+    d.run_optimization(fused=False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    d.run_optimization(fused=False)
+    best = int(d.get_argmin())  # (reads the logs: the deferred host copies happen here)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (nb + 1)
+    print(f'{cfg}: DiffDope.run_optimization(fused=False) {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s (arg-min hypothesis {best})')
