@@ -379,7 +379,7 @@ __device__ __forceinline__ void cull_ok_store(const EngineDev& E, int* s_bad, bo
 // (later iterations get theirs from update_xfm_kernel).  Grid (B, vertex slices): the slicing of update_xfm_kernel, so that
 // both leave the same per-slice view-volume flags (cull_ok).  Every lane rebuilds its hypothesis' matrices from the 7
 // parameters (uniform scalar loads, ~150 flops: cheaper than a separate launch + a dependent load).
-__global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
+__global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E, int it0 /* the iteration this run starts at */)
 {
     const int b = blockIdx.x, slice = blockIdx.y, B = E.d.B, V = E.d.V;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -395,8 +395,13 @@ __global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E)
     pose_matrices(q, t, E.b.proj, M, F);
     final_row(pr, M, Fr);
     if (slice == 0 && tid == 0) {
-        const int it = E.st->it;
-        if (b == 0) E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
+        const int it = it0;
+        if (b == 0) {
+            E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
+            // (the iteration counters of the run: a launch of their own cost 2 us plus a host launch gap in front of every run)
+            E.st->it = it0;
+            E.st->it_next = it0;
+        }
         E.L.bigcount[b] = 0;              // the hypothesis' list of large triangles, filled again by scatter_kernel
         float* dst = E.mats + ((size_t)(it & 1) * B + b) * 32;
         float* pp = E.params2 + (size_t)(it & 1) * 7 * B;
@@ -1481,7 +1486,6 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     DDX_TRACE_END(E.trace, 3, 1ull);
 }
 
-__global__ void set_it_kernel(EngineState* st, int it) { st->it = it; st->it_next = it; }
 
 // ---------------------------------------------------------------------------------------------
 enum { K_SCATTER, K_COMPACT_BIG, K_SHADE, K_EDGE, K_UPDATE, K_COUNT };
@@ -1525,8 +1529,7 @@ static int run_prologue(ddx_engine* e, int it0, hipStream_t s)
                                hipMemcpyDeviceToDevice, s));
         e->adam_parity = it0 & 1;
     }
-    set_it_kernel<<<1, 1, 0, s>>>(E.st, it0);
-    pose_xfm_kernel<<<dim3(E.d.B, upd_slices(E.d)), 256, 0, s>>>(E);
+    pose_xfm_kernel<<<dim3(E.d.B, upd_slices(E.d)), 256, 0, s>>>(E, it0);
     DDX_LAUNCH_CHECK();
     return 0;
 }

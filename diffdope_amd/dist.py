@@ -64,17 +64,34 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = loss_rows.shape[1]
-    # (one rank: its row is fully written by the kernel, no zero fill needed)
-    table = (torch.zeros if world > 1 else torch.empty)((world, 18), dtype=torch.float32, device=loss_rows.device)
+    if not dist.is_initialized():
+        # one process: the kernel stores its 18 floats straight into pinned host memory (mapped into the GPU's address space):
+        # no device -> host copy to launch, the stream synchronisation is the only wait
+        table = _pinned_row()
+        _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table.data_ptr(),
+                                       _lib.stream_ptr()), "ddx_select_best")
+        torch.cuda.current_stream().synchronize()
+        t = table.numpy()
+        return int(t[0, 1]), float(t[0, 0]), table[0, 2:].clone().reshape(4, 4)
+    table = torch.zeros((world, 18), dtype=torch.float32, device=loss_rows.device)
     _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table[rank].data_ptr(),
                                    _lib.stream_ptr()), "ddx_select_best")
-    if dist.is_initialized():
-        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     t = table.cpu().numpy()  # the one synchronisation (device -> host copy of world x 18 floats)
     losses, gidx = t[:, 0], t[:, 1]
     cand = [(gidx[r], r) for r in range(world) if losses[r] == losses.min()]  # ties -> lowest global index
     row = min(cand)[1]
-    return int(t[row, 1]), float(t[row, 0]), table[row, 2:].reshape(4, 4)  # (the pose stays on the device: a view of the table)
+    return int(t[row, 1]), float(t[row, 0]), table[row, 2:].reshape(4, 4)  # (the pose: a view of the table)
+
+
+_PINNED = None
+
+
+def _pinned_row():
+    global _PINNED
+    if _PINNED is None:
+        _PINNED = torch.empty((1, 18), dtype=torch.float32, pin_memory=True)
+    return _PINNED
 
 
 def merge_object_tables(table, group=None):
