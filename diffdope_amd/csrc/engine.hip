@@ -1864,7 +1864,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     // ---- which scatter variant: expected covered centres per triangle, from the observed segmentation mask (the hypotheses
     // render the object at about the observed size; front and back faces both produce fragments).  Above about one centre per
     // triangle the fragment-exchange variant wins (cfg2 at half the distance: 42 -> 37 us, at a third: 115 -> 63 us); below it
-    // costs occupancy (cfg3ref: 44 -> 52 us).  DDX_SCATTER_EXCHANGE=0/1 overrides (tuning).
+    // costs occupancy (cfg3ref: 44 -> 52 us).  DDX_SCATTER_EXCHANGE=0/1/2 overrides (tuning).
     {
         EngineState hst;
         DDX_HIP(hipMemcpyAsync(&hst, E.st, sizeof(EngineState), hipMemcpyDeviceToHost, s));
@@ -1894,7 +1894,12 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         DDX_HIP(hipStreamSynchronize(s));  // (host vectors are the copy sources)
         const double per_tri = 2.0 * (hst.c_mask / 3.0) / (double)std::max(E.d.T, 1);
         E.L.scatter_exchange = per_tri > SCATTER_EXCHANGE_PER_TRI ? 1 : 0;
-        if (const char* ov = getenv("DDX_SCATTER_EXCHANGE")) E.L.scatter_exchange = atoi(ov) ? 1 : 0;
+        // micro-polygon regime on a launch of three or more rounds of resident workgroups (cfg3: 12 800 workgroups, cfg50k64: 6 400):
+        // the compacting variant (2) -- survivors of the bbox / area / back-face tests packed into full waves before the coverage
+        // and fragment code: scatter 32.7 -> 31.5 us on cfg3, 33.6 -> 32.0 on cfg3ref, 19.5 -> 19.2 on cfg50k64; on shorter
+        // launches (cfg2, cfg4: 2 560 / 3 776 workgroups, latency-bound) it costs 0.8 us
+        if (!E.L.scatter_exchange && (long long)ddx_cdiv(E.d.T, 512) * E.d.B >= 6000) E.L.scatter_exchange = 2;
+        if (const char* ov = getenv("DDX_SCATTER_EXCHANGE")) { const int v = atoi(ov); E.L.scatter_exchange = v < 0 ? 0 : (v > 2 ? 2 : v); }
     }
     e->setup_done = true;
     return 0;

@@ -31,7 +31,8 @@ struct RasterScratch {
     int cull_sign;
     const int* cull_ok;
     int scatter_exchange;     // 1: expect more than ~1 covered centre per triangle -- scatter_kernel's fragment-exchange variant
-                              // (lane j takes record j; ids in zbuf stay the original ones, so the result does not depend on it)
+                              // (lane j takes record j; ids in zbuf stay the original ones, so the result does not depend on it);
+                              // 2: the compacting variant (long launches in the micro-polygon regime, see scatter_kernel)
     size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount)
     int ntx, nty, NT;
     PixNdc ndc;               // pixel index -> NDC centre constants for (H, W)

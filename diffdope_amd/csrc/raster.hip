@@ -142,7 +142,9 @@ struct ScatterCov { scatter_mask_t mask; int px0, py0, nxp; int clipped; };  // 
 #ifndef SCATTER_DIRECT_MAX
 #define SCATTER_DIRECT_MAX 3  // waves in which no lane owns more fragments than this resolve them lane by lane
 #endif
-template <int WALK>
+// DEFER (the compacting variant of the kernel): a small triangle that is neither degenerate nor culled is only reported
+// (cv.clipped = 2); scatter_small_deferred() resolves it after the wave has packed such triangles into consecutive lanes.
+template <int WALK, bool DEFER = false>
 __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, int V, int H, int W, const RasterScratch& L, int b, int t,
                                                 int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c, ScatterCov& cv, int cull)
 {
@@ -162,6 +164,9 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
             if (small) {
                 // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
                 const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
+                if (DEFER) {
+                    if (area != 0 && !(cull != 0 && (area < 0) == (cull < 0))) cv.clipped = 2;
+                } else
                 if (area != 0 && !(cull != 0 && (area < 0) == (cull < 0))) {  // (non-degenerate and not a culled back face)
                     const bool flip = area < 0;
                     const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
@@ -259,6 +264,61 @@ __device__ __forceinline__ unsigned scatter_one(const float* __restrict__ pos, i
     return range;
 }
 
+// The body of scatter_one for a SMALL, non-degenerate, not culled triangle (see DEFER there): bbox, coverage mask of its
+// <= RASTER_SMALL_PX centres, tile flags, one depth evaluation + atomicMin per covered centre.  Same arithmetic, same results.
+__device__ __forceinline__ void scatter_small_deferred(const float* __restrict__ pos, int V, int H, int W, const RasterScratch& L, int b, int t,
+                                                       int i0, int i1, int i2, const int2& a, const int2& bq, const int2& c)
+{
+    const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
+    const int ymin = min(a.y, min(bq.y, c.y)), ymax = max(a.y, max(bq.y, c.y));
+    int px0 = (xmin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, px1 = (xmax - DDX_SUBPIX / 2) >> 8;
+    int py0 = (ymin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, py1 = (ymax - DDX_SUBPIX / 2) >> 8;
+    px0 = max(px0, 0); py0 = max(py0, 0);
+    px1 = min(px1, W - 1); py1 = min(py1, H - 1);
+    const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
+    const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
+    const bool flip = area < 0;
+    const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
+    const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
+    const Edge32 e1 = make_edge(c.x, c.y, a.x, a.y, X0, Y0, flip);
+    const Edge32 e2 = make_edge(a.x, a.y, bq.x, bq.y, X0, Y0, flip);
+    const int b0 = e0.e00 + (int)e0.own - 1, b1 = e1.e00 + (int)e1.own - 1, b2 = e2.e00 + (int)e2.own - 1;
+    scatter_mask_t mask = 0;
+    {
+        int idx = 0;
+        int r0 = b0, r1 = b1, r2 = b2;
+        for (int j = 0; j < nyp; ++j, r0 += e0.sy, r1 += e1.sy, r2 += e2.sy) {
+            int v0 = r0, v1 = r1, v2 = r2;
+            for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
+                mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
+        }
+    }
+    if (!mask) return;  // covers no centre: draws nothing, no tile to flag
+    {
+        const int tx0 = max(px0 - 1, 0) / DDX_TILE, tx1 = min(px1 + 1, W - 1) / DDX_TILE;
+        const int ty0 = max(py0 - 1, 0) / DDX_TILE, ty1 = min(py1 + 1, H - 1) / DDX_TILE;
+        int* flag = L.tile_flag + (size_t)b * L.NT;
+#pragma clang loop unroll(disable) vectorize(disable)
+        for (int ty = ty0; ty <= ty1; ++ty)
+#pragma clang loop unroll(disable) vectorize(disable)
+            for (int tx = tx0; tx <= tx1; ++tx) flag[__mul24(ty, L.ntx) + tx] = 1;
+    }
+    const float* P = pos + (size_t)b * V * 4;
+    const float4 p0 = ld4(P + (size_t)i0 * 4), p1 = ld4(P + (size_t)i1 * 4), p2 = ld4(P + (size_t)i2 * 4);
+    unsigned long long* Z = L.zbuf + (size_t)b * L.zper;
+    const PixNdc ndc = L.ndc;
+    const float rn = __frcp_rn((float)nxp);
+    while (mask) {
+        const int k = RASTER_SMALL_PX > 32 ? __ffsll((long long)mask) - 1 : __ffs((unsigned)mask) - 1;
+        mask &= mask - 1;
+        const int j = (int)(((float)k + 0.5f) * rn), i = k - __mul24(j, nxp);
+        float zw;
+        const float fx = __fmaf_rn((float)(px0 + i), ndc.xs, ndc.xo), fy = __fmaf_rn((float)(py0 + j), ndc.ys, ndc.yo);
+        if (pixel_depth(p0, p1, p2, fx, fy, zw))
+            atomicMin(Z + zaddr(px0 + i, py0 + j, L.zwb), ((unsigned long long)depth_key(zw) << 32) | (unsigned)t);
+    }
+}
+
 // every lane walks the fragments of its own triangle (clip-space vertices loaded only when it owns a centre)
 __device__ __forceinline__ void scatter_walk(const ScatterCov& cv, const float* __restrict__ P, int i0, int i1, int i2, int t,
                                              unsigned long long* __restrict__ Z, const PixNdc& ndc, int zwb)
@@ -306,7 +366,14 @@ template <int SCATTER_TPL, int SCATTER_NT, int MODE>
 __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
                                                       int T, int H, int W, RasterScratch L)
 {
-    constexpr bool EXCHANGE = MODE != 0;
+    constexpr bool EXCHANGE = MODE == 1 || MODE == 2;
+    constexpr bool COMPACT = MODE == 3;
+    // COMPACT (MODE 3; dense meshes whose launch is several rounds of resident workgroups, where the kernel is VALU-bound): only
+    // ~30 % of the triangles survive the bbox / area / back-face tests, and a wave pays the coverage + fragment code for its
+    // 2 x 64 triangles whenever ONE lane survives.  The survivors of both triangles of the lanes are packed into consecutive
+    // lanes through LDS (32 bytes each: first corner, the other two relative to it in 16 bits -- a small triangle spans < 2^13
+    // sub-pixels --, vertex ids, triangle id) and resolved in ceil(n / 64) passes: one instead of two, with full lanes.
+    __shared__ int4 s_q[COMPACT ? SCATTER_NT / 64 : 1][COMPACT ? 64 * SCATTER_TPL : 1][2];
     // fragment exchange of one wave: exclusive prefix of the lanes' fragment counts, their coverage masks and triangle records
     __shared__ int s_pref[EXCHANGE ? SCATTER_NT / 64 : 1][EXCHANGE ? 64 : 1];
     __shared__ scatter_mask_t s_mask[EXCHANGE ? SCATTER_NT / 64 : 1][EXCHANGE ? 64 : 1];
@@ -367,7 +434,37 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
         if (t[k] >= T || !ok[k]) continue;
         // (plain variant: triangle by triangle -- coverage of both triangles first and all fragments afterwards measured
         // 2 us slower on cfg2: more atomics in flight at once make the atomicMin stream slower)
-        range[k] = scatter_one<MODE == 0 ? 1 : MODE == 2 ? 2 : 0>(pos, V, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k], cull);
+        range[k] = scatter_one<(MODE == 0 || MODE == 3) ? 1 : MODE == 2 ? 2 : 0, COMPACT>(pos, V, H, W, L, b, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k], cull);
+    }
+    if (COMPACT) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        int n_q = 0;
+#pragma unroll
+        for (int k = 0; k < SCATTER_TPL; ++k) {
+            const bool push = cv[k].clipped == 2;
+            if (push) cv[k].clipped = 0;
+            const unsigned long long m = __ballot(push);
+            if (push) {
+                const int slot = n_q + __popcll(m & ((1ull << lane) - 1ull));
+                const unsigned rb = ((unsigned)(vb[k].x - va[k].x) & 0xffffu) | ((unsigned)(vb[k].y - va[k].y) << 16);
+                const unsigned rc = ((unsigned)(vc[k].x - va[k].x) & 0xffffu) | ((unsigned)(vc[k].y - va[k].y) << 16);
+                s_q[wv][slot][0] = make_int4(va[k].x, va[k].y, (int)rb, (int)rc);
+                s_q[wv][slot][1] = make_int4(i0[k], i1[k], i2[k], t[k]);
+            }
+            n_q += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < n_q; base += 64) {  // (wave-uniform)
+            const int idx = base + lane;
+            if (idx < n_q) {
+                const int4 g = s_q[wv][idx][0], h = s_q[wv][idx][1];
+                const int2 qa = make_int2(g.x, g.y);
+                const int2 qb = make_int2(g.x + (int)(short)((unsigned)g.z & 0xffffu), g.y + ((int)g.z >> 16));
+                const int2 qc = make_int2(g.x + (int)(short)((unsigned)g.w & 0xffffu), g.y + ((int)g.w >> 16));
+                scatter_small_deferred(pos, V, H, W, L, b, h.w, h.x, h.y, h.z, qa, qb, qc);
+            }
+        }
     }
     SPH(3);
     // ---- fragments.  A lane owns 0..64 covered centres of its triangle, most lanes none: walked lane by lane the wave runs
@@ -751,7 +848,8 @@ int raster_run(const float* pos, const int* tri, int B, int V, int T, int H, int
     if ((long long)ddx_cdiv(T, 512) * B >= 1024) {
         // dense meshes: the plain kernel in the micro-polygon regime (64 VGPRs, no LDS); the hybrid (72 VGPRs, 19 KB LDS: 4-20 %
         // slower there) when the caller expects triangles to own more than about one pixel centre each
-        if (L.scatter_exchange) scatter_kernel<TPLD, 256, 2><<<dim3(ddx_cdiv(T, 256 * TPLD), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+        if (L.scatter_exchange == 2) scatter_kernel<TPLD, 256, 3><<<dim3(ddx_cdiv(T, 256 * TPLD), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
+        else if (L.scatter_exchange) scatter_kernel<TPLD, 256, 2><<<dim3(ddx_cdiv(T, 256 * TPLD), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
         else scatter_kernel<TPLD, 256, 0><<<dim3(ddx_cdiv(T, 256 * TPLD), B), 256, 0, s>>>(pos, tri, V, T, H, W, L);
     }
     else scatter_kernel<1, 64, 1><<<dim3(ddx_cdiv(T, 64), B), 64, 0, s>>>(pos, tri, V, T, H, W, L);

@@ -361,8 +361,8 @@ def test_engine_result_does_not_depend_on_the_order_of_the_mesh_file():
 
 def test_engine_close_up_dense_mesh_scatter_variants_agree(monkeypatch):
     """A dense mesh seen from close (about two covered pixel centres per triangle): the engine picks the fragment-exchange
-    variant of scatter_kernel from the observed segmentation mask.  Forced on, forced off and chosen automatically the
-    optimisation is bit-identical (visibility is an order-independent atomicMin of exact keys), and iteration 0 of one
+    variant of scatter_kernel from the observed segmentation mask.  Forced on, forced off, with the compacting variant and
+    chosen automatically the optimisation is bit-identical (visibility is an order-independent atomicMin of exact keys), and iteration 0 of one
     hypothesis matches the oracle."""
     weights = dict(rgb=0.7, depth=1.0, mask=1.0)
     sc = make_scene(80, 128, 480, 640, B=32, dist=3.0, textured=True, tex_size=256)
@@ -370,7 +370,7 @@ def test_engine_close_up_dense_mesh_scatter_variants_agree(monkeypatch):
     assert per_tri > 1.5
     lrs = [0.2, 0.15, 0.1]
     runs = {}
-    for mode in ("0", "1", None):
+    for mode in ("0", "1", "2", None):  # (2: the compacting variant, normally picked for long launches in the micro-polygon regime)
         if mode is None:
             monkeypatch.delenv("DDX_SCATTER_EXCHANGE", raising=False)
         else:
@@ -380,7 +380,7 @@ def test_engine_close_up_dense_mesh_scatter_variants_agree(monkeypatch):
         eng.finish()
         eng.check()
         runs[mode] = (eng.losses().cpu().numpy().copy(), p.cpu().numpy().copy())
-    for mode in ("1", None):
+    for mode in ("1", "2", None):
         assert np.array_equal(runs["0"][0], runs[mode][0]) and np.array_equal(runs["0"][1], runs[mode][1])
     R = sc["oracle"]
     R.weights = {k: weights.get(k) for k in ("rgb", "depth", "mask", "edge")}
