@@ -551,6 +551,14 @@ __global__ __launch_bounds__(SCATTER_NT) void scatter_kernel(const float* __rest
     DDX_TRACE_END(L.trace, 0, 1ull);
 }
 
+// clip_near as a real call: inlined into the candidate loop of the tile pass its code (used by the rare near-plane straddlers
+// only) sat in the middle of the loop body every large tile walks, and the large-triangle workloads paid for it in instruction
+// fetch (hugetri's tile pass 24.7 -> 32.2 us).
+__device__ __attribute__((noinline)) int clip_near_call(const float4& p0, const float4& p1, const float4& p2, int H, int W, SnapTri out[2])
+{
+    return clip_near(p0, p1, p2, H, W, out);
+}
+
 // One launch, two roles.
 //   workgroups [0, B): compaction -- workgroup b turns hypothesis b's tile flags into its ordered active-tile
 //     segment + count (ballot ranks, no atomics).
@@ -707,7 +715,9 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
                 i0 = tri[t_id * 3 + 0]; i1 = tri[t_id * 3 + 1]; i2 = tri[t_id * 3 + 2];
                 if (ent_id >> 31) {
                     cp0 = ld4(P + (size_t)i0 * 4); cp1 = ld4(P + (size_t)i1 * 4); cp2 = ld4(P + (size_t)i2 * 4);
-                    nst = clip_near(cp0, cp1, cp2, H, W, stv);
+                    SnapTri clipped[2];  // (lives in scratch: its address goes to a real call; only this rare path touches it)
+                    nst = clip_near_call(cp0, cp1, cp2, H, W, clipped);
+                    stv[0] = clipped[0]; stv[1] = clipped[1];
                 } else {
                     const int2 sa = S[i0], sb = S[i1], sc = S[i2];
                     snap_from_vertices(sa, sb, sc, stv[0]);
