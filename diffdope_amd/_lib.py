@@ -74,6 +74,7 @@ _SIGNATURES = {
     "ddx_adam_step": (_I, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "ddx_engine_status_ptr": (_P, [_P]),
     "ddx_engine_cull_sign": (_I, [_P]),
+    "ddx_engine_new_observation": (_I, [_P]),
     "ddx_engine_profile": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I, _P]),
     "ddx_engine_destroy": (None, [_P]),
 }

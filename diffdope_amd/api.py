@@ -682,8 +682,23 @@ class DiffDope:
         params = self.object3d.params_tensor()
         gt = {k: v[0] for k, v in self.gt_tensors.items()}
         tex = dict(uv=r["uv"][0], tex=r["tex"][0]) if self.object3d.mesh.has_textured_map else dict(vtx_color=r["vtx_color"][0])
-        eng = RefineEngine(r["pos"][0], r["pos_idx"][0], self.camera.cam_proj[0], self.resolution, gt, params, self.learning_rates,
-                           self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, **tex)
+        # the engine of the previous run is kept while everything but the observation and the initial poses is the same (the
+        # same object in the next frame, or a second run on the same frame): the mesh half of its set-up -- sorted copies,
+        # triangle / texel records, closedness analysis, ~half of a 100-iteration call -- is then not repeated
+        from .render import _buffer_key
+
+        mesh_t = [r["pos"], r["pos_idx"], self.camera.cam_proj] + list(tex.values())
+        sig = (tuple(_buffer_key(t) for t in mesh_t), tuple(self.resolution), self.batchsize, tuple(sorted(weights.items())), optimizer,
+               global_batch, len(self.lr_schedule()), {k: tuple(v.shape) for k, v in gt.items()}.__repr__())
+        cached = getattr(self, "_engine_cache", None)
+        if cached is not None and cached[0] == sig and getattr(self, "_pending", None) is None:
+            eng = cached[1]
+            eng.new_observation(gt=gt, params=params, lr_mult=self.learning_rates, lr_sched=self.lr_schedule())
+            params = eng.params
+        else:
+            eng = RefineEngine(r["pos"][0], r["pos_idx"][0], self.camera.cam_proj[0], self.resolution, gt, params, self.learning_rates,
+                               self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, **tex)
+            self._engine_cache = (sig, eng, mesh_t)  # (mesh_t: keeps the keyed buffers alive, see render._buffer_key)
         eng.run()
         self._pending = (eng, params, weights, torch.cuda.current_stream())
 

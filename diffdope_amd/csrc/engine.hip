@@ -128,6 +128,7 @@ struct ddx_engine {
     hipGraphExec_t exec = nullptr;
     int graph_chunk = 1;  // iterations per captured graph
     bool setup_done = false;
+    bool mesh_done = false;  // the mesh half of the setup (sorted copies, triangle / texel records, closedness) survives ddx_engine_new_observation
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
@@ -1710,14 +1711,15 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
     setup_kernel<<<1, 1024, 0, s>>>(E);
     if (E.d.use_edge) edge_setup_kernel<<<1, 1024, 0, s>>>(E);
-    if (E.texq && E.b.tex) build_texq_kernel<<<ddx_cdiv((long long)E.d.Th * E.d.Tw, 256), 256, 0, s>>>(E);
+    if (!e->mesh_done && E.texq && E.b.tex) build_texq_kernel<<<ddx_cdiv((long long)E.d.Th * E.d.Tw, 256), 256, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
+    DDX_HIP(hipMemsetD32Async((hipDeviceptr_t)E.cull_ok, 1, (size_t)E.d.B * 8, s));
     // ---- internal sorted mesh (host, once per engine).  (1) Vertices renumbered in Morton order of their object-space
     // position: the vertex data of neighbouring triangles and pixels become neighbours in memory whatever order the mesh
     // file had.  (2) Processing order of the rasteriser: triangles sorted by the Morton code of their centroid -- the 64-bit
     // atomicMin stream is bound by distinct zbuf lines per instruction; in file order the 128 triangles of a wave may be a
     // long thin strip (or anything), in Morton order they are a compact patch.  Triangle ids are not renumbered.
-    {
+    if (!e->mesh_done) {
         const int V = E.d.V, T = E.d.T;
         std::vector<float> hpos((size_t)V * 3);
         std::vector<int> htri((size_t)T * 3);
@@ -1787,7 +1789,6 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         // in any pinhole projection); and counter-clockwise is outward when the signed volume is positive.
         E.L.cull_sign = 0;
         E.L.cull_ok = E.cull_ok;
-        DDX_HIP(hipMemsetD32Async((hipDeviceptr_t)E.cull_ok, 1, (size_t)E.d.B * 8, s));
         bool want = !E.d.no_backface_cull;
         if (const char* ov = getenv("DDX_NO_CULL")) want = want && !atoi(ov);
         if (want) {
@@ -1860,6 +1861,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             if (closed && pinhole && vol6 != 0.0 && detA != 0.0 && std::isfinite(vol6) && std::isfinite(detA))
                 E.L.cull_sign = ((vol6 > 0.0) == (detA > 0.0)) ? 1 : -1;
         }
+        e->mesh_done = true;
     }
     // ---- which scatter variant: expected covered centres per triangle, from the observed segmentation mask (the hypotheses
     // render the object at about the observed size; front and back faces both produce fragments).  Above about one centre per
@@ -2086,6 +2088,15 @@ extern "C" int ddx_adam_step(float* params, const float* grad, float* exp_avg, f
 }
 
 extern "C" const int32_t* ddx_engine_status_ptr(ddx_engine* e) { return e ? &e->dev.st->overflow : nullptr; }
+
+extern "C" int ddx_engine_new_observation(ddx_engine* e)
+{
+    DDX_REQUIRE(e, DDX_E_NULL, "engine_new_observation: NULL engine");
+    e->setup_done = false;  // the next run / eval redoes the observation half of the setup (frame constants, seg list, optimiser state)
+    e->adam_parity = 0;
+    e->fwd_cached_it = -1;
+    return 0;
+}
 
 extern "C" int ddx_engine_cull_sign(ddx_engine* e) { return (e && e->setup_done) ? e->dev.L.cull_sign : 0; }
 

@@ -118,6 +118,31 @@ class RefineEngine:
         _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
         self.it += n
 
+    def new_observation(self, gt=None, params=None, lr_mult=None, lr_sched=None):
+        """The same object in a new frame (ddx_engine_new_observation): copies the given observed images (dict with the keys
+        of the constructor's `gt`), initial parameters [7,B], multipliers and / or schedule (same length) into the engine's
+        buffers and restarts at iteration 0 with a fresh optimiser state.  The mesh half of the set-up (sorted copies, triangle
+        and texel records, closedness analysis) is kept; mesh, texture, projection, resolution, batch size and loss set must be
+        unchanged.  `params` is copied INTO the tensor the engine was built on (self.params), which keeps receiving the result."""
+        def put(dst, src, what):
+            if src is None:
+                return
+            if dst is None or tuple(dst.shape) != tuple(src.shape):
+                raise ValueError(f"new_observation: {what} must keep its shape {None if dst is None else tuple(dst.shape)}")
+            dst.copy_(src.to(device=dst.device, dtype=dst.dtype))
+        if gt is not None:
+            put(self.gt_seg, gt.get("segmentation"), "segmentation")
+            if self.gt_rgb is not None:
+                put(self.gt_rgb, gt.get("rgb"), "rgb")
+            if self.gt_depth is not None:
+                put(self.gt_depth, gt.get("depth"), "depth")
+        put(self.params, params, "params")
+        put(self.lr_mult, lr_mult, "lr_mult")
+        if lr_sched is not None:
+            put(self.lr_sched, torch.as_tensor(lr_sched, dtype=torch.float64).to(torch.float32), "lr_sched")
+        _lib.check(self.lib.ddx_engine_new_observation(self.handle), "ddx_engine_new_observation")
+        self.it = 0
+
     def finish(self):
         """Wait until everything run() enqueued on the current stream has executed (run() itself is asynchronous)."""
         torch.cuda.current_stream().synchronize()

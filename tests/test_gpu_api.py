@@ -61,6 +61,52 @@ def test_fused_and_autograd_paths_agree_and_results_api():
         assert os.path.getsize(out) > 1000
 
 
+def test_engine_is_reused_across_runs_and_frames():
+    """A second run_optimization on the same DiffDope -- same frame, or a new observation of the same object -- keeps the fused
+    engine (mesh half of its set-up is not repeated: RefineEngine.new_observation / ddx_engine_new_observation) and gives
+    bit for bit what a fresh DiffDope gives; changing the loss set builds a new engine."""
+    import diffdope_amd as dd
+
+    sc_a = make_scene(16, 20, 60, 80, B=1, dist=1.8)
+    sc_b = make_scene(16, 20, 60, 80, B=1, dist=2.1)  # same mesh and texture, another observation (and initial pose)
+    B = 4
+    scene_of = lambda sc: dd.Scene(tensor_rgb=dd.Image(img_tensor=torch.tensor(sc["gt"]["rgb"])), tensor_depth=dd.Image(img_tensor=torch.tensor(sc["gt"]["depth"])),
+                                   tensor_segmentation=dd.Image(img_tensor=torch.tensor(sc["gt"]["segmentation"])))
+
+    def result(d):
+        return d.object3d.params_tensor().cpu().clone(), {k: v.clone() for k, v in d.losses_values.items()}, d.get_pose().copy()
+
+    def same(x, y):
+        return torch.equal(x[0], y[0]) and set(x[1]) == set(y[1]) and all(torch.equal(x[1][k], y[1][k]) for k in x[1]) and np.array_equal(x[2], y[2])
+
+    d = _ddope(sc_a, ("rgb", "depth", "mask"), B)
+    d.run_optimization(fused=True)
+    first = result(d)
+    eng = d.last_engine
+    d.object3d.reset_pose()
+    d.run_optimization(fused=True)  # the same frame again
+    assert d.last_engine is eng and same(result(d), first)
+    # the next frame of the same object
+    d.scene = scene_of(sc_b)
+    d.scene.cuda()
+    d.scene.set_batchsize(B)
+    d.object3d.reset_pose()
+    d.run_optimization(fused=True)
+    assert d.last_engine is eng
+    fresh = _ddope(sc_a, ("rgb", "depth", "mask"), B)
+    fresh.scene = scene_of(sc_b)
+    fresh.scene.cuda()
+    fresh.scene.set_batchsize(B)
+    fresh.run_optimization(fused=True)
+    assert fresh.last_engine is not eng and same(result(d), result(fresh))
+    assert not same(result(d), first)
+    # another loss set: not the same engine
+    d.loss_functions = d.loss_functions[:2]
+    d.object3d.reset_pose()
+    d.run_optimization(fused=True)
+    assert d.last_engine is not eng and set(d.losses_values) == {"rgb", "depth"}
+
+
 def test_edge_extension_fused_and_autograd_paths_agree():
     """cfg.losses.l1_edge (this build's extension): the fused engine's edge role and the torch conv2d loss of the
     op-by-op path optimise alike."""

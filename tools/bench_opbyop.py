@@ -71,6 +71,14 @@ if '--api' in sys.argv:
                  hyperparameters=dict(nb_iterations=nb, batchsize=B, base_lr=1e-3, learning_rates_bound=[0.5, 2.0], learning_rate_base=1,
                                       lr_decay=0.1, seed=3))
     d = dd.DiffDope(cfg=cfg_d, camera=cam, object3d=obj, scene=scene)
+    if '--fused' in sys.argv:  # the default path of the same object: whole calls incl. engine construction and result collection
+        d.cfg.hyperparameters.nb_iterations = 100
+        for _ in range(2): d.run_optimization(fused=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): d.run_optimization(fused=True)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        print(f'{cfg}: DiffDope.run_optimization(fused=True), 100 iterations: {dt*1e3:.2f} ms per call')
+        sys.exit(0)
     d.run_optimization(fused=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     d.run_optimization(fused=False)
