@@ -2093,6 +2093,10 @@ extern "C" int ddx_engine_new_observation(ddx_engine* e)
 {
     DDX_REQUIRE(e, DDX_E_NULL, "engine_new_observation: NULL engine");
     e->setup_done = false;  // the next run / eval redoes the observation half of the setup (frame constants, seg list, optimiser state)
+    // a captured graph holds the kernels' by-value arguments of the OLD observation (size of the segmentation list, scatter
+    // variant): it is captured again by the next run that asks for one
+    if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     e->adam_parity = 0;
     e->fwd_cached_it = -1;
     return 0;

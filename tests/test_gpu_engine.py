@@ -320,6 +320,33 @@ def test_engine_eval_pass_gradient_against_oracle_and_torch_optimizer(weights):
     assert float(val.detach()) < 0.7 * first
 
 
+@pytest.mark.parametrize("use_graph", [False, 2])
+def test_engine_new_observation_equals_a_fresh_engine(use_graph):
+    """RefineEngine.new_observation (ddx_engine_new_observation): the same mesh against another observed frame, other initial
+    poses and another schedule -- the engine that already ran on the first frame gives bit for bit what a fresh engine gives
+    (also when it replays captured graphs: they are captured again for the new frame)."""
+    w = dict(rgb=0.7, depth=1.0, mask=1.0)
+    sc_a = make_scene(16, 20, 60, 80, B=3, dist=1.8)
+    sc_b = make_scene(16, 20, 60, 80, B=3, dist=2.3, rot_deg=5.0)
+    lrs_a, lrs_b = [0.2, 0.15, 0.1, 0.05], [0.3, 0.2, 0.1, 0.02]
+    eng, p = _engine(sc_a, w, lrs_a)
+    eng.run(use_graph=use_graph)
+    eng.finish()
+    eng.new_observation(gt={k: T(v) for k, v in sc_b["gt"].items()}, params=T(sc_b["params"]), lr_mult=T(sc_b["lr_mult"]), lr_sched=lrs_b)
+    eng.run(use_graph=use_graph)
+    eng.finish()
+    fresh, pf = _engine(sc_b, w, lrs_b)
+    fresh.run(use_graph=use_graph)
+    fresh.finish()
+    assert torch.equal(p, pf) and torch.equal(eng.losses(), fresh.losses()) and torch.equal(eng.mtx_log, fresh.mtx_log)
+    first, _ = _engine(sc_a, w, lrs_a)
+    first.run()
+    first.finish()
+    assert not torch.equal(first.losses(), fresh.losses())
+    with pytest.raises(ValueError):
+        eng.new_observation(gt=dict(segmentation=torch.zeros(10, 10, 3)))
+
+
 def test_device_side_selection_matches_torch_argmin():
     """ddx_select_best / dist.global_argmin_fused == dist.global_argmin(loss_rows[used].mean(0), ...), ties -> lowest index."""
     from diffdope_amd import dist as ddist
