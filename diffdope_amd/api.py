@@ -689,7 +689,7 @@ class DiffDope:
 
         mesh_t = [r["pos"], r["pos_idx"], self.camera.cam_proj] + list(tex.values())
         sig = (tuple(_buffer_key(t) for t in mesh_t), tuple(self.resolution), self.batchsize, tuple(sorted(weights.items())), optimizer,
-               global_batch, len(self.lr_schedule()), {k: tuple(v.shape) for k, v in gt.items()}.__repr__())
+               global_batch, len(self.lr_schedule()), tuple(sorted((k, tuple(v.shape)) for k, v in gt.items())))
         cached = getattr(self, "_engine_cache", None)
         if cached is not None and cached[0] == sig and getattr(self, "_pending", None) is None:
             eng = cached[1]
