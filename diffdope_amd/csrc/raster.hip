@@ -749,12 +749,14 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
                         hit = hit && any_in;
                         // tile-local form of the same exact edge function for the pixel loop: value at the tile's first
                         // pixel centre (int64) with the ownership rule folded in (e + own - 1 >= 0), and the 32-bit
-                        // steps per pixel in x and y
+                        // steps per sub-pixel in x and y
                         int dx = st.X[kb] - st.X[ka], dy = st.Y[kb] - st.Y[ka];
                         long long ev = (long long)dx * (long long)(cy0 - st.Y[ka]) - (long long)dy * (long long)(cx0 - st.X[ka]);
                         if (flip) { ev = -ev; dx = -dx; dy = -dy; }
                         ev += ((dy > 0) || (dy == 0 && dx < 0)) ? 0 : -1;
-                        es[k] = make_int4((int)(unsigned)(ev & 0xffffffffll), (int)(ev >> 32), -dy * DDX_SUBPIX, dx * DDX_SUBPIX);
+                        // (steps kept per SUB-pixel: a corner clamped to the 2^24 guard band makes |dx|, |dy| reach 2^25, and the
+                        // per-pixel step dx * 256 would leave 32 bits -- a triangle with a vertex just in front of the eye plane)
+                        es[k] = make_int4((int)(unsigned)(ev & 0xffffffffll), (int)(ev >> 32), -dy, dx);
                     }
                 }
             }
@@ -776,13 +778,14 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
             if (px < W) {
                 for (int j = 0; j < nh; ++j) {
                     const int4 q0 = s_e0[wave][j], q1 = s_e1[wave][j], q2 = s_e2[wave][j];
-                    const long long c0 = (((long long)q0.y << 32) | (unsigned)q0.x) + (long long)lx * q0.z;
-                    const long long c1 = (((long long)q1.y << 32) | (unsigned)q1.x) + (long long)lx * q1.z;
-                    const long long c2 = (((long long)q2.y << 32) | (unsigned)q2.x) + (long long)lx * q2.z;
+                    const long long c0 = (((long long)q0.y << 32) | (unsigned)q0.x) + (long long)(lx * DDX_SUBPIX) * q0.z;
+                    const long long c1 = (((long long)q1.y << 32) | (unsigned)q1.x) + (long long)(lx * DDX_SUBPIX) * q1.z;
+                    const long long c2 = (((long long)q2.y << 32) | (unsigned)q2.x) + (long long)(lx * DDX_SUBPIX) * q2.z;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int ly = ly0 + 4 * q, py = tcy * DDX_TILE + ly;
-                        const long long v0 = c0 + (long long)ly * q0.w, v1 = c1 + (long long)ly * q1.w, v2 = c2 + (long long)ly * q2.w;
+                        const long long v0 = c0 + (long long)(ly * DDX_SUBPIX) * q0.w, v1 = c1 + (long long)(ly * DDX_SUBPIX) * q1.w,
+                                        v2 = c2 + (long long)(ly * DDX_SUBPIX) * q2.w;
                         if ((v0 | v1 | v2) < 0 || py >= H) continue;
                         const unsigned long long key = frag_key(s_p0[wave][j], s_p1[wave][j], s_p2[wave][j], px, py, H, W, s_t[wave][j]);
                         best[q] = key < best[q] ? key : best[q];

@@ -319,3 +319,31 @@ def test_near_plane_clipping_matches_oracle():
     assert (ref[..., 3] > 0).mean() > 0.2
     rast, _ = dd.rasterize(dd.RasterizeGLContext(), T(clip), T(tri2), [H, W])
     _check_rast(rast.cpu().numpy(), ref)
+    # vertices just in FRONT of the eye plane (0 < w << 1, behind the near plane): they project thousands of pixels away and
+    # are snapped onto the 2^24 sub-pixel guard band, so edge steps reach 2^25 sub-pixels (a randomised sweep,
+    # tools/fuzz_parity.py, found the tile pass keeping them per pixel in 32 bits).  Two triangles of that sweep, then soups.
+    H, W = 119, 164
+    P = np.array([[[0.155741, 0.070639, -0.0197, 0.000301], [-0.035678, 0.085586, 0.096324, 0.116313], [0.077421, -0.045683, -0.014131, 0.00587],
+                   [-0.01334, 0.277606, 0.13426, 0.154246], [-0.294005, -0.123691, 0.299812, 0.319781], [-0.315817, -0.205851, 0.29457, 0.31454],
+                   [-0.291243, 0.150862, -0.019581, 0.00042]]], np.float32)
+    tri3 = np.array([[0, 1, 2], [3, 1, 0], [4, 5, 6]], np.int32)
+    ref = orc.rasterize_fwd(P, tri3, H, W)
+    assert (ref[..., 3] > 0).sum() > 100
+    rast, _ = dd.rasterize(dd.RasterizeGLContext(), T(P), T(tri3), [H, W])
+    _check_rast(rast.cpu().numpy(), ref)
+    drawn = 0
+    for seed in range(6):
+        rng = np.random.RandomState(100 + seed)
+        n = 40
+        Pn = np.concatenate([rng.uniform(-0.4, 0.4, (n * 3, 2)), rng.uniform(-0.02, 0.3, (n * 3, 1)), np.zeros((n * 3, 1))], 1)
+        Pn[:, 3] = Pn[:, 2] + 0.02  # (z + w = 2 z + 0.02: vertices with z < -0.01 are behind the near plane)
+        tiny = rng.rand(n * 3) < 0.35
+        Pn[tiny, 3] = 10.0 ** rng.uniform(-4.5, -2.5, tiny.sum())  # just in front of the eye plane ...
+        Pn[tiny, 2] = -rng.uniform(0.005, 0.03, tiny.sum())         # ... and behind the near plane
+        Pn = Pn.astype(np.float32)[None]
+        trin = np.arange(n * 3, dtype=np.int32).reshape(n, 3)
+        ref = orc.rasterize_fwd(Pn, trin, H, W)
+        drawn += int((ref[..., 3] > 0).sum())
+        rast, _ = dd.rasterize(dd.RasterizeGLContext(), T(Pn), T(trin), [H, W])
+        _check_rast(rast.cpu().numpy(), ref)
+    assert drawn > 5000
