@@ -27,3 +27,14 @@ def test_randomised_parity_sweep_fixed_slice():
             os.environ["DDX_SCATTER_EXCHANGE"] = old
     assert bad == 0, stats
     assert stats["outside"] > 20 and stats["big"] > 60 and stats["materialising"] > 20 and stats["trajectories"] > 40
+
+
+def test_randomised_triangle_soups_fixed_slice():
+    """300 random clip-space soups (sub-pixel to far beyond the frame, w from 1e-5 to 10 and negative, near / far violations,
+    shared and degenerate triangles): op-level ids, u, v, z/w, rasterize backward, antialias and interpolate forward / backward."""
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad, stats = fuzz.sweep_soups(300, 4242, verbose=True)
+    assert bad == 0, stats
+    assert stats["drawn"] > 1_000_000 and stats["straddlers"] > 1000 and stats["near_eye"] > 1000

@@ -117,5 +117,104 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
     return bad, stats
 
 
+def sweep_soups(n_cases=200, seed0=0, verbose=True):
+    """Random triangle soups in clip space through the op-level rasteriser (ids bit for bit, u / v / z-w to 2e-6) and its
+    backward, antialias with random colours and interpolate forward / backward against the oracle: sizes from sub-pixel to far
+    beyond the frame, w from 1e-5 to 10 and negative, z inside / outside [-w, w], shared and degenerate triangles."""
+    bad = 0
+    stats = dict(drawn=0, straddlers=0, near_eye=0, max_uvz=0.0)
+    t_start = time.time()
+    for case in range(n_cases):
+        rng = np.random.RandomState(seed0 + case)
+        H, W = int(rng.randint(1, 200)), int(rng.randint(1, 260))
+        n_tri = int(rng.randint(1, 400))
+        B = int(rng.randint(1, 4))
+        nv = n_tri * 3
+        cx, cy = rng.uniform(-0.5 * W, 1.5 * W, n_tri), rng.uniform(-0.5 * H, 1.5 * H, n_tri)
+        size = np.exp(rng.uniform(np.log(0.2), np.log(4.0 * max(H, W, 8)), n_tri))
+        ang = rng.uniform(0, 2 * np.pi, (n_tri, 3))
+        rad = size[:, None] * rng.uniform(0.1, 1.0, (n_tri, 3))
+        px, py = cx[:, None] + rad * np.cos(ang), cy[:, None] + rad * np.sin(ang)
+        snap = rng.rand(n_tri) < 0.15
+        px[snap] = np.round(px[snap] * 2) / 2
+        py[snap] = np.round(py[snap] * 2) / 2
+        z = np.round(rng.uniform(-0.9, 0.9, (n_tri, 1)) * 8) / 8 + rng.uniform(-0.05, 0.05, (n_tri, 3)) * (rng.rand(n_tri, 1) < 0.7)
+        w = np.exp(rng.uniform(np.log(0.3), np.log(10.0), (n_tri, 3)))
+        pos = np.zeros((B, nv, 4), np.float32)
+        for b in range(B):
+            sh = 0.37 * b
+            ww = w.reshape(-1).copy()
+            pos[b, :, 0], pos[b, :, 1] = ((px + sh) / W * 2 - 1).reshape(-1) * ww, ((py - sh) / H * 2 - 1).reshape(-1) * ww
+            pos[b, :, 2], pos[b, :, 3] = z.reshape(-1) * ww, ww
+        behind = rng.rand(nv) < 0.04
+        pos[:, behind, 3] *= -1.0
+        far = rng.rand(nv) < 0.03
+        pos[:, far, 2] = 1.7 * pos[:, far, 3]
+        eye = rng.rand(nv) < 0.04  # just in front of the eye plane, behind the near plane: projects far outside the guard band
+        pos[:, eye, 3] = (10.0 ** rng.uniform(-5, -2, eye.sum())).astype(np.float32)
+        pos[:, eye, 2] = -np.abs(pos[:, eye, 2]) - 0.01
+        tri = np.arange(nv, dtype=np.int32).reshape(n_tri, 3)
+        share = rng.rand(n_tri) < 0.3
+        tri[share, 0] = tri[rng.randint(0, n_tri, share.sum()), 1]
+        dup = rng.rand(n_tri) < 0.05
+        tri[dup] = tri[rng.randint(0, n_tri, dup.sum())]
+        deg = rng.rand(n_tri) < 0.03
+        tri[deg, 2] = tri[deg, 1]
+        tag = f"soup {case} seed {seed0 + case}: {n_tri} triangles, frame {H}x{W}, B {B}"
+        try:
+            ref = orc.rasterize_fwd(pos, tri, H, W)
+            pos_t = T(pos, requires_grad=True)
+            tri_t = T(tri)
+            rast, _ = dd.rasterize(dd.RasterizeGLContext(), pos_t, tri_t, [H, W])
+            got = rast.detach().cpu().numpy()
+            ids_ok = np.array_equal(got[..., 3], ref[..., 3])
+            uvz = float(np.abs(got[..., :3] - ref[..., :3]).max())
+            ok = ids_ok and uvz < 3e-6
+            stats["max_uvz"] = max(stats["max_uvz"], uvz)
+            stats["drawn"] += int((ref[..., 3] > 0).sum())
+            wt = pos[0, tri.reshape(-1), 3].reshape(-1, 3)
+            stats["straddlers"] += int(((wt <= 0).any(1) & (wt > 0).any(1)).sum())
+            stats["near_eye"] += int(eye.sum())
+            if ok and case % 2 == 0:
+                # backward of rasterize, and antialias / interpolate on this visibility
+                g = rng.normal(size=ref.shape).astype(np.float32)
+                rast.backward(T(g))
+                dref = orc.rasterize_bwd(pos, tri, ref, g)
+                ok &= bool(np.abs(pos_t.grad.cpu().numpy() - dref).max() <= 5e-3 * max(np.abs(dref).max(), 1e-6))
+                rd = rast.detach()
+                col = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+                c_t, p_t = T(col, requires_grad=True), T(pos, requires_grad=True)
+                out = dd.antialias(c_t, rd, p_t, tri_t)
+                oref = orc.antialias_fwd(col, ref, pos, tri)
+                ok &= bool(np.abs(out.detach().cpu().numpy() - oref).max() < 5e-5)
+                go = rng.normal(size=oref.shape).astype(np.float32)
+                out.backward(T(go))
+                dcol, dpos = orc.antialias_bwd(col, ref, pos, tri, go)
+                ok &= bool(np.abs(c_t.grad.cpu().numpy() - dcol).max() < 2e-4)
+                ok &= bool(np.abs(p_t.grad.cpu().numpy() - dpos).max() <= 1e-2 * max(np.abs(dpos).max(), 1e-6))
+                attr = rng.normal(size=(B, nv, 3)).astype(np.float32)
+                a_t, r_t = T(attr, requires_grad=True), rd.clone().requires_grad_(True)
+                io, _ = dd.interpolate(a_t, r_t, tri_t)
+                iref = orc.interpolate_fwd(attr, ref, tri)
+                ok &= bool(np.abs(io.detach().cpu().numpy() - iref).max() < 2e-5)
+                gi = rng.normal(size=iref.shape).astype(np.float32)
+                io.backward(T(gi))
+                dattr, drast = orc.interpolate_bwd(attr, ref, tri, gi, True)
+                ok &= bool(np.abs(r_t.grad.cpu().numpy() - drast).max() < 2e-4 * max(1.0, np.abs(drast).max()))
+                ok &= bool(np.abs(a_t.grad.cpu().numpy() - dattr).max() < 2e-3 * max(1.0, np.abs(dattr).max()))
+            if not ok:
+                bad += 1
+                print("MISMATCH", tag, "ids", ids_ok, "uvz", uvz, "pixels with other id", int((got[..., 3] != ref[..., 3]).sum()))
+        except Exception as e:
+            bad += 1
+            print("ERROR", tag, repr(e))
+    if verbose:
+        print(f"{n_cases} soups, {bad} bad, {time.time() - t_start:.0f} s", stats)
+    return bad, stats
+
+
 if __name__ == "__main__":
+    if os.environ.get("FUZZ_SOUPS"):
+        sweep_soups(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        sys.exit(0)
     sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
