@@ -38,11 +38,18 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
             if rng.rand() < float(os.environ.get('FUZZ_NEAR', '0.25')):  # push one hypothesis towards / through the camera plane
                 sc["params"][6, 0] = -float(rng.uniform(0.05, 0.6))
             R = sc["oracle"]
+            if textured and rng.rand() < 0.5:  # any texture size: non-square, not a power of two, down to 1 x 1
+                sc["tex"] = rng.uniform(size=(int(rng.randint(1, 70)), int(rng.randint(1, 70)), 3)).astype(np.float32)
+                R = orc.RenderOracle(sc["pos"], sc["tri"], sc["proj"], H, W, {}, dict(rgb=0.7, depth=1.0, mask=1.0), dtype=np.float32, cull_backfaces=True,
+                                     uv=sc["uv"], tex=sc["tex"])
+                R.gt = {k: v[None] for k, v in sc["gt"].items()}
+                stats["odd_textures"] = stats.get("odd_textures", 0) + 1
+            G = B + int(rng.randint(0, 20)) if rng.rand() < 0.3 else B  # the hypotheses are a shard of a larger global batch
             R.weights = {k: weights.get(k) for k in KEYS}
-            total, logs, g_ref, _ = R.loss_and_grad(sc["params"], sc["lr_mult"])
+            total, logs, g_ref, _ = R.loss_and_grad(sc["params"], sc["lr_mult"], global_B=G)
             tex = dict(uv=T(sc["uv"]), tex=T(sc["tex"])) if textured else dict(vtx_color=T(sc["vtx_color"]))
             params = T(sc["params"])
-            eng = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, params, T(sc["lr_mult"]), [0.1], weights, **tex)
+            eng = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, params, T(sc["lr_mult"]), [0.1], weights, global_batch=G, **tex)
             losses, grad = eng.loss_and_grad()
             torch.cuda.synchronize()
             st = eng.check()
@@ -53,6 +60,8 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                 if k in logs: ok &= np.allclose(lg[i], logs[k], rtol=1e-4, atol=2e-7)
             gerr = np.abs(gg - g_ref).max() / scale
             ok &= gerr < 1e-2
+            if gerr > 2e-3 and verbose:
+                print("note: gradient error", float(gerr), tag, "| max |g_ref|", float(np.abs(g_ref).max()))
             stats['max_grad_err'] = max(stats['max_grad_err'], float(gerr)); stats['outside'] += int(st['outside_view_volume'] > 0); stats['big'] += int(st['big_triangles'] > 0)
             stats['covered'] += int(sc['coverage'] > 0); stats['empty'] += int(np.abs(g_ref).max() == 0)
             # op-level ids, both faces (nvdiffrast semantics)
@@ -66,7 +75,7 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
             if case % 4 == 1 and not (sc["params"][6] > -0.7).any():
                 R.cull_backfaces = False
                 R.weights = dict(rgb=0.7, depth=1.0, mask=1.0)
-                tot2, _, g2, r2 = R.loss_and_grad(sc["params"], sc["lr_mult"])
+                tot2, _, g2, r2 = R.loss_and_grad(sc["params"], sc["lr_mult"])  # (global batch = B: the torch expressions below)
                 R.cull_backfaces = True
                 pl = [T(sc["params"][i], requires_grad=True) for i in range(7)]
                 q = torch.stack(pl[:4], dim=0).T
@@ -90,22 +99,34 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                 mat_ok &= abs(float(loss.detach()) - tot2) < 2e-5 * max(1, abs(tot2))
                 mat_ok &= np.abs(gm - g2).max() < 1e-2 * max(np.abs(g2).max(), 1e-7)
                 stats["materialising"] = stats.get("materialising", 0) + 1
-            # every 4th case: three fused SGD iterations against the oracle's loop
+            # every 4th case: three fused SGD iterations, the oracle teacher-forced on the engine's own parameters before each (a free-
+            # running comparison measures the chaos of L1 sign flips under large steps, not the kernels: seed 203758 differs by 3e-3
+            # after three steps although every single gradient agrees to 3e-7).  State carried between iterations -- zbuf / tile-flag
+            # re-arm, double-buffered matrices -- is what this adds over the single evaluation above.
             traj_ok = True
             if case % 4 == 2:
                 lrs3 = [0.05, 0.04, 0.03]
                 R.weights = {k: weights.get(k) for k in KEYS}
-                p_ref, _ = R.optimise(sc["params"], sc["lr_mult"], lrs3)[:2]
                 p3 = T(sc["params"])
-                e3 = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, p3, T(sc["lr_mult"]), lrs3, weights, **tex)
-                e3.run(); e3.finish()
-                d3 = np.abs(p3.cpu().numpy() - p_ref).max()
-                traj_ok = bool(d3 < 2e-3)
+                e3 = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, p3, T(sc["lr_mult"]), lrs3, weights, global_batch=G, **tex)
+                for it3, lr3 in enumerate(lrs3):
+                    before = p3.cpu().numpy().copy()
+                    e3.run(1); e3.finish()
+                    after = p3.cpu().numpy()
+                    _, lg3, g3, _ = R.loss_and_grad(before, sc["lr_mult"], global_B=G)
+                    # the step itself is compared (the gradient recovered from a float32 parameter difference is quantised at
+                    # 6e-8 |param| / lr): within 1 % of the largest step plus that round-off
+                    err = np.abs(after - (before - np.float32(lr3) * g3)).max()
+                    d3 = float(err / (1e-2 * lr3 * max(np.abs(g3).max(), 1e-6) + 4e-7 * max(1.0, np.abs(before).max())))
+                    stats["max_traj_diff"] = max(stats.get("max_traj_diff", 0.0), d3)
+                    row = e3.losses()[it3].cpu().numpy()
+                    for i, k in enumerate(KEYS):
+                        if k in lg3: traj_ok &= bool(np.allclose(row[i], lg3[k], rtol=1e-4, atol=2e-7))
+                    traj_ok &= d3 < 1.0  # (in units of the tolerance)
                 stats["trajectories"] = stats.get("trajectories", 0) + 1
-                stats["max_traj_diff"] = max(stats.get("max_traj_diff", 0.0), float(d3))
             if not (mat_ok and traj_ok):
                 bad += 1
-                print("MISMATCH (materialising path)" if not mat_ok else "MISMATCH (trajectory)", tag, stats.get("max_traj_diff"))
+                print("MISMATCH (materialising path)" if not mat_ok else "MISMATCH (trajectory)", tag)
             if not (ok and ids_ok and uvz < 1e-5):
                 bad += 1
                 print("MISMATCH", tag, "| grad err", gerr, "ids", ids_ok, "uvz", uvz, "status", st, "| max |g_ref|", float(np.abs(g_ref).max()), "max |g_gpu|", float(np.abs(gg).max()), "| losses", lg[:, 0], {k: v[0] for k, v in logs.items()})
