@@ -503,8 +503,10 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
     B = surf.shape[0]
     cam = dd_ops.xfm_points(surf[..., :3].reshape(B, H * W, 3).contiguous(), mtx)
     depth = -cam[..., 2].reshape(B, H, W)
-    # silhouette: coverage with antialiased edges (:212-214; the reference interpolates a tensor of ones)
-    cover, _ = interpolate(torch.ones((1, faces.shape[0], 3), device=pos.device), rast, faces)
+    # silhouette: coverage with antialiased edges (:212-214).  The reference interpolates torch.ones(pos_idx.shape), a [T,3] tensor
+    # used as per-VERTEX attributes: with more vertices than triangles the vertex ids run past it; one 1 per vertex is what is
+    # meant (DESIGN.md deviation D6) and what the fused pass computes
+    cover, _ = interpolate(torch.ones((1, pos.shape[1], 3), device=pos.device), rast, faces)
     mask = antialias(cover, rast, clip, faces)
     # colour: bilinear texture lookup at the interpolated uv, or interpolated vertex colours; background zeroed (:216-231)
     if textured:

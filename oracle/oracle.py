@@ -348,8 +348,11 @@ class RenderOracle:
         gb_pos = interpolate_fwd(posw, rast, self.tri)  # :203
         gb3 = np.ascontiguousarray(gb_pos[..., :3]).reshape(B, -1, 3)
         depth = -xfm_fwd(gb3, mtx, True).reshape(B, self.H, self.W, 4)[..., 2]  # :208-209
-        ones = np.ones((1, self.tri.shape[0], 3), dt)
-        cov = interpolate_fwd(ones, rast, self.tri)  # :212 (ones [T,3] indexed per vertex)
+        # :212 -- the reference builds the tensor of ones with the SHAPE OF THE INDEX BUFFER ([T,3]) and hands it to dr.interpolate
+        # as per-vertex attributes: with more vertices than triangles (a mesh un-merged along its uv seams) the vertex ids run
+        # past it.  Meant, and restated here, is the interpolation of one 1 per VERTEX = the coverage image (deviation D6).
+        ones = np.ones((1, self.pos.shape[0], 3), dt)
+        cov = interpolate_fwd(ones, rast, self.tri)
         mask = antialias_fwd(cov, rast, pos_clip, self.tri, self.opp)  # :214
         cov1 = np.clip(rast[..., 3:], 0, 1)
         r = dict(final=final, pos_clip=pos_clip, rast=rast, gb3=gb3, depth=depth, cov=cov, mask=mask)

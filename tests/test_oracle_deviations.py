@@ -242,3 +242,28 @@ def test_d5_backface_culling_only_on_closed_meshes_and_invisible_there():
     clip = orc.xfm_fwd(pos[None], np.matmul(proj[None].astype(np.float32), mtx), True)
     both = np.stack([orc.rasterize_fwd(clip, open_tri, H, W, s)[0, ..., 3] > 0 for s in (0, -1)])
     assert orc.mesh_cull_sign(pos, open_tri, proj) == 0 and both[0].sum() >= both[1].sum()
+
+
+def test_d6_coverage_interpolates_one_per_vertex_not_per_index_row():
+    """D6: the reference builds the silhouette's tensor of ones with the shape of the INDEX buffer
+    (`torch.ones(pos_idx.shape)`, diffdope.py:212: [B,T,3]) and hands it to dr.interpolate as per-vertex attributes.  With more
+    vertices than triangles -- any mesh un-merged along its uv seams or per wedge, V up to 3T -- vertex ids run past that tensor:
+    dr.interpolate's kernel leaves such a pixel at zero (an index check), so the reference's mask has holes there.  This build
+    interpolates one 1 per VERTEX: the mask is the coverage of the drawn triangles whatever V and T are."""
+    H, W = 32, 40
+    proj = orc.projection_matrix(fx=60.0, fy=60.0, cx=W / 2, cy=H / 2, im_width=W, im_height=H)
+    # three triangles, nine vertices (nothing shared: V = 9 > T = 3)
+    pos = np.array([[-0.3, -0.2, 0.0], [0.1, -0.25, 0.0], [-0.1, 0.25, 0.0], [0.05, -0.1, 0.1], [0.4, -0.05, 0.1], [0.2, 0.3, 0.1],
+                    [-0.45, 0.1, 0.05], [-0.2, 0.15, 0.05], [-0.4, 0.35, 0.05]], np.float32)
+    tri = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], np.int32)
+    vcol = np.ones((9, 3), np.float32)
+    R = orc.RenderOracle(pos, tri, proj, H, W, {}, dict(mask=1.0), vtx_color=vcol, dtype=np.float32)
+    mtx = orc.pose_fwd(np.array([[0.0], [0.0], [0.0], [1.0], [0.0], [0.0], [-1.5]], np.float32))
+    r = R.render(mtx)
+    ids = r["rast"][0, ..., 3]
+    assert (ids == 1).sum() > 20 and (ids == 2).sum() > 20 and (ids == 3).sum() > 5
+    inner = (ids > 0) & np.roll(ids > 0, 1, 0) & np.roll(ids > 0, -1, 0) & np.roll(ids > 0, 1, 1) & np.roll(ids > 0, -1, 1)
+    np.testing.assert_allclose(r["mask"][0][inner], 1.0, atol=1e-6)  # full coverage inside BOTH triangles
+    # what the [T,3]-shaped tensor gives when the attribute lookup checks its bounds (only the vertex ids 0..2 lie inside its 3 rows)
+    literal = orc.interpolate_fwd(np.ones((1, 3, 3), np.float32), r["rast"], tri)
+    assert literal[0][ids == 1].min() > 0.999 and literal[0][ids == 2].max() == 0.0 and literal[0][ids == 3].max() == 0.0

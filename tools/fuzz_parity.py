@@ -234,7 +234,83 @@ def sweep_soups(n_cases=200, seed0=0, verbose=True):
     return bad, stats
 
 
+def sweep_engine_soups(n_cases=200, seed0=0, verbose=True):
+    """The fused engine on arbitrary object-space triangle soups (open, self-intersecting, with degenerate, duplicated and
+    unreferenced parts, sizes from specks to triangles larger than the frame, shared vertices): losses and pose gradients
+    against the oracle.  No culling applies (not a closed surface); straddlers, the tile pass and depth ties all occur."""
+    bad = 0
+    stats = dict(max_grad_err=0.0, outside=0, big=0)
+    t_start = time.time()
+    for case in range(n_cases):
+        rng = np.random.RandomState(seed0 + case)
+        H, W = int(rng.randint(8, 160)), int(rng.randint(8, 220))
+        n_tri = int(rng.randint(1, 250))
+        nv = int(rng.randint(3, 3 * n_tri + 1))
+        B = int(rng.randint(1, 5))
+        ext = float(np.exp(rng.uniform(np.log(0.05), np.log(1.5))))
+        pos = rng.normal(size=(nv, 3)).astype(np.float32) * np.float32(0.35)
+        tri = rng.randint(0, nv, size=(n_tri, 3)).astype(np.int32)
+        local = rng.rand(n_tri) < 0.7  # most triangles small: corners near the first one
+        near = np.clip(tri[:, :1] + rng.randint(-4, 5, size=(n_tri, 3)), 0, nv - 1)
+        tri[local] = near[local]
+        pos = (pos * ext).astype(np.float32)
+        if os.environ.get("FUZZ_NO_DEGENERATE"):
+            keep = (tri[:, 0] != tri[:, 1]) & (tri[:, 1] != tri[:, 2]) & (tri[:, 0] != tri[:, 2])
+            tri = tri[keep] if keep.any() else np.array([[0, 1, 2]], np.int32)
+            n_tri = len(tri)
+        textured = bool(rng.randint(2))
+        uv = rng.uniform(-0.5, 1.5, size=(nv, 2)).astype(np.float32)
+        tex = rng.uniform(size=(int(rng.randint(1, 40)), int(rng.randint(1, 40)), 3)).astype(np.float32)
+        vcol = rng.uniform(size=(nv, 3)).astype(np.float32)
+        from diffdope_amd import synthetic as syn
+        proj = orc.projection_matrix(**syn.camera_intrinsics(W, H)).astype(np.float32)
+        dist = float(np.exp(rng.uniform(np.log(0.4), np.log(6.0))))
+        names = [k for k in KEYS if rng.rand() < 0.6] or ["depth"]
+        weights = {k: float(rng.uniform(0.3, 1.5)) for k in names}
+        kw = dict(uv=uv, tex=tex) if textured else dict(vtx_color=vcol)
+        tag = f"engine soup {case} seed {seed0 + case}: {n_tri} triangles / {nv} vertices, frame {H}x{W}, dist {dist:.2f}, B {B}, {'tex' if textured else 'vcol'} {sorted(weights)}"
+        try:
+            R = orc.RenderOracle(pos, tri, proj, H, W, {}, dict(rgb=1.0, depth=1.0, mask=1.0), dtype=np.float32, cull_backfaces=True, **kw)
+            q_gt, t_gt = syn.random_quat(rng), np.array([rng.uniform(-0.2, 0.2) * dist, rng.uniform(-0.2, 0.2) * dist, -dist])
+            r = R.render(orc.pose_fwd(np.concatenate([q_gt, t_gt])[:, None].astype(np.float32)))
+            cov = r["rast"][0, ..., 3] > 0
+            gt = dict(rgb=r["rgb"][0].copy(), depth=r["depth"][0].copy(), segmentation=np.repeat(cov[..., None], 3, -1).astype(np.float32))
+            R.gt = {k: v[None] for k, v in gt.items()}
+            params = []
+            for b in range(B):
+                q, t = syn.perturb_pose(q_gt, t_gt, float(rng.uniform(0, 30)), float(rng.uniform(0, 0.3)), rng)
+                params.append(np.concatenate([q * rng.uniform(0.7, 1.4), t]))
+            params = np.stack(params, 1).astype(np.float32)
+            lr_mult = rng.uniform(0.5, 2.0, size=B).astype(np.float32)
+            R.weights = {k: weights.get(k) for k in KEYS}
+            total, logs, g_ref, _ = R.loss_and_grad(params, lr_mult)
+            texk = dict(uv=T(uv), tex=T(tex)) if textured else dict(vtx_color=T(vcol))
+            eng = dd.RefineEngine(T(pos), T(tri), T(proj), [H, W], {k: T(v) for k, v in gt.items()}, T(params), T(lr_mult), [0.1], weights, **texk)
+            losses, grad = eng.loss_and_grad()
+            torch.cuda.synchronize()
+            st = eng.check()
+            lg, gg = losses.cpu().numpy(), grad.cpu().numpy()
+            ok = bool(np.isfinite(gg).all()) and eng.cull_sign == R._cull_sign
+            for i, k in enumerate(KEYS):
+                if k in logs: ok &= bool(np.allclose(lg[i], logs[k], rtol=1e-4, atol=2e-7))
+            gerr = float(np.abs(gg - g_ref).max() / max(np.abs(g_ref).max(), 1e-6))
+            ok &= gerr < 1e-2
+            stats["max_grad_err"] = max(stats["max_grad_err"], gerr); stats["outside"] += int(st["outside_view_volume"] > 0); stats["big"] += int(st["big_triangles"] > 0)
+            if not ok:
+                bad += 1
+                print("MISMATCH", tag, "| grad err", gerr, "cull", eng.cull_sign, R._cull_sign, "status", st, "| losses", lg[:, 0], {k: v[0] for k, v in logs.items()})
+        except Exception as e:
+            bad += 1
+            print("ERROR", tag, repr(e))
+    if verbose:
+        print(f"{n_cases} engine soups, {bad} bad, {time.time() - t_start:.0f} s", stats)
+    return bad, stats
+
+
 if __name__ == "__main__":
+    if os.environ.get("FUZZ_ENGINE_SOUPS"):
+        sweep_engine_soups(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        sys.exit(0)
     if os.environ.get("FUZZ_SOUPS"):
         sweep_soups(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
         sys.exit(0)
