@@ -1845,11 +1845,17 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             }
             if (getenv("DDX_DEBUG_CULL")) fprintf(stderr, "ddx cull: edges paired %d\n", (int)closed);
             if (closed) {
-                std::vector<double> svol((size_t)V, 0.0);
+                // every shell must enclose a volume of the sign of the whole -- and a real one: a flat two-sided patch (the same
+                // triangles wound both ways) is "closed" with a volume that is round-off of either sign
+                std::vector<double> svol((size_t)V, 0.0), sabs((size_t)V, 0.0);
                 for (int t = 0; t < T; ++t)
-                    if (tvol[(size_t)t] != 0.0) svol[(size_t)root(canon[(size_t)htri[(size_t)t * 3]])] += tvol[(size_t)t];
+                    if (tvol[(size_t)t] != 0.0) {
+                        const size_t r = (size_t)root(canon[(size_t)htri[(size_t)t * 3]]);
+                        svol[r] += tvol[(size_t)t];
+                        sabs[r] += std::fabs(tvol[(size_t)t]);
+                    }
                 for (int v = 0; v < V && closed; ++v)
-                    if (svol[(size_t)v] != 0.0 && (svol[(size_t)v] > 0.0) != (vol6 > 0.0)) closed = false;
+                    if (sabs[(size_t)v] > 0.0 && (!(std::fabs(svol[(size_t)v]) > 1e-9 * sabs[(size_t)v]) || (svol[(size_t)v] > 0.0) != (vol6 > 0.0))) closed = false;
             }
             float hp[16];
             DDX_HIP(hipMemcpyAsync(hp, E.b.proj, sizeof(hp), hipMemcpyDeviceToHost, s));

@@ -177,7 +177,9 @@ def mesh_cull_sign(pos, tri, proj):
     g = coo_matrix((np.ones(len(a), np.int8), (a, b)), shape=(nc, nc))
     _, label = connected_components(g, directed=False)
     svol = np.bincount(label[c[:, 0]], weights=tvol)
-    if np.any((svol != 0) & ((svol > 0) != (vol6 > 0))):
+    sabs = np.bincount(label[c[:, 0]], weights=np.abs(tvol))
+    # ... and a real volume: a flat two-sided patch (the same triangles wound both ways) is "closed" with a volume that is round-off
+    if np.any((sabs > 0) & (~(np.abs(svol) > 1e-9 * sabs) | ((svol > 0) != (vol6 > 0)))):
         return 0
     P = np.asarray(proj, np.float64)
     if not (P[0, 3] == 0 and P[1, 3] == 0 and P[3, 3] == 0):

@@ -574,6 +574,12 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
         eng.loss_and_grad()  # (the mesh is analysed by the first run)
         torch.cuda.synchronize()
         assert eng.cull_sign == want == orc.mesh_cull_sign(pos2, tri2, sc["proj"])
+    # (e) a flat two-sided patch next to the solid (edges pair up, the enclosed volume is round-off): no culling
+    tri3 = np.concatenate([sc["tri"], sc["tri"][:30] + n, (sc["tri"][:30] + n)[:, [0, 2, 1]]]).astype(np.int32)
+    eng, _ = _engine(dict(sc, pos=pos2, tri=tri3, uv=uv2), w, [0.1])
+    eng.loss_and_grad()
+    torch.cuda.synchronize()
+    assert eng.cull_sign == 0 == orc.mesh_cull_sign(pos2, tri3, sc["proj"])
 
 
 @pytest.mark.parametrize("deg,frac,tol_rad", [(1.0, 0.01, 1e-3), (10.0, 0.04, 5e-3), (40.0, 0.16, None)])

@@ -213,6 +213,11 @@ def test_d5_backface_culling_only_on_closed_meshes_and_invisible_there():
     small = tri + len(pos)
     assert orc.mesh_cull_sign(two_pos, np.concatenate([tri, small]), proj) == -1
     assert orc.mesh_cull_sign(two_pos, np.concatenate([tri, small[:, [0, 2, 1]]]), proj) == 0
+    # a flat two-sided patch (the same triangles wound both ways) has every edge shared by two opposite triangles, but its
+    # volume is round-off of either sign: not a solid, never culled
+    flat = np.concatenate([tri[:40], tri[:40][:, [0, 2, 1]]])
+    assert orc.mesh_cull_sign(pos, flat, proj) == 0
+    assert orc.mesh_cull_sign(two_pos, np.concatenate([tri, flat + len(pos)]), proj) == 0  # (also next to a real solid)
     bad_proj = proj.copy()
     bad_proj[3, 3] = 1.0  # orthographic-style w row: not the pinhole the sign argument needs
     assert orc.mesh_cull_sign(pos, tri, bad_proj) == 0
