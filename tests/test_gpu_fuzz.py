@@ -38,3 +38,26 @@ def test_randomised_triangle_soups_fixed_slice():
     bad, stats = fuzz.sweep_soups(300, 4242, verbose=True)
     assert bad == 0, stats
     assert stats["drawn"] > 1_000_000 and stats["straddlers"] > 1000 and stats["near_eye"] > 1000
+
+
+def test_randomised_small_ops_and_fused_adam_fixed_slice():
+    """150 cases of the small ops with random shapes and extreme values (xfm bit for bit, texture with uv far outside [0,1],
+    masked L1 at any element count, the pose-matrix op) and 50 fused-Adam sequences, each step against the oracle's Adam
+    teacher-forced with the oracle's gradient at the engine's own parameters."""
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad, stats = fuzz.sweep_ops(150, 777, verbose=True)
+    assert bad == 0, stats
+    assert stats["adam"] == 50 and stats["xfm"] == 150
+
+
+def test_randomised_engine_soups_fixed_slice():
+    """300 arbitrary object-space triangle soups through the fused engine (open, self-intersecting, degenerate, duplicated, more
+    vertices than triangles): losses and pose gradients against the oracle, same culling decision."""
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad, stats = fuzz.sweep_engine_soups(150, 306440, verbose=True)   # (holds seed 306514: a flat two-sided patch)
+    bad2, _ = fuzz.sweep_engine_soups(150, 313350, verbose=True)      # (holds seed 313409: the same, decided the other way round 2)
+    assert bad + bad2 == 0, stats

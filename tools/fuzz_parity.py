@@ -307,7 +307,135 @@ def sweep_engine_soups(n_cases=200, seed0=0, verbose=True):
     return bad, stats
 
 
+def sweep_ops(n_cases=300, seed0=0, verbose=True):
+    """The small ops with random shapes and extreme values against the oracle: xfm_points / xfm_vectors forward and backward
+    (any N, batch-1 broadcast of points or matrices), texture (uv far outside [0,1], negative, exactly on texel borders, 1x1 ..
+    odd sizes), masked L1 (any element count, mask / no mask / channel-0 mask), the pose-matrix op, the fused Adam step
+    (teacher-forced against the oracle's Adam over consecutive iterations)."""
+    from diffdope_amd.render import masked_l1_mean
+    bad = 0
+    stats = dict(xfm=0, texture=0, masked_l1=0, pose=0, adam=0)
+    t_start = time.time()
+    for case in range(n_cases):
+        rng = np.random.RandomState(seed0 + case)
+        tag = f"ops case {case} seed {seed0 + case}"
+        try:
+            ok = True
+            # ---- xfm
+            B, N = int(rng.randint(1, 6)), int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, int(rng.randint(1, 5000))]))
+            pb, mb = (1 if rng.rand() < 0.3 else B), B  # (points may be one broadcast copy; the matrix carries the batch, as in the reference)
+            pts = (rng.normal(size=(pb, N, 3)) * 10.0 ** rng.uniform(-3, 3)).astype(np.float32)
+            mtx = rng.normal(size=(mb, 4, 4)).astype(np.float32)
+            for is_points in (True, False):
+                fn = dd.ops.xfm_points if is_points else dd.ops.xfm_vectors
+                p_t, m_t = T(pts, requires_grad=True), T(mtx, requires_grad=True)
+                out = fn(p_t, m_t)
+                pe, me = np.broadcast_to(pts, (max(pb, mb),) + pts.shape[1:]), np.broadcast_to(mtx, (max(pb, mb), 4, 4))
+                ref = orc.xfm_fwd(np.ascontiguousarray(pe), np.ascontiguousarray(me), is_points)
+                ok &= bool(np.array_equal(out.detach().cpu().numpy(), ref))  # (bit-identical: the k-ordered fma chain)
+                go = rng.normal(size=ref.shape).astype(np.float32)
+                out.backward(T(go))
+                dp, dm = orc.xfm_bwd(np.ascontiguousarray(pe), np.ascontiguousarray(me), go, is_points)
+                if pb == 1 and max(pb, mb) > 1: dp = dp.sum(0, keepdims=True)
+                if mb == 1 and max(pb, mb) > 1: dm = dm.sum(0, keepdims=True)
+                ok &= bool(np.allclose(p_t.grad.cpu().numpy(), dp, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(dp).max())))
+                ok &= bool(np.allclose(m_t.grad.cpu().numpy(), dm, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(dm).max())))
+            stats["xfm"] += 1
+            if not ok: print("MISMATCH xfm", tag, B, N, pb, mb)
+            # ---- texture
+            ok2 = True
+            Bt, H, W = int(rng.randint(1, 4)), int(rng.randint(1, 40)), int(rng.randint(1, 50))
+            Th, Tw = int(rng.randint(1, 33)), int(rng.randint(1, 33))
+            tb = 1 if rng.rand() < 0.5 else Bt
+            tex = rng.uniform(size=(tb, Th, Tw, 3)).astype(np.float32)
+            uv = (rng.normal(size=(Bt, H, W, 2)) * 10.0 ** rng.uniform(-1, 4)).astype(np.float32)
+            snap = rng.rand(Bt, H, W, 2) < 0.2
+            uv[snap] = (np.round(uv[snap] * Tw) / Tw).astype(np.float32)  # on texel borders / centres
+            tx_t, uv_t = T(tex, requires_grad=True), T(uv, requires_grad=True)
+            out = dd.texture(tx_t, uv_t, filter_mode="linear")
+            ref = orc.texture_fwd(tex, uv)
+            ok2 &= bool(np.allclose(out.detach().cpu().numpy(), ref, rtol=0, atol=2e-6))
+            go = rng.normal(size=ref.shape).astype(np.float32)
+            out.backward(T(go))
+            duv, dtex = orc.texture_bwd(tex, uv, go, True)
+            ok2 &= bool(np.allclose(uv_t.grad.cpu().numpy(), duv, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(duv).max())))
+            ok2 &= bool(np.allclose(tx_t.grad.cpu().numpy(), dtex, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(dtex).max())))
+            stats["texture"] += 1
+            if not ok2: print("MISMATCH texture", tag, (Bt, H, W), (tb, Th, Tw), float(np.abs(uv).max()))
+            # ---- masked L1
+            ok3 = True
+            Bm, Hm, Wm = int(rng.randint(1, 7)), int(rng.randint(1, 60)), int(rng.randint(1, 60))
+            seg = (rng.rand(1, Hm, Wm, 3) > rng.uniform(0.1, 0.95)).astype(np.float32) * rng.choice([1.0, 0.5, -2.0])
+            for shape, ch0 in (((Bm, Hm, Wm, 3), False), ((Bm, Hm, Wm), True)):
+                x = rng.normal(size=shape).astype(np.float32)
+                y = rng.normal(size=(1,) + shape[1:]).astype(np.float32)
+                use_mask = rng.rand() < 0.8 or ch0
+                x_t = T(x, requires_grad=True)
+                yb, sb = T(y).expand(shape), T(seg).expand(Bm, Hm, Wm, 3)
+                lr = T(rng.rand(Bm).astype(np.float32))
+                o = masked_l1_mean(x_t, yb, sb if use_mask else None, mask_channel0=ch0)
+                mk = (seg[..., 0] if ch0 else seg) if use_mask else 1.0
+                refv = np.abs((x.astype(np.float64) - y) * mk).mean(axis=tuple(range(1, x.ndim)))
+                ok3 &= bool(np.allclose(o.detach().cpu().numpy(), refv, rtol=3e-5, atol=1e-7))
+                (o * lr).mean().backward()
+                d = (x - y) * mk
+                gref = np.sign(d) * mk * (lr.cpu().numpy().reshape((-1,) + (1,) * (x.ndim - 1)) / Bm / np.prod(shape[1:]))
+                ok3 &= bool(np.allclose(x_t.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-10))
+            stats["masked_l1"] += 1
+            if not ok3: print("MISMATCH masked_l1", tag, (Bm, Hm, Wm))
+            # ---- pose matrix op
+            ok4 = True
+            Bp = int(rng.randint(1, 300))
+            q = (rng.normal(size=(Bp, 4)) * 10.0 ** rng.uniform(-2, 2)).astype(np.float32)
+            t = (rng.normal(size=(Bp, 3)) * 10.0 ** rng.uniform(-2, 2)).astype(np.float32)
+            qn = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+            q_t, t_t = T(qn, requires_grad=True), T(t, requires_grad=True)
+            M = dd.matrix_batch_44_from_position_quat(q=q_t, p=t_t)
+            pr = np.concatenate([qn, t], 1).T.astype(np.float32)
+            Mref = orc.pose_fwd(pr)  # (normalises again: idempotent to round-off)
+            ok4 &= bool(np.allclose(M.detach().cpu().numpy(), Mref, rtol=1e-5, atol=1e-6 * max(1.0, np.abs(t).max())))
+            stats["pose"] += 1
+            if not ok4: print("MISMATCH pose", tag, Bp)
+            # ---- fused Adam: consecutive iterations, oracle Adam teacher-forced with the oracle's gradient at the engine's parameters
+            ok5 = True
+            if case % 3 == 0:
+                sc = make_scene(int(rng.randint(6, 20)), int(rng.randint(8, 24)), int(rng.randint(30, 90)), int(rng.randint(40, 120)), B=int(rng.randint(1, 5)),
+                                dist=float(rng.uniform(1.2, 4.0)), seed=seed0 + case)
+                weights = dict(rgb=0.7, depth=1.0, mask=1.0)
+                R = sc["oracle"]; R.weights = dict(weights, edge=None)
+                lrs = [0.01, 0.008, 0.006, 0.004]
+                p_t = T(sc["params"])
+                eng = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [sc["H"], sc["W"]], {k: T(v) for k, v in sc["gt"].items()}, p_t, T(sc["lr_mult"]), lrs,
+                                      weights, uv=T(sc["uv"]), tex=T(sc["tex"]), optimizer="adam")
+                m1 = np.zeros_like(sc["params"]); m2 = np.zeros_like(sc["params"])
+                b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-8)
+                for step, lr in enumerate(lrs, start=1):
+                    before = p_t.cpu().numpy().copy()
+                    eng.run(1); eng.finish()
+                    _, _, g, _ = R.loss_and_grad(before, sc["lr_mult"])
+                    m1 = (b1 * m1 + (np.float32(1) - b1) * g).astype(np.float32)
+                    m2 = (b2 * m2 + (np.float32(1) - b2) * g * g).astype(np.float32)
+                    c1, c2 = np.float32(1.0 - 0.9 ** step), np.float32(1.0 - 0.999 ** step)
+                    upd = np.float32(lr) * (m1 / c1) / (np.sqrt(m2 / c2) + eps)
+                    got = before - p_t.cpu().numpy()
+                    # components whose gradient is round-off are excluded: Adam normalises them to a full-size step of either sign
+                    big = np.abs(g) > 1e-4 * np.abs(g).max()
+                    ok5 &= bool(np.allclose(got[big], upd[big], rtol=2e-3, atol=2e-3 * lr))
+                stats["adam"] += 1
+                if not ok5: print("MISMATCH adam", tag)
+            if not (ok and ok2 and ok3 and ok4 and ok5): bad += 1
+        except Exception as e:
+            bad += 1
+            print("ERROR", tag, repr(e))
+    if verbose:
+        print(f"{n_cases} op cases, {bad} bad, {time.time() - t_start:.0f} s", stats)
+    return bad, stats
+
+
 if __name__ == "__main__":
+    if os.environ.get("FUZZ_OPS"):
+        sweep_ops(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        sys.exit(0)
     if os.environ.get("FUZZ_ENGINE_SOUPS"):
         sweep_engine_soups(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
         sys.exit(0)
