@@ -296,6 +296,20 @@ def sweep_engine_soups(n_cases=200, seed0=0, verbose=True):
             gerr = float(np.abs(gg - g_ref).max() / max(np.abs(g_ref).max(), 1e-5))  # (floor: oracle round-off where the true gradient vanishes)
             ok &= gerr < 1e-2
             stats["max_grad_err"] = max(stats["max_grad_err"], gerr); stats["outside"] += int(st["outside_view_volume"] > 0); stats["big"] += int(st["big_triangles"] > 0)
+            if case % 3 == 0:  # the materialising path on the same soup: fused and op by op against the oracle's images (both faces drawn)
+                R.cull_backfaces = False
+                r2 = R.render(orc.pose_fwd(params))
+                ex = lambda a: T(a)[None].expand(B, *a.shape)
+                kw2 = dict(uv=ex(uv), uv_idx=ex(tri), tex=ex(tex)) if textured else dict(vtx_color=ex(vcol))
+                for fused in (True, False):
+                    out = dd.render_texture_batch(dd.RasterizeGLContext(), ex(proj), T(orc.pose_fwd(params)), ex(pos), ex(tri), [H, W], return_rast_out=True, fused=fused, **kw2)
+                    mok = bool(np.array_equal(out["rast_out"][..., 3].cpu().numpy(), r2["rast"][..., 3]))
+                    for k in ("rgb", "depth", "mask"):
+                        mok &= bool(np.allclose(out[k].cpu().numpy(), r2[k], rtol=1e-4, atol=5e-5 * max(1.0, float(np.abs(r2[k]).max()))))
+                    if not mok:
+                        ok = False
+                        print("MISMATCH (materialising path, fused =", fused, ")", tag)
+                stats["materialising"] = stats.get("materialising", 0) + 1
             if not ok:
                 bad += 1
                 print("MISMATCH", tag, "| grad err", gerr, "cull", eng.cull_sign, R._cull_sign, "status", st, "| losses", lg[:, 0], {k: v[0] for k, v in logs.items()})
