@@ -446,7 +446,66 @@ def sweep_ops(n_cases=300, seed0=0, verbose=True):
     return bad, stats
 
 
+def sweep_api(n_cases=60, seed0=0, verbose=True):
+    """DiffDope.run_optimization through the fused engine and through the op-by-op autograd path (what a user loss function
+    gets) on random small scenes and loss sets: the logged losses of iteration 0 agree tightly (same parameters), the run as a
+    whole loosely (two different float orders driving L1 terms), engine reuse on a second run gives the first run's result."""
+    bad = 0
+    stats = dict(max_first_loss_diff=0.0, max_param_diff=0.0)
+    t_start = time.time()
+    for case in range(n_cases):
+        rng = np.random.RandomState(seed0 + case)
+        rows, cols = int(rng.randint(5, 22)), int(rng.randint(6, 26))
+        H, W = int(rng.randint(30, 100)), int(rng.randint(40, 130))
+        B = int(rng.randint(1, 7))
+        losses = [k for k in ("rgb", "depth", "mask", "edge") if rng.rand() < 0.6] or ["mask"]
+        sc = make_scene(rows, cols, H, W, B=1, dist=float(rng.uniform(1.3, 5.0)), seed=seed0 + case, rot_deg=float(rng.uniform(1, 12)), trans=float(rng.uniform(0, 0.05)))
+        tag = f"api case {case} seed {seed0 + case}: mesh {rows}x{cols} frame {H}x{W} B {B} {losses}"
+        try:
+            def make():
+                mesh = dd.Mesh.from_arrays(sc["pos"], sc["tri"], uv=sc["uv"], tex=sc["tex"])
+                q, t = sc["params"][:4, 0], sc["params"][4:, 0]
+                obj = dd.Object3D(position=list(t), rotation=list(q / np.linalg.norm(q)), batchsize=B, opencv2opengl=False, scale=1, mesh=mesh)
+                scene = dd.Scene(tensor_rgb=dd.Image(img_tensor=torch.tensor(sc["gt"]["rgb"])), tensor_depth=dd.Image(img_tensor=torch.tensor(sc["gt"]["depth"])),
+                                 tensor_segmentation=dd.Image(img_tensor=torch.tensor(sc["gt"]["segmentation"])))
+                cam = dd.Camera(fx=1, fy=1, cx=0, cy=0, im_width=W, im_height=H)
+                cam.cam_proj = torch.tensor(sc["proj"], dtype=torch.float64)
+                cfg = dict(losses=dict(l1_rgb_with_mask="rgb" in losses, weight_rgb=0.7, l1_depth_with_mask="depth" in losses, weight_depth=1.0,
+                                       l1_mask="mask" in losses, weight_mask=1.0, l1_edge="edge" in losses, weight_edge=0.6),
+                           hyperparameters=dict(nb_iterations=3, batchsize=B, base_lr=0.05, learning_rates_bound=[0.5, 2.0], learning_rate_base=1, lr_decay=0.1, seed=3))
+                return dd.DiffDope(cfg=cfg, camera=cam, object3d=obj, scene=scene)
+            a, b = make(), make()
+            a.run_optimization(fused=True)
+            b.run_optimization(fused=False)
+            ok = set(a.losses_values) == set(b.losses_values)
+            for k in a.losses_values:
+                la, lb = a.losses_values[k].numpy(), b.losses_values[k].numpy()
+                d0 = float(np.abs(la[0] - lb[0]).max() / max(np.abs(lb[0]).max(), 1e-6))
+                stats["max_first_loss_diff"] = max(stats["max_first_loss_diff"], d0)
+                ok &= d0 < 2e-3
+            pa, pb = a.object3d.params_tensor().cpu().numpy(), b.object3d.params_tensor().cpu().numpy()
+            dp = float(np.abs(pa - pb).max())
+            stats["max_param_diff"] = max(stats["max_param_diff"], dp)
+            ok &= dp < 5e-3
+            first = (pa.copy(), {k: v.clone() for k, v in a.losses_values.items()})
+            a.object3d.reset_pose()
+            a.run_optimization(fused=True)  # (reuses its engine)
+            ok &= bool(np.array_equal(a.object3d.params_tensor().cpu().numpy(), first[0])) and all(torch.equal(a.losses_values[k], first[1][k]) for k in first[1])
+            if not ok:
+                bad += 1
+                print("MISMATCH", tag, "first-iteration loss diff", stats["max_first_loss_diff"], "param diff", dp)
+        except Exception as e:
+            bad += 1
+            print("ERROR", tag, repr(e))
+    if verbose:
+        print(f"{n_cases} api cases, {bad} bad, {time.time() - t_start:.0f} s", stats)
+    return bad, stats
+
+
 if __name__ == "__main__":
+    if os.environ.get("FUZZ_API"):
+        sweep_api(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        sys.exit(0)
     if os.environ.get("FUZZ_OPS"):
         sweep_ops(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
         sys.exit(0)
