@@ -63,15 +63,17 @@ class RefineEngine:
             self.tex = self.tex[0].contiguous()
         H, W = int(resolution[0]), int(resolution[1])
         self.H, self.W = H, W
-        self.gt_seg = f32(gt["segmentation"])
-        self.gt_rgb = f32(gt.get("rgb"))
-        self.gt_depth = f32(gt.get("depth"))
+        # (private copies: new_observation() overwrites these buffers in place, which must not reach back into the caller's images)
+        own = lambda t: None if t is None else (f32(t).clone() if f32(t).data_ptr() == t.data_ptr() else f32(t))
+        self.gt_seg = own(gt["segmentation"])
+        self.gt_rgb = own(gt.get("rgb"))
+        self.gt_depth = own(gt.get("depth"))
         assert tuple(self.gt_seg.shape) == (H, W, 3), f"segmentation must be [H,W,3], got {tuple(self.gt_seg.shape)}"
         self.params = params
         assert params.is_cuda and params.dtype == torch.float32 and params.is_contiguous() and params.shape[0] == 7
         B = params.shape[1]
         self.B = B
-        self.lr_mult = f32(lr_mult)
+        self.lr_mult = own(lr_mult)
         self.lr_sched = torch.as_tensor(lr_sched, dtype=torch.float64).to(torch.float32).to(dev).contiguous()
         n_it = self.lr_sched.numel()
         self.max_iters = n_it

@@ -61,3 +61,15 @@ def test_randomised_engine_soups_fixed_slice():
     bad, stats = fuzz.sweep_engine_soups(150, 306440, verbose=True)   # (holds seed 306514: a flat two-sided patch)
     bad2, _ = fuzz.sweep_engine_soups(150, 313350, verbose=True)      # (holds seed 313409: the same, decided the other way round 2)
     assert bad + bad2 == 0, stats
+
+
+def test_randomised_engine_state_machine_fixed_slice():
+    """120 cases of the engine as a state machine: six iterations in one go against the same iterations in random pieces with
+    evaluation passes in between and graph replay, after a rewind / new observation, after another observation and back, and as
+    two shards with the unsharded run's slice counts -- parameters, loss log and pose log bit for bit."""
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad, stats = fuzz.sweep_state(120, 31337, verbose=True)
+    assert bad == 0, stats
+    assert stats["graphs"] > 40

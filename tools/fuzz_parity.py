@@ -449,6 +449,88 @@ def sweep_ops(n_cases=300, seed0=0, verbose=True):
     return bad, stats
 
 
+def sweep_state(n_cases=100, seed0=0, verbose=True):
+    """The engine as a state machine: a six-iteration run in one go against the same six iterations cut into random pieces with
+    evaluation passes in between, replayed from captured graphs, restarted after a rewind, continued after a new observation
+    and back, and computed as two shards with the unsharded run's slice counts -- everything bit for bit."""
+    bad = 0
+    stats = dict(graphs=0, shards=0, rewinds=0, observations=0)
+    t_start = time.time()
+    for case in range(n_cases):
+        rng = np.random.RandomState(seed0 + case)
+        rows, cols = int(rng.randint(5, 24)), int(rng.randint(6, 28))
+        H, W = int(rng.randint(30, 110)), int(rng.randint(40, 140))
+        B = int(rng.randint(2, 9))
+        names = [k for k in KEYS if rng.rand() < 0.6] or ["rgb"]
+        weights = {k: float(rng.uniform(0.3, 1.5)) for k in names}
+        optimizer = "adam" if rng.rand() < 0.5 else "sgd"
+        sc = make_scene(rows, cols, H, W, B=B, dist=float(rng.uniform(1.2, 5.0)), seed=seed0 + case, textured=bool(rng.randint(2)))
+        tag = f"state case {case} seed {seed0 + case}: mesh {rows}x{cols} frame {H}x{W} B {B} {sorted(weights)} {optimizer}"
+        n = 6
+        lrs = [float(x) for x in rng.uniform(0.002, 0.02, n)]
+        try:
+            tex = dict(uv=T(sc["uv"]), tex=T(sc["tex"])) if sc["textured"] else dict(vtx_color=T(sc["vtx_color"]))
+            gt = {k: T(v) for k, v in sc["gt"].items()}
+            def engine(params, lr_mult, lo=0, hi=B, **kw):
+                return dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], gt, params, T(lr_mult[lo:hi]), lrs, weights, optimizer=optimizer, **tex, **kw)
+            p_ref = T(sc["params"])
+            ref = engine(p_ref, sc["lr_mult"])
+            ref.run(); ref.finish()
+            want = (p_ref.clone(), ref.losses().clone(), ref.mtx_log.clone())
+            same = lambda p, e: torch.equal(p, want[0]) and torch.equal(e.losses(), want[1]) and torch.equal(e.mtx_log, want[2])
+            ok = True
+            # (1) pieces + evaluation passes + graphs
+            use_graph = int(rng.choice([0, 0, 1, 2, 3]))
+            p1 = T(sc["params"])
+            e1 = engine(p1, sc["lr_mult"])
+            done = 0
+            while done < n:
+                k = int(rng.randint(1, n - done + 1))
+                if rng.rand() < 0.5: e1.loss_and_grad()
+                e1.run(k, use_graph=use_graph)
+                done += k
+            e1.finish()
+            ok1 = same(p1, e1)
+            stats["graphs"] += int(use_graph > 0)
+            # (2) rewind: a few iterations, parameters put back, start again
+            p2 = T(sc["params"])
+            e2 = engine(p2, sc["lr_mult"])
+            e2.run(int(rng.randint(1, n))); e2.finish()
+            if rng.rand() < 0.5 or optimizer == "adam":  # (a plain rewind keeps Adam's moments: only new_observation restarts them)
+                e2.new_observation(params=T(sc["params"]))
+            else:
+                p2.copy_(T(sc["params"])); e2.rewind(0)
+            e2.run(); e2.finish()
+            ok2 = same(p2, e2)
+            stats["rewinds"] += 1
+            # (3) another observation in between, then back
+            sc_b = make_scene(rows, cols, H, W, B=B, dist=float(rng.uniform(1.2, 5.0)), seed=seed0 + case, textured=sc["textured"], rot_deg=3.0)
+            e1.new_observation(gt={k: T(v) for k, v in sc_b["gt"].items()}, params=T(sc_b["params"]))
+            e1.run(int(rng.randint(1, n + 1))); e1.finish()
+            e1.new_observation(gt=gt, params=T(sc["params"]))
+            e1.run(); e1.finish()
+            ok3 = same(p1, e1)
+            stats["observations"] += 1
+            # (4) two shards with the unsharded run's slice counts
+            cut = int(rng.randint(1, B))
+            ss, es = ref.slices
+            pa, pb = T(sc["params"][:, :cut]), T(sc["params"][:, cut:])
+            ea = engine(pa, sc["lr_mult"], 0, cut, global_batch=B, shade_slices=ss, edge_slices=es)
+            eb = engine(pb, sc["lr_mult"], cut, B, global_batch=B, shade_slices=ss, edge_slices=es)
+            ea.run(); eb.run(); ea.finish(); eb.finish()
+            ok4 = torch.equal(torch.cat([pa, pb], 1), want[0]) and torch.equal(torch.cat([ea.losses(), eb.losses()], 2), want[1])
+            stats["shards"] += 1
+            if not (ok1 and ok2 and ok3 and ok4):
+                bad += 1
+                print("MISMATCH", tag, "pieces/graphs", ok1, "(graph", use_graph, ") rewind", ok2, "observation", ok3, "shards", ok4, "cut", cut)
+        except Exception as e:
+            bad += 1
+            print("ERROR", tag, repr(e))
+    if verbose:
+        print(f"{n_cases} state cases, {bad} bad, {time.time() - t_start:.0f} s", stats)
+    return bad, stats
+
+
 def sweep_api(n_cases=60, seed0=0, verbose=True):
     """DiffDope.run_optimization through the fused engine and through the op-by-op autograd path (what a user loss function
     gets) on random small scenes and loss sets: the logged losses of iteration 0 agree tightly (same parameters), the run as a
@@ -506,6 +588,9 @@ def sweep_api(n_cases=60, seed0=0, verbose=True):
 
 
 if __name__ == "__main__":
+    if os.environ.get("FUZZ_STATE"):
+        sweep_state(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        sys.exit(0)
     if os.environ.get("FUZZ_API"):
         sweep_api(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
         sys.exit(0)
