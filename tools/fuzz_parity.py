@@ -25,6 +25,8 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
             rows, cols = int(rng.randint(30, 110)), int(rng.randint(40, 140))
             H, W = int(rng.randint(200, 500)), int(rng.randint(250, 660))
         dist = float(np.exp(rng.uniform(np.log(0.9), np.log(9.0))))
+        if os.environ.get("FUZZ_FAR"):  # out to and beyond the far plane (zfar = 200): specks, far clipping per fragment
+            dist = float(np.exp(rng.uniform(np.log(5.0), np.log(260.0))))
         textured = bool(rng.randint(2))
         B = int(rng.randint(1, 6)) if not os.environ.get("FUZZ_BIG") else int(rng.randint(2, 40))
         names = [k for k in KEYS if rng.rand() < 0.6] or ["mask"]
