@@ -95,7 +95,9 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                 loss = loss + (masked_l1_mean(out["mask"], gtt["segmentation"]) * lrm).mean()
                 loss.backward()
                 gm = np.stack([p_.grad.cpu().numpy() for p_ in pl])
-                mat_ok = np.array_equal(out["rast_out"][..., 3].detach().cpu().numpy(), r2["rast"][..., 3])
+                # (ids: the matrices of this path come from the device's pose op and torch's matmul, the oracle's from numpy: a last-bit
+                # difference in a clip coordinate can hand an exact-edge pixel to the neighbouring triangle -- seed 5001213, one pixel)
+                mat_ok = int((out["rast_out"][..., 3].detach().cpu().numpy() != r2["rast"][..., 3]).sum()) <= 2
                 for k in ("rgb", "depth", "mask"):
                     # (the clip-space vertices come from torch's proj @ mtx here, the oracle's from numpy's: last-bit differences that
                     # a sliver pixel's barycentrics amplify -- seed 702717: one pixel off by 1.6e-4; hence the median-tight, max-loose pair)
