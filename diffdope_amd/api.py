@@ -205,16 +205,21 @@ class Camera:
 
 
 class Mesh(torch.nn.Module):
-    """Mesh tensors for the renderer (diffdope.py:746-935).  `path_model` is a PLY file (with
-    `texture_u/texture_v` + `comment TextureFile` for a textured model, or per-vertex colours); or build one
-    from arrays with Mesh.from_arrays."""
+    """Mesh tensors for the renderer (diffdope.py:746-935).  `path_model` is a PLY file (with `texture_u/texture_v` or
+    per-face texture coordinates + `comment TextureFile` for a textured model, or per-vertex colours) or a Wavefront OBJ
+    (`vt` + `mtllib` -> `map_Kd`); or build one from arrays with Mesh.from_arrays."""
 
     def __init__(self, path_model=None, scale=1, _arrays=None):
         super().__init__()
         self.path_model = path_model
         self.to_process = ["pos", "pos_idx", "vtx_color", "tex", "uv", "uv_idx", "vtx_normals"]
         if _arrays is None:
-            m = io_ply.read_ply(path_model)
+            if str(path_model).lower().endswith(".obj"):
+                from . import io_obj
+
+                m = io_obj.read_obj(path_model)
+            else:
+                m = io_ply.read_ply(path_model)
             tex = None
             if m["uv"] is not None and m["texture_file"] is not None:
                 from PIL import Image as PILImage

@@ -276,3 +276,41 @@ def test_reference_named_viz_helpers():
     assert st.shape == (8, 10, 3) and st.dtype == np.uint8
     r0, c0, size = dd.find_crop(fg[0])
     assert r0 <= 5 and c0 <= 8 and size >= 12
+
+
+def test_obj_reader_and_mesh_class(tmp_path):
+    """Wavefront OBJ (what HOPE / YCB models ship as; the reference reads any format through trimesh): positions, per-corner
+    texture coordinates un-merged into per-vertex uv, quads, negative indices, vertex colours, the material library's map_Kd."""
+    from PIL import Image as PILImage
+
+    import diffdope_amd as dd
+    from diffdope_amd.io_obj import read_obj
+
+    PILImage.fromarray((np.random.RandomState(0).rand(8, 8, 3) * 255).astype(np.uint8)).save(tmp_path / "tex.png")
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd -s 1 1 1 tex.png\n")
+    (tmp_path / "m.obj").write_text(
+        "# a quad and a triangle sharing an edge, a uv seam on vertex 2\nmtllib m.mtl\no thing\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 0.5 0.25\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.25 0.75\nvt 0.5 0.5\n"
+        "vn 0 0 1\ns 1\nusemtl a\ng part\n"
+        "f 1/1/1 2/2/1 3/3/1 4/4/1\n"
+        "f -4/2/1 5/6/1 -3/5/1\n")
+    m = read_obj(str(tmp_path / "m.obj"))
+    assert m["faces"].shape == (3, 3) and m["faces"].dtype == np.int32 and m["texture_file"].endswith("tex.png")
+    corners = m["pos"][m["faces"].reshape(-1)]
+    want = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 0, 0], [1, 1, 0], [0, 1, 0], [1, 0, 0], [2, 0.5, 0.25], [1, 1, 0]], np.float32)
+    np.testing.assert_array_equal(corners, want)
+    want_uv = np.array([[0, 0], [1, 0], [1, 1], [0, 0], [1, 1], [0, 1], [1, 0], [0.5, 0.5], [0.25, 0.75]], np.float32)
+    np.testing.assert_array_equal(m["uv"][m["faces"].reshape(-1)], want_uv)
+    assert len(m["pos"]) == 6  # vertex 3 (1-based) appears with two texture coordinates: (1,1) and (0.25,0.75)
+    np.testing.assert_array_equal(m["normals"], np.tile([[0, 0, 1]], (6, 1)).astype(np.float32))
+    mesh = dd.Mesh(path_model=str(tmp_path / "m.obj"))
+    assert mesh.has_textured_map and tuple(mesh.tex.shape) == (8, 8, 3) and tuple(mesh.uv.shape) == (6, 2)
+    np.testing.assert_allclose(mesh.uv[:, 1].numpy(), 1 - m["uv"][:, 1])  # diffdope.py:822
+    # vertex colours (the "v x y z r g b" extension), no texture
+    (tmp_path / "c.obj").write_text("v 0 0 0 1 0 0\nv 1 0 0 0 1 0\nv 0 1 0 0 0 1\nf 1 2 3\n")
+    c = read_obj(str(tmp_path / "c.obj"))
+    np.testing.assert_array_equal(c["colors"], np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255]], np.uint8))
+    assert c["uv"] is None and c["texture_file"] is None
+    mesh2 = dd.Mesh(path_model=str(tmp_path / "c.obj"))
+    assert not mesh2.has_textured_map and tuple(mesh2.vtx_color.shape) == (3, 3)
