@@ -320,6 +320,30 @@ def test_engine_eval_pass_gradient_against_oracle_and_torch_optimizer(weights):
     assert float(val.detach()) < 0.7 * first
 
 
+@pytest.mark.parametrize("rows,cols,H,W,B,dist", [(700, 720, 1080, 1920, 3, 2.2), (120, 160, 2160, 3840, 2, 1.6)])
+def test_engine_at_the_large_end(rows, cols, H, W, B, dist):
+    """A million triangles at 1080p, and a 4K frame (the upper end of what ddx_engine_create accepts is 4096 x 4096): all four
+    loss terms and the pose gradient against the oracle, three iterations without a status flag, index arithmetic included."""
+    sc = make_scene(rows, cols, H, W, B=B, dist=dist, tex_size=512)
+    assert len(sc["tri"]) in (1008000, 38400) and sc["coverage"] > 0.1
+    w = dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.5)
+    R = sc["oracle"]
+    R.weights = w
+    total, logs, g_ref, _ = R.loss_and_grad(sc["params"], sc["lr_mult"])
+    eng, params = _engine(sc, w, [0.05, 0.05, 0.05])
+    losses, grad = eng.loss_and_grad()
+    torch.cuda.synchronize()
+    lg = losses.cpu().numpy()
+    for i, key in enumerate(KEYS):
+        np.testing.assert_allclose(lg[i], logs[key], rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-3, atol=1e-4 * np.abs(g_ref).max())
+    eng.run()
+    eng.finish()
+    st = eng.check()
+    assert st["it"] == 2 and st["active_tiles"] > 1000 and np.isfinite(params.cpu().numpy()).all()
+    assert float(eng.losses()[2].sum()) < float(eng.losses()[0].sum())
+
+
 def test_mesh_with_more_vertices_than_triangles():
     """Deviation D6: a mesh un-merged per wedge (V = 3 T > T, what a PLY with per-face uv becomes).  The reference's tensor of
     ones has T rows; here coverage is interpolated per vertex.  Fused engine, fused and op-by-op materialising paths all agree
