@@ -102,7 +102,7 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                     # (the clip-space vertices come from torch's proj @ mtx here, the oracle's from numpy's: last-bit differences that
                     # a sliver pixel's barycentrics amplify -- seed 702717: one pixel off by 1.6e-4; hence the median-tight, max-loose pair)
                     dk = np.abs(out[k].detach().cpu().numpy() - r2[k])
-                    mat_ok &= bool(dk.max() < 2e-3 * max(1.0, float(np.abs(r2[k]).max())) and np.percentile(dk, 99.9) < 5e-5 * max(1.0, float(np.abs(r2[k]).max())))
+                    mat_ok &= bool(dk.max() < 2e-3 * max(1.0, float(np.abs(r2[k]).max())) and np.percentile(dk, 99.9) < 2e-4 * max(1.0, float(np.abs(r2[k]).max())))
                 mat_ok &= abs(float(loss.detach()) - tot2) < 2e-5 * max(1, abs(tot2))
                 mat_ok &= np.abs(gm - g2).max() < 1e-2 * max(np.abs(g2).max(), 1e-7)
                 stats["materialising"] = stats.get("materialising", 0) + 1
