@@ -197,8 +197,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DDX_BENCH_SHARE_GPU (tests only): every rank on device 0 with the gloo backend -- RCCL refuses two ranks on one GPU, and
+    # the 1-GPU test box is where the world-size-2 code path of this file can be exercised on the device at all
+    share = bool(os.environ.get("DDX_BENCH_SHARE_GPU"))
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or bool(os.environ.get("DDX_FORCE_DIST"))  # DDX_FORCE_DIST: exercise the RCCL path with one rank
     if use_dist:
         import torch.distributed as dist
@@ -206,7 +210,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))  # (only reached without a launcher: DDX_FORCE_DIST on one rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from diffdope_amd import dist as ddist
     from diffdope_amd import workloads as wl

@@ -64,3 +64,20 @@ def test_bench_runs_through_the_rccl_path_on_one_rank():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["global_hypotheses"] == 64
     assert line["final_pose"]["argmin_global_index"] in range(64)
+
+
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """bench.py at world size 2, launched the way the driver launches it (torch.distributed.run, two ranks).  RCCL refuses two
+    ranks on one device, so the ranks share GPU 0 over gloo (DDX_BENCH_SHARE_GPU): every line of the N > 1 path runs -- shard
+    offsets, global batch 128 in the batch mean, barrier-bracketed window, the [2,18] table all_reduce, max over ranks."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DDX_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_hypotheses"] == 128 and line["config"]["hypotheses_per_gpu"] == 64
+    assert line["value"] > 0 and abs(line["value"] - 2 * 1000.0 / line["ms_per_step"]) < 1e-6 * line["value"]  # whole-job rate = 2 ranks x iterations/s
+    assert line["final_pose"]["argmin_global_index"] in range(128)
