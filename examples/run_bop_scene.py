@@ -27,10 +27,11 @@ from diffdope_amd import api, bop, synthetic as syn  # noqa: E402
 
 def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    share = bool(os.environ.get("DDX_BENCH_SHARE_GPU"))  # (tests: two ranks on the one GPU of the test box, over gloo)
+    torch.cuda.set_device(0 if share else int(os.environ.get("LOCAL_RANK", 0)))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl")
+        torch.distributed.init_process_group("gloo" if share else "nccl")
     H, W = 240, 320
     intr = syn.camera_intrinsics(W, H)
     cam = dd.Camera(**intr)

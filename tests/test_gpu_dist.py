@@ -81,3 +81,20 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_hypotheses"] == 128 and line["config"]["hypotheses_per_gpu"] == 64
     assert line["value"] > 0 and abs(line["value"] - 2 * 1000.0 / line["ms_per_step"]) < 1e-6 * line["value"]  # whole-job rate = 2 ranks x iterations/s
     assert line["final_pose"]["argmin_global_index"] in range(128)
+
+
+def test_multi_object_frame_with_two_ranks_sharing_the_gpu():
+    """examples/run_bop_scene.py (bop.refine_frame: objects sharded over ranks, one all_reduce of the object table) with two ranks on
+    the one GPU over gloo: the same poses as the single-process run, every object's owner reported."""
+    ex = os.path.join(ROOT, "examples", "run_bop_scene.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, ex], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), ex]
+    two = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, DDX_BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    a = [l.split("(owner")[0] for l in one.stdout.splitlines() if l.startswith("object ")]
+    b = [l.split("(owner")[0] for l in two.stdout.splitlines() if l.startswith("object ")]
+    assert len(a) == 3 and a == b  # same arg-min hypothesis, loss and pose errors, digit for digit
+    owners = [l.split("(owner rank ")[1].rstrip(")") for l in two.stdout.splitlines() if l.startswith("object ")]
+    assert owners == ["0", "1", "0"]
