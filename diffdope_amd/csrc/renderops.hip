@@ -303,8 +303,9 @@ __global__ __launch_bounds__(256) void antialias_kernel(const float* __restrict_
     };
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
+    bool need_drain = false;
     for (int x0 = 0; x0 < W; x0 += 256) {  // (workgroup-uniform)
-        if (s_n > AA_QUEUE - 2 * AA_ROWS * 256) drain();  // (uniform: s_n only changes between barriers)
+        if (need_drain) drain();  // (uniform: decided between the two barriers at the end of the previous round)
         const int px = x0 + threadIdx.x;
         const bool inx = px < W;
         float id[AA_ROWS + 1];  // own rows and the row above the last
@@ -325,6 +326,10 @@ __global__ __launch_bounds__(256) void antialias_kernel(const float* __restrict_
                 if (t0 != t1 && t0 < T && t1 < T) s_pair[atomicAdd(&s_n, 1)] = ((unsigned)r << 17) | ((unsigned)px << 1) | 1u;
             }
         }
+        // every thread reads the queue length BETWEEN two barriers: no wave pushes into the next round before all waves have
+        // taken the same decision (a wave that read s_n late could otherwise enter drain() -- which has barriers -- alone)
+        __syncthreads();
+        need_drain = s_n > AA_QUEUE - 2 * AA_ROWS * 256;
         __syncthreads();
     }
     drain();
