@@ -34,8 +34,7 @@ def algorithmic_bytes(V, T, HW, B):
     """SURVEY.md section 8(d), fp32/int32 'visibility-buffer model', bytes per LAUNCH (all B hypotheses).  Kept as
     `roofline.model_8d` for continuity: it counts full-frame G-buffer streams this engine never moves."""
     return {
-        "update_xfm_kernel": (12.0 * V + 16.0 * V) * B + 212.0 * B,
-        "raster_stage": (16.0 * V + 12.0 * T + 16.0 * HW) * B,
+        "step_kernel": (12.0 * V + 16.0 * V) * B + 212.0 * B + (16.0 * V + 12.0 * T + 16.0 * HW) * B,  # xfm + raster rows
         "shade_kernel": (32.0 * HW + 60.0 * V) * B + 40.0 * HW,
         "iteration": (104.0 * V + 12.0 * T + (48.0 + 40.0 / B) * HW) * B,
     }
@@ -46,24 +45,24 @@ def compulsory_bytes(V, T, HW, B, active_tiles, covered_px, textured, n_roles, s
     once, at the 64-byte granularity of the memory-side requests, nothing for what stays in L2 between kernels being
     optimistic.  active_tiles = 16x16 tiles with any coverage summed over the hypotheses (engine status), covered_px =
     covered pixels summed over the hypotheses (coverage x HW x B).
-      scatter : snap 8 B x V x B read, trisort 16 B x T read (shared by the hypotheses), clip 16 B x V x B read, zbuf
+      step    : partial rows read (every workgroup of a hypothesis reads them: L2 hits after the first), the meshlet tables
+                (16 B per vertex slot ~ 1.2 V, 8 B per triangle; static, shared by the hypotheses), clip 16 B + snap 8 B per
+                vertex and hypothesis WRITTEN (read back by the mask role only for silhouette triangles: not counted), zbuf
                 atomics 8 B x 2 fragments per covered pixel (front + back faces) as 64-B sectors of the 4x4-pixel blocks
-                => active_tiles x 256 x 8 B read-modify-write
-      shade   : zbuf 8 B x 256 per active tile (read once; both roles hit the same lines), triangle records 64 B x T
-                (static table, shared), observed rgb + seg 24 B/px of the tiles one hypothesis touches (shared), texels: ONE
-                64-byte record per covered pixel (the engine's texq layout: the whole 2x2 bilinear footprint in one sector;
-                no reuse across hypotheses: 3 500 samples spread over a 268 MB table), partial rows written
-      update  : partial rows read, spos 12 B x V read once per hypothesis, clip 16 B + snap 8 B per vertex written, zbuf
-                re-arm 8 B x 256 per active tile written
+                => active_tiles x 256 x 8 B read-modify-write, zbuf re-arm 8 B x 256 per active tile written
+      shade   : the tile-flag rows (NT bytes per hypothesis), zbuf 8 B x 256 per active tile (read once; both roles hit the
+                same lines), triangle records 64 B x T (static table, shared), observed rgb + seg 24 B/px of the tiles one
+                hypothesis touches (shared), texels: ONE 64-byte record per covered pixel (the engine's texq layout: the whole
+                2x2 bilinear footprint in one sector; no reuse across hypotheses: 3 500 samples spread over a 268 MB table),
+                partial rows written
     """
     tiles_one = active_tiles / max(B, 1)
-    part = B * shade_slices * 4 * n_roles * 96.0
+    part = B * shade_slices * n_roles * 96.0
     tex = 64.0 * covered_px if (textured and (uses["rgb"] or uses["edge"])) else 0.0
     gt = tiles_one * 256 * (12.0 + (12.0 if uses["rgb"] else 0.0) + (4.0 if uses["depth"] else 0.0))
     out = {
-        "scatter_kernel": (8.0 + 16.0) * V * B + 16.0 * T + 2 * active_tiles * 256 * 8.0,
-        "shade_kernel": active_tiles * 256 * 8.0 + (64.0 if textured else 80.0) * T + gt + tex + part,
-        "update_xfm_kernel": part + (12.0 + 16.0 + 8.0) * V * B + active_tiles * 256 * 8.0,
+        "step_kernel": part + 16.0 * 1.2 * V + 8.0 * T + (16.0 + 8.0) * V * B + 3 * active_tiles * 256 * 8.0,
+        "shade_kernel": B * HW / 256.0 + active_tiles * 256 * 8.0 + (64.0 if textured else 80.0) * T + gt + tex + part,
     }
     out["iteration"] = sum(out.values())
     return out
@@ -286,11 +285,11 @@ def main():
         # the event-bracketed durations sum to more than the iteration itself.  The timed region above IS the four kernels
         # back to back (rocprofv3: they sum to the iteration within 1 us, profiles/), so each kernel's share of the timed
         # iteration is its event-measured share: kernel_ms = kernel_ms_events * ms_per_step / sum(kernel_ms_events).
-        ev_scale = min(1.0, ms_per_step / max(sum(kms_ev.values()), 1e-9))
-        kms = {k: v * ev_scale for k, v in kms_ev.items()}
-        raster_ms = sum(kms[k] for k in ("scatter_kernel", "compact_big_kernel"))
-        groups = {"raster_stage": raster_ms, "shade_kernel": kms["shade_kernel"], "update_xfm_kernel": kms["update_xfm_kernel"]}
-        dom = max(("shade_kernel", "scatter_kernel"), key=lambda k: kms[k])
+        per_it = [k for k in kms_ev if k != "finish_kernel"]  # (finish_kernel runs once per run, not per iteration)
+        ev_scale = min(1.0, ms_per_step / max(sum(kms_ev[k] for k in per_it), 1e-9))
+        kms = {k: v * (ev_scale if k in per_it else 1.0) for k, v in kms_ev.items()}
+        groups = {"step_stage": kms["step_kernel"] + kms["big_pass_kernel"], "shade_stage": kms["shade_kernel"] + kms["edge_kernel"]}
+        dom = max(("shade_kernel", "step_kernel"), key=lambda k: kms[k])
         dom_s = kms[dom] * 1e-3
         # ---- counters of the committed rocprofv3 --pmc passes for THIS workload (profiles/summarize_sq.py; separate passes,
         # kernel trace only): wave-level VALU instructions and HBM-side bytes per launch.  null if no pass matches.
@@ -305,7 +304,7 @@ def main():
         n_roles = int(uses["rgb"] or uses["depth"] or uses["edge"]) + int(uses["mask"])
         comp = compulsory_bytes(V, T, HW, Bl, r["status"]["active_tiles"], w["coverage"] * HW * Bl, w["tex"] is not None,
                                 max(n_roles, 1), r["eng"].slices[0], uses)
-        model_bytes = alg["shade_kernel"] if dom == "shade_kernel" else alg["raster_stage"]
+        model_bytes = alg[dom]
         # The dominant kernels are bound by dependent-latency chains and VALU issue, not by DRAM (traffic_frac below), so the
         # roofline of record is VALU issue: wave-level VALU instructions per launch (PMC) / live launch duration against
         # 1228.8 G wave-instructions/s.  `hbm` holds the byte view (work-proportional compulsory bytes, PMC traffic).

@@ -2,14 +2,23 @@
 //
 // One call of ddx_engine_run(it0, n) executes n iterations of DiffDope.run_optimization's loop body
 // (diffdope/diffdope.py:1656-1714) for B pose hypotheses with the built-in losses
-// (diffdope.py:547-613), entirely on the device:
+// (diffdope.py:547-613), entirely on the device.  An iteration is THREE launches:
 //
-//   pose_xfm_kernel  q/|q|, [R|t] (diffdope.py:46-89,1085-1098), final = proj . mtx (:195), mtx log,
-//                  clip = final . [pos;1] on the matrix core (MFMA 4x4x1, as xfm.hip) (:196), and the
-//                  1/256-pixel window-coordinate snap of every vertex
-//   scatter/scan/fill/raster_big   per-triangle scatter rasteriser with a binned path for large
-//                  triangles (raster.hip) -> zbuf (depth key, id), active-tile list    (:198)
-//   shade_kernel   per pixel of the active tiles, in registers: barycentrics, uv/colour/position
+//   step_kernel    workgroup = (meshlet, hypothesis).  Head (every workgroup of a hypothesis, redundantly -- a few KB from L2):
+//                  the optimiser step of the PREVIOUS iteration: fixed-order sum of the hypothesis' partial rows, whole-frame
+//                  constants for the pixels outside the active tiles, proj^T chain, quaternion chain, SGD/Adam, loss log
+//                  (diffdope.py:558,576,604,1713-1714).  Then, with the new pose: q/|q|, [R|t] (diffdope.py:46-89,1085-1098),
+//                  final = proj . mtx (:195), and the workgroup's MESHLET -- up to 512 triangles and the <= 512 vertices they
+//                  use, a static table -- goes through the pipeline without leaving the CU: clip = final . [pos;1] on the matrix
+//                  core (MFMA 4x4x1, as xfm.hip) (:196) and the 1/256-pixel window snap into LDS, then the per-triangle scatter
+//                  rasteriser (raster_dev.h) reads its vertices from LDS: exact integer coverage, fp32 depth, 64-bit atomicMin
+//                  of (depth key, id) into zbuf, byte flags for the touched 16x16 tiles, large / near-clipped triangles to the
+//                  hypothesis' list (:198).  Each vertex is also stored once to clip / snap in HBM (by the meshlet that owns
+//                  it) for the antialias pass and the tile pass.  zbuf, the tile flags and the large-triangle counters exist
+//                  twice, by iteration parity: while drawing iteration i the workgroups re-arm what iteration i - 1 dirtied.
+//   big_pass_kernel  the tile pass for large triangles; exits on one scalar load when the batch has none.
+//   shade_kernel   every wave scans its hypothesis' tile-flag row (no list kernel, no atomics) and takes the tiles of its
+//                  slice; per pixel of the active tiles, in registers: barycentrics, uv/colour/position
 //                  interpolation (:203,:218,:230), bilinear texture (:221), depth (:204-209),
 //                  antialiased coverage (:212-214), the three L1 terms against the observed images,
 //                  AND the whole analytic backward down to d loss / d(final, mtx) -- the per-pixel
@@ -17,33 +26,26 @@
 //                  backward are one pass and no G-buffer (rast, gb_pos, texc, color, mask: 1.1 GB per
 //                  iteration at 64 x 640x480 in the reference) is ever written.  Vertex gradients are
 //                  contracted with [pos;1] in registers (the xfm_bwd_mtx product, mesh.cu:165-214),
-//                  reduced per workgroup and written as one 24-float partial per tile: no atomics,
+//                  reduced per workgroup and written as one 24-float partial row per (slice, role): no atomics,
 //                  bit-reproducible.
 //   edge_kernel    (edge extension only) Sobel-gradient L1 of the rendered luminance against the observed image, from the
 //                  luminance + unit gradients the colour role of shade_kernel wrote; owner-computes, texture-free
-//   update_xfm_kernel  per hypothesis: fixed-order sum of its quadrant partials, whole-frame constants for the
-//                  pixels outside the active tiles, proj^T chain, quaternion chain, SGD/Adam step,
-//                  loss log (diffdope.py:558,576,604) -- and, with the new pose, the NEXT iteration's
-//                  matrices, clip-space vertices (MFMA) and window-coordinate snap, so an iteration is
-//                  4 launches: scatter, compact_big, shade, update_xfm.
+// and finish_kernel (the head of step_kernel alone) closes a run with the optimiser step of its last iteration.
 //
 // Whole-frame semantics without whole-frame work: a pixel outside every active tile renders
 // rgb = 0, mask = 0, depth = -mtx[2][3], so its loss terms are
 // |gt*seg|, |seg| and |(-t_z - gt_d) seg0|.  The first two are constants of the observed images
-// (summed once at engine creation); the third is evaluated per hypothesis and iteration over the
-// compacted list of pixels with seg0 != 0.  Pixels of active tiles add (actual - background) terms.
+// (summed once at engine creation); the third is evaluated per hypothesis and iteration from the depth-sorted
+// list of pixels with seg0 != 0.  Pixels of active tiles add (actual - background) terms.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
-#ifdef DDX_TRACE
 #include <cstdio>
-#include <vector>
-#endif
 
-#include "raster.h"
+#include "raster_dev.h"
 
 #define NPART 24  // floats per tile partial: 12 dFinal(x,y,w rows) | 4 dMtx row 2 | 4 losses (rgb, depth, mask, edge) | pad
 #define NVALS 20  // of which are used
@@ -57,25 +59,31 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int overflow;
     int last_pairs;
     int last_active;
-    int it;          // iteration index of the running iteration
+    int it;          // iteration the next step_kernel draws (written by one lane of shade_kernel, read by step / finish)
     int n_seg;       // entries in the compact seg list
-    int it_next;     // written by update_xfm_kernel (one lane), copied into `it` by the next shade_kernel (one lane)
-    int outside;     // hypotheses of the last iteration with a vertex outside the view volume (w <= 0 or |z| > w): their triangles
-                     // at w <= 0 were clipped at the near plane by the tile pass and their back faces drawn (D5 off)
+    int it_next;     // iteration being drawn + 1 (written by one lane of step_kernel, read by big_pass / shade / edge): no kernel
+                     // reads a word that the same launch writes
+    int outside;     // hypotheses of the last iteration whose bounding box left the view volume (w <= 0 or |z| > w at a corner):
+                     // their triangles at w <= 0 were clipped at the near plane by the tile pass and their back faces drawn (D5 off)
     int pad[1];
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
     double c_edge;   // sum over the frame of |Gx| + |Gy| of the observed, masked image (edge extension)
 };
 
+// step_kernel(mode): STEP_FIRST draws the first iteration of a run from the caller's parameters (no optimiser step);
+// STEP_NORMAL steps the optimiser for iteration it - 1 and draws iteration it
+enum { STEP_FIRST = 0, STEP_NORMAL = 1 };
+
 struct EngineDev {
     ddx_engine_desc d;
     ddx_engine_buffers b;
-    RasterScratch L;
-    float* clip;      // [B,V,4] (rasteriser and mask role; the colour role recomputes its vertices from crec)
+    RasterScratch L;  // two parities (npar = 2) of zbuf / tile flags / large-triangle counters
+    float* clip;      // [B,V,4] clip-space vertices in sorted vertex order, stored once per vertex by the meshlet that owns it
+                      // (read by the mask role and the tile pass; the colour role recomputes its vertices from crec)
     float* mats;      // [2][B,2,16]: mtx | final, by iteration parity
     float* params2;   // [2][7,B]: the parameters, by iteration parity (b.params is the user-visible copy)
-    float* partials;  // [B*NT*4*NR, NPART]: per 8x8 quadrant and shade role, index ((b*NT + tile)*4 + quadrant)*NR + role, NR = 2 (3 with the edge role)
+    float* partials;  // [B, pslices, NR, NPART]: one row per slice (workgroup of the shade / edge grid) and role, NR = 2 (3 with the edge role)
     float2* gtedge;   // [H*W] Sobel gradients of lum(gt_rgb * seg) (edge extension), or null
     float* lumbuf;    // [B,H*W] luminance of the rendered colour at covered pixels (written by the colour role, read by
     float* ubuf;      // [B,H*W,12] edge_kernel; garbage where zbuf says "background") and U = d lum / d final per pixel
@@ -97,10 +105,25 @@ struct EngineDev {
     int* stri;        // [T,3] triangles (original triangle order) with sorted vertex ids
     int* vnew;        // [V] old vertex id -> sorted id
     int* vold;        // [V] sorted id -> old vertex id
-    int4* trisort;    // [T] {v0,v1,v2,id}: triangles in Morton order of their object-space centroids (scatter_kernel's processing order)
+    // MESHLETS: the triangles in Morton order of their object-space centroids, cut into runs of at most mesh_ntri triangles that
+    // use at most mesh_nvc distinct vertices (fixed-size slots, so a workgroup's loads do not depend on a header):
+    float4* mvert;    // [M, mesh_nvc] (x, y, z, bits): object-space position; bits = sorted vertex id | owner << 31, or all ones
+                      // for an unused slot.  Every referenced vertex is owned by exactly one meshlet (the first that uses it).
+    int2* mtri;       // [M, mesh_ntri] (l0 | l1 << 10 | l2 << 20 local vertex slots, original triangle id or -1 for an unused slot)
+    int n_meshlets, mesh_ntri, mesh_nvc;
+    int scatter_mode; // scatter_resolve MODE of the dense variant: 0 plain, 2 hybrid, 3 compacting (the small-mesh variant is MODE 1)
+    // Back-face culling for CLOSED meshes (deviation D5).  A closed, consistently oriented surface that lies
+    // entirely inside the view volume covers every pixel centre with as many front- as back-facing triangles, and the nearest one
+    // is front-facing: skipping the back faces changes nothing in exact arithmetic and halves the fragments.  cull_sign: 0 = off;
+    // +1 / -1 = triangles whose SNAPPED area has this sign are back faces (sign(signed volume) * sign(det of proj's x,y,w rows),
+    // decided once per engine on the host).  A hypothesis culls only while the 8 corners of the mesh's object-space bounding box
+    // (bbox), transformed like vertices, all have w > 0 and -w <= z <= w -- then so has every vertex (the three conditions are
+    // half-spaces of object space) and the drawn surface is closed.
+    int cull_sign;
+    float bbox[6];    // lo x,y,z, hi x,y,z over all vertices (cull_sign = 0 if any coordinate is not finite)
+    int* inside;      // [B] the box test of the iteration last drawn (status only)
     float4* crec;     // [T,4] (textured) or [T,5] (vertex colours): what the colour role needs of a covered triangle, in ONE
                       // record fetched by triangle id: object-space positions of the 3 vertices (9), then uv (6) or colours (9)
-    int* cull_ok;     // [B,8] per vertex slice of the transform: every vertex inside the view volume (RasterScratch::cull_ok)
     int4* trirec;     // [T,2] {v0,v1,v2,opp0} {opp1,opp2,0,0}: one record per triangle for the antialias pass
     float4* texq;     // [Th*Tw,4] the texture as one 64-byte record per texel (x,y): the 2x2 bilinear footprint whose corner it
                       // is -- (x,y), (x+1,y), (x,y+1), (x+1,y+1) with wrap, rgb each, 4 floats of padding -- or null.  A
@@ -115,11 +138,8 @@ struct EngineDev {
     int s_shade, s_edge;     // slices per hypothesis of shade_kernel / edge_kernel (grid y)
     int pslices;             // rows of the partial table per hypothesis: max(s_shade, s_edge) slices
     float* eval_grad;        // [7,B] or null.  Non-null = evaluation pass (ddx_engine_eval): d loss / d params and the
-    float* eval_loss;        // [4,B] losses are written here, no optimiser step, no transform for a next iteration
+    float* eval_loss;        // [4,B] losses are written here, no optimiser step
     float* eval_tmp;         // [7,B] gradient sink of ddx_render_loss_fwd
-#ifdef DDX_TRACE
-    unsigned long long* trace;  // [4 kernels][8192 workgroups][4]: start, end (s_memtime), hw id, work units
-#endif
 };
 
 struct ddx_engine {
@@ -128,11 +148,23 @@ struct ddx_engine {
     hipGraphExec_t exec = nullptr;
     int graph_chunk = 1;  // iterations per captured graph
     bool setup_done = false;
-    bool mesh_done = false;  // the mesh half of the setup (sorted copies, triangle / texel records, closedness) survives ddx_engine_new_observation
+    bool mesh_done = false;  // the mesh half of the setup (sorted copies, meshlets, triangle / texel records, closedness) survives ddx_engine_new_observation
+    bool small_mesh = false; // step_kernel variant: one triangle per lane in 64-thread workgroups (few triangles x hypotheses)
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
+
+// meshlet geometry of the two step_kernel variants (triangles, vertex slots): dense = (2, 256), small = (1, 64) threads
+static inline void mesh_geometry(bool small_mesh, int& ntri, int& nvc)
+{
+    ntri = small_mesh ? 64 : 512;
+    nvc = small_mesh ? 128 : 512;
+}
+
+// small meshes: 512-triangle meshlets would leave most of the chip without a workgroup (a 384-triangle CAD model x 64
+// hypotheses = 64 workgroups)
+static inline bool mesh_is_small(const ddx_engine_desc& d) { return (long long)ddx_cdiv(d.T, 512) * d.B < 1024; }
 
 // ---------------------------------------------------------------------------------------------
 static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
@@ -145,21 +177,27 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     };
     char* p = (char*)base;
     const size_t o_state = carve(sizeof(EngineState));
-    // per-hypothesis state that update_xfm_kernel both reads and writes is double-buffered by iteration parity:
-    // its workgroups (8 slices per hypothesis) read buffer it&1 and slice 0 writes buffer (it+1)&1, so a slice
-    // that starts late can never see the next iteration's values
+    // per-hypothesis state that the optimiser step both reads and writes is double-buffered by iteration parity: every
+    // workgroup of a hypothesis reads buffer it & 1 and one of them writes buffer (it + 1) & 1, so a workgroup that starts late
+    // can never see the next iteration's values
     const size_t o_mats = carve((size_t)2 * d.B * 32 * sizeof(float));
     const size_t o_adam = carve((size_t)2 * 14 * d.B * sizeof(float));
     const size_t o_par = carve((size_t)2 * 7 * d.B * sizeof(float));
     const size_t o_etmp = carve((size_t)7 * d.B * sizeof(float));
-    const size_t o_cull = carve((size_t)d.B * 8 * sizeof(int));
+    const size_t o_inside = carve((size_t)d.B * sizeof(int));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_sgd = carve(d.use_depth ? (size_t)d.H * d.W * sizeof(float) : 0);
     const size_t o_sW = carve(d.use_depth ? ((size_t)d.H * d.W + 1) * sizeof(double) : sizeof(double));
     const size_t o_sG = carve(d.use_depth ? ((size_t)d.H * d.W + 1) * sizeof(double) : sizeof(double));
     const size_t o_rec = carve((size_t)d.T * 2 * sizeof(int4));
-    const size_t o_perm = carve((size_t)d.T * sizeof(int4));
+    // meshlets: a run closes at mesh_ntri triangles or mesh_nvc vertices; a triangle brings at most 3 new vertices, so runs
+    // that close on the vertex limit hold at least (mesh_nvc - 2) / 3 triangles: M <= T / ((nvc - 2) / 3) + T / ntri + 1
+    int ntri, nvc;
+    mesh_geometry(mesh_is_small(d), ntri, nvc);
+    const size_t Mmax = (size_t)d.T / ((nvc - 2) / 3) + (size_t)d.T / ntri + 2;
+    const size_t o_mvert = carve(Mmax * nvc * sizeof(float4));
+    const size_t o_mtri = carve(Mmax * ntri * sizeof(int2));
     const size_t o_crec = carve((size_t)d.T * 5 * sizeof(float4));
     const size_t o_texq = carve(d.Th > 0 ? (size_t)d.Th * d.Tw * 4 * sizeof(float4) : 0);
     const size_t o_spos = carve((size_t)d.V * 3 * sizeof(float));
@@ -168,27 +206,29 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_stri = carve((size_t)d.T * 3 * sizeof(int));
     const size_t o_vnew = carve((size_t)d.V * sizeof(int));
     const size_t o_vold = carve((size_t)d.V * sizeof(int));
-    const int ntx = ddx_cdiv(d.W, DDX_TILE), nty = ddx_cdiv(d.H, DDX_TILE);
-    const size_t o_part = carve((size_t)d.B * 64 * 4 * MAX_ROLES * NPART * sizeof(float));  // per (slice <= 64, wave, role)
+    const size_t o_part = carve((size_t)d.B * 64 * MAX_ROLES * NPART * sizeof(float));  // per (slice <= 64, role)
     const size_t o_edge = carve(d.use_edge ? (size_t)d.H * d.W * sizeof(float2) : 0);
     const size_t o_lum = carve(d.use_edge ? (size_t)d.B * d.H * d.W * sizeof(float) : 0);
     const size_t o_ubuf = carve(d.use_edge ? (size_t)d.B * d.H * d.W * 12 * sizeof(float) : 0);
     const size_t o_rast = carve(0);
-    const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W);
+    const size_t rast_bytes = raster_layout(E.L, p + o_rast, d.B, d.V, d.T, d.H, d.W, 2);
     off += rast_bytes;
     E.st = (EngineState*)(p + o_state);
     E.mats = (float*)(p + o_mats);
     E.adam = (float*)(p + o_adam);
     E.params2 = (float*)(p + o_par);
     E.eval_tmp = (float*)(p + o_etmp);
-    E.cull_ok = (int*)(p + o_cull);
+    E.inside = (int*)(p + o_inside);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.seg_gd = (float*)(p + o_sgd);
     E.seg_W = (double*)(p + o_sW);
     E.seg_G = (double*)(p + o_sG);
     E.trirec = (int4*)(p + o_rec);
-    E.trisort = (int4*)(p + o_perm);
+    E.mvert = (float4*)(p + o_mvert);
+    E.mtri = (int2*)(p + o_mtri);
+    E.mesh_ntri = ntri;
+    E.mesh_nvc = nvc;
     E.crec = (float4*)(p + o_crec);
     E.texq = d.Th > 0 ? (float4*)(p + o_texq) : nullptr;
     E.spos = (float*)(p + o_spos);
@@ -337,7 +377,7 @@ __device__ __forceinline__ void pose_matrices(float q[4], const float t[3], cons
 
 // row r of final = proj . mtx, the k-ordered fma chain of pose_matrices (same bits).  The matrix-core transform wants row
 // lane % 4 of final in each lane; selecting it from a full F[16] held in registers compiles to an indexed scratch array (four
-// scratch loads in the tail of update_xfm_kernel), computing just that row from proj's row r does not.
+// scratch loads), computing just that row from proj's row r does not.
 __device__ __forceinline__ void final_row(const float pr[4], const float M[16], float Fr[4])
 {
 #pragma unroll
@@ -350,84 +390,16 @@ __device__ __forceinline__ void final_row(const float pr[4], const float M[16], 
 }
 
 // one vertex per lane on the matrix core: four v_mfma_f32_4x4x1_16b_f32 with A = row (lane%4) of final and
-// B = p[k] (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain), then the
-// 1/256-pixel window-coordinate snap.  Must be called by all 64 lanes of a wave.
-__device__ __forceinline__ void xfm_vertex_regs(const EngineDev& E, const float Fr[4] /* row lane % 4 of final */, int b, int n, bool live,
-                                                float px, float py, float pz, bool& inside /* &= vertex inside the view volume */)
+// B = p[k] (same lane mapping and k-ordered accumulation as xfm.hip / the oracle's fmaf chain).  Must be executed by all
+// 64 lanes of a wave.
+__device__ __forceinline__ f32x4 xfm_vertex_mfma(const float Fr[4] /* row lane % 4 of final */, float px, float py, float pz)
 {
-    const int V = E.d.V;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[0], px, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[1], py, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[2], pz, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_4x4x1f32(Fr[3], 1.0f, acc, 0, 0, 0);
-    if (!live) return;
-    *reinterpret_cast<f32x4*>(E.clip + ((size_t)b * V + n) * 4) = acc;
-    E.L.snap[(size_t)b * V + n] = snap_vertex(make_float4(acc.x, acc.y, acc.z, acc.w), E.d.H, E.d.W);
-    inside = inside && acc.w > 0.f && acc.z >= -acc.w && acc.z <= acc.w;  // (NaN: false)
-}
-
-// cull_ok[b][slice] = every lane of the workgroup kept `inside`.  All 256 threads must call; s_bad was zeroed before an
-// earlier barrier of the caller.
-__device__ __forceinline__ void cull_ok_store(const EngineDev& E, int* s_bad, bool inside, int b, int slice)
-{
-    if (!inside) *s_bad = 1;  // (benign race: every writer stores 1)
-    __syncthreads();
-    if (threadIdx.x == 0) E.cull_ok[(size_t)b * 8 + slice] = *s_bad ? 0 : 1;
-}
-
-// pose -> matrices -> clip-space vertices -> snapped window coordinates for the FIRST iteration of a run
-// (later iterations get theirs from update_xfm_kernel).  Grid (B, vertex slices): the slicing of update_xfm_kernel, so that
-// both leave the same per-slice view-volume flags (cull_ok).  Every lane rebuilds its hypothesis' matrices from the 7
-// parameters (uniform scalar loads, ~150 flops: cheaper than a separate launch + a dependent load).
-__global__ __launch_bounds__(256) void pose_xfm_kernel(EngineDev E, int it0 /* the iteration this run starts at */)
-{
-    const int b = blockIdx.x, slice = blockIdx.y, B = E.d.B, V = E.d.V;
-    const int tid = threadIdx.x, lane = tid & 63;
-    __shared__ int s_bad;
-    if (tid == 0) s_bad = 0;
-    float q[4], t[3], M[16], F[16], pr[4], Fr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = E.b.params[(size_t)i * B + b];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = E.b.params[(size_t)(4 + i) * B + b];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pr[k] = E.b.proj[(lane & 3) * 4 + k];
-    pose_matrices(q, t, E.b.proj, M, F);
-    final_row(pr, M, Fr);
-    if (slice == 0 && tid == 0) {
-        const int it = it0;
-        if (b == 0) {
-            E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
-            // (the iteration counters of the run: a launch of their own cost 2 us plus a host launch gap in front of every run)
-            E.st->it = it0;
-            E.st->it_next = it0;
-        }
-        E.L.bigcount[b] = 0;              // the hypothesis' list of large triangles, filled again by scatter_kernel
-        float* dst = E.mats + ((size_t)(it & 1) * B + b) * 32;
-        float* pp = E.params2 + (size_t)(it & 1) * 7 * B;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) pp[(size_t)i * B + b] = E.b.params[(size_t)i * B + b];  // un-normalised, as the user holds them
-        float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            dst[i] = M[i];
-            dst[16 + i] = F[i];
-            if (logm) logm[i] = M[i];
-        }
-    }
-    const int n_slices = (int)gridDim.y;
-    const int per = (V + n_slices - 1) / n_slices;
-    const int n_begin = slice * per, n_end = min(V, n_begin + per);
-    bool inside = true;
-    for (int n0 = n_begin; n0 < n_end; n0 += 256) {  // (workgroup-uniform trip count: every lane reaches the matrix-core ops)
-        const int n = n0 + tid;
-        const bool live = n < n_end;
-        const float* p = E.spos + (size_t)(live ? n : 0) * 3;
-        xfm_vertex_regs(E, Fr, b, n, live, p[0], p[1], p[2], inside);
-    }
-    __syncthreads();  // (s_bad = 0 is visible)
-    cull_ok_store(E, &s_bad, inside, b, slice);
+    return acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,6 +447,8 @@ __device__ __forceinline__ void acc_vertex_regs(PixAcc& A, float x, float y, flo
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4  // waves per SIMD the shade kernel is compiled for (128 VGPRs)
 #endif
+#define SCAN_U 16          // shade_kernel's flag scan: dwords per lane and chunk at most (4096 flags)
+#define SCAN_LIST 256      // ... tiles of one workgroup per chunk at most
 #define QUAD 8             // one wave shades one 8x8 quadrant of a 16x16 tile
 #define QH (QUAD + 2)      // quadrant + 1-pixel halo
 #define PAIR_CAP 160       // >= 2*64 + 8 + 8 candidate antialias pairs per quadrant
@@ -624,29 +598,12 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
 // footprint instead of the union of both.  Each role writes its own partial per quadrant.
 // The edge term (extension) is a separate, texture-free kernel (edge_kernel below): in the edge build the colour role
 // also writes the luminance and U = d lum / d final of every covered pixel.
-#if defined(DDX_TRACE) && defined(DDX_PHASES)
-#ifndef DDX_PHASE_ROLE
-#define DDX_PHASE_ROLE 0
-#endif
-#define DDX_PHASE(i)                                                           \
-    do {                                                                       \
-        if (ROLE == DDX_PHASE_ROLE) {                                          \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
-            ph[i] = __builtin_amdgcn_s_memrealtime();                          \
-        }                                                                      \
-    } while (0)
-#else
-#define DDX_PHASE(i)
-#endif
 
 // `pool`: per-wave LDS scratch owned by the kernel (one allocation shared by the roles, which are different
 // workgroups): 12 x 64 floats for the mask role, 24 x 64 for the edge role.
 template <int ROLE, int NR>
 __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict__ pool)
 {
-#if defined(DDX_TRACE) && defined(DDX_PHASES)
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
     __shared__ float s_gm[WAVES_PER_TILE][64];          // d loss / d mask of each pixel
@@ -656,30 +613,37 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     const int H = d.H, W = d.W, V = d.V;
     const RasterScratch& L = E.L;
     const float* __restrict__ pos = E.spos;
-    const int* __restrict__ tri = E.stri;
     int* ids = s_ids[wave];
-    // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's ordered active list -- no prefix over hypotheses,
-    // no global list, workgroups beyond the count leave after one scalar load
+    // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's active tiles in ascending tile order.  There is no list kernel:
+    // every WAVE scans the hypothesis' row of tile flags itself (bytes written by step_kernel; NTp / 4 dwords, 5 loads per lane at
+    // 640x480, all in flight), ranks the set flags with ballots and keeps the tiles whose rank is s mod S -- no atomics, no
+    // barrier, and the first dependent level of this kernel is the flag row instead of count -> list entry.  The z = 0 role's
+    // first wave also writes the ordered list and the count for the kernels that come later (edge_kernel, update_head).
     // grid (B, S, roles): x = hypothesis, y = slice.  Workgroups are dispatched in linear-id order and land on CUs
     // in a fixed pattern of that id (XCD = id % 8, CU = f(id/8 % 32), measured): slice-major order sends the
     // working slices of every hypothesis first and the idle ones (slice >= n_tiles) last, so the tail of the launch
     // is made of workgroups that exit at once, and every CU sees the same mix of slices.
+    __shared__ unsigned short s_list[WAVES_PER_TILE][SCAN_LIST];
     const int b = blockIdx.x;
-    if (ROLE == E.st_role && blockIdx.y == 0 && b == 0 && tid == 0) E.st->it = E.st->it_next;  // see update_xfm_kernel
-    const int n_tiles = L.b_count[b];
-    const int k_first = blockIdx.y, k_step = gridDim.y;
-    // the first list entry is requested together with the count (one dependent round trip less; an entry beyond
-    // the count is stale and unused)
-    const int txy_first = k_first < L.NT ? L.active[(size_t)b * L.NT + k_first] : 0;
-    // colour role: rows x, y, w of this hypothesis' final = proj . mtx (uniform: scalar loads, requested with the tile list)
+    const int it_cur = E.st->it_next - 1;  // the iteration being drawn (it_next is stable during this launch)
+    const int par = it_cur & 1;
+    if (ROLE == E.st_role && blockIdx.y == 0 && b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
+    const int sl = blockIdx.y, S = gridDim.y;
+    const unsigned* __restrict__ frow = reinterpret_cast<const unsigned*>(L.tile_flag + ((size_t)par * d.B + b) * L.NTp);
+    const int nu_all = L.NTp >> 8;   // dwords per lane for the whole row
+    const int UCH = min(SCAN_U, S);  // dwords per lane per chunk: a chunk holds 256 UCH flags, i.e. at most 256 UCH / S <= SCAN_LIST tiles of this slice
+    const float invS = __frcp_rn((float)S);
+    const bool lister = ROLE == E.st_role && wave == 0;
+    int* __restrict__ g_active = L.active + (size_t)b * L.NT;
+    // colour role: rows x, y, w of this hypothesis' final = proj . mtx (uniform: scalar loads, requested with the flag row)
     float Fx[4] = {0.f, 0.f, 0.f, 0.f}, Fy[4] = {0.f, 0.f, 0.f, 0.f}, Fw[4] = {0.f, 0.f, 0.f, 0.f};
     if (ROLE == 0) {
-        const float* Fm = E.mats + ((size_t)(E.st->it_next & 1) * d.B + b) * 32 + 16;  // it_next = this iteration (stable here)
+        const float* Fm = E.mats + ((size_t)par * d.B + b) * 32 + 16;
 #pragma unroll
         for (int c = 0; c < 4; ++c) { Fx[c] = Fm[c]; Fy[c] = Fm[4 + c]; Fw[c] = Fm[12 + c]; }
     }
-    // every lane accumulates its pixels' terms over ALL the tiles of the workgroup; one wave reduction and one partial row
-    // per (slice, wave, role) at the end, instead of one per tile (update_xfm_kernel sums min(slices, tiles) rows)
+    // every lane accumulates its pixels' terms over ALL the tiles of the workgroup; one wave reduction, one fold over the four
+    // waves and one partial row per (slice, role) at the end (update_head sums min(slices, tiles) rows per role)
     PixAcc A;
 #pragma unroll
     for (int i = 0; i < 12; ++i) A.dF[i] = 0.f;
@@ -688,14 +652,47 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     A.L[0] = A.L[1] = A.L[2] = A.L[3] = 0.f;
     const float lrb = E.b.lr_mult[b];
     const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
-    for (int k = k_first; k < n_tiles; k += k_step) {
-        const int txy = k == k_first ? txy_first : L.active[(size_t)b * L.NT + k];
-        DDX_PHASE(0);
-        const int tcx = txy & 0xffff, tcy = txy >> 16;
-        const int flat = b * L.NT + tcy * L.ntx + tcx;
+    int rank_base = 0, mine_before = 0;  // set flags / tiles of this slice before the chunk (wave-uniform)
+    for (int u0 = 0; u0 < nu_all; u0 += UCH) {
+    int mine_after;
+    {
+        unsigned dw[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) dw[u] = (u < UCH && u0 + u < nu_all) ? frow[(size_t)(u0 + u) * 64 + lane] : 0u;
+        int cnt = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int u = 0; u < SCAN_U; ++u) {
+            const unsigned dd = dw[u];
+            const unsigned long long m0 = __ballot((dd & 0xffu) != 0u), m1 = __ballot((dd & 0xff00u) != 0u), m2 = __ballot((dd & 0xff0000u) != 0u),
+                                     m3 = __ballot((dd & 0xff000000u) != 0u);
+            const int c_u = (__popcll(m0) + __popcll(m1)) + (__popcll(m2) + __popcll(m3));
+            if (c_u == 0) continue;  // (wave-uniform)
+            int r = rank_base + cnt + (__popcll(m0 & below) + __popcll(m1 & below)) + (__popcll(m2 & below) + __popcll(m3 & below));
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+                if ((dd >> (8 * jb)) & 0xffu) {
+                    const int rank = r++;
+                    const int q = (int)(((float)rank + 0.5f) * invS);  // rank / S, exact for rank < 2^16
+                    if (rank - q * S == sl) {
+                        const int tile = ((u0 + u) * 64 + lane) * 4 + jb;
+                        const int ty = tile / L.ntx, tx = tile - ty * L.ntx;
+                        s_list[wave][q - mine_before] = (unsigned short)((ty << 8) | tx);
+                        if (lister) g_active[rank] = (ty << 16) | tx;
+                    }
+                }
+            cnt += c_u;
+        }
+        rank_base += cnt;
+        mine_after = rank_base > sl ? (rank_base - sl + S - 1) / S : 0;
+        wave_lds_sync();
+    }
+    for (int k = 0; k < mine_after - mine_before; ++k) {
+        const int txy8 = s_list[wave][k];
+        const int tcx = txy8 & 0xff, tcy = txy8 >> 8;
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
-        const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * L.zper;
+        const unsigned long long* __restrict__ zb = L.zbuf + ((size_t)par * d.B + b) * L.zper;
         const int lx = lane % QUAD, ly = lane / QUAD;
         const int px = qx + lx, py = qy + ly;
         const int hidx = (ly + 1) * QH + lx + 1;
@@ -732,7 +729,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             wave_lds_sync();
             id = ids[hidx];
         }
-        DDX_PHASE(1);
         if (ROLE == 0 && id > 0) {
             const int t = id - 1;
             // ONE record per covered triangle, fetched by id: object-space positions + uv (or colours) of its vertices.  The
@@ -743,11 +739,9 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             const float4 r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3];
             float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!(d.Th > 0)) r4 = R[4];
-            DDX_PHASE(2);
             const float x0 = r0.x, y0 = r0.y, z0 = r0.z, x1 = r0.w, y1 = r1.x, z1 = r1.y, x2 = r1.z, y2 = r1.w, z2 = r2.x;
             const float a0x = r2.y, a0y = r2.z, a1x = r2.w, a1y = r3.x, a2x = r3.y, a2y = r3.z;  // (textured)
             const float4 p0 = clip_xyw(Fx, Fy, Fw, x0, y0, z0), p1 = clip_xyw(Fx, Fy, Fw, x1, y1, z1), p2 = clip_xyw(Fx, Fy, Fw, x2, y2, z2);
-            DDX_PHASE(3);
             Bary bc;
             pixel_bary(p0, p1, p2, px, py, H, W, bc);
             const float u = clamp01(bc.u), v = clamp01(bc.v), w2 = (1.0f - u) - v;
@@ -779,7 +773,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                         dcu[c] = dX * ux + dY * uy;
                         dcv[c] = dX * vx + dY * vy;
                     }
-                    DDX_PHASE(4);
                 } else {
                     const float k0[3] = {r2.y, r2.z, r2.w}, k1[3] = {r3.x, r3.y, r3.z}, k2[3] = {r3.w, r4.x, r4.y};
 #pragma unroll
@@ -825,7 +818,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             }
             if (d.use_depth) {
                 const float k = d.w_depth * lrb * inv_b / ((float)H * (float)W);
-                const float* M = E.mats + ((size_t)(E.st->it_next & 1) * d.B + b) * 32;  // it_next = this iteration (stable here)
+                const float* M = E.mats + ((size_t)par * d.B + b) * 32;
                 const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
                 const float gbx = __fmaf_rn(w2, x2, __fmaf_rn(v, x1, u * x0));
                 const float gby = __fmaf_rn(w2, y2, __fmaf_rn(v, y1, u * y0));
@@ -852,7 +845,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 acc_vertex_regs(A, x2, y2, z2, gx[2], gy[2], gw[2]);
             }
         }
-        DDX_PHASE(5);
         if (ROLE == 1) {
             // ---- antialias, pair-parallel: compact the candidate pairs (exactly one side covered, at least
             // one side in this quadrant) with ballots, then ONE lane per pair instead of 4 divergent
@@ -874,7 +866,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             if (c2) s_pairs[wave][n0 + n1 + __popcll(m2 & lt)] = (unsigned short)(lane | (2 << 6));
             if (c3) s_pairs[wave][n0 + n1 + n2 + __popcll(m3 & lt)] = (unsigned short)(lane | (3 << 6));
             wave_lds_sync();
-            DDX_PHASE(2);
             // forward: each lane owns pair `lane` (+64, ... in the rare quadrant with more than 64 pairs)
             int tl0 = -1;
             float cd0 = 0.f;
@@ -907,7 +898,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 }
             }
             wave_lds_sync();
-            DDX_PHASE(3);
             // pixel: mask value, loss term, d loss / d mask
             float gm = 0.f;
             if (inimg) {
@@ -919,7 +909,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             s_gm[wave][lane] = gm;
             s_m[wave][lane] = 0.f;  // re-arm for the next tile
             wave_lds_sync();
-            DDX_PHASE(4);
             // backward: a pair whose target pixel is ours scales its unit contribution by d loss / d alpha
             for (int j0 = 0; j0 < np; j0 += 64) {
                 int tl = tl0;
@@ -954,21 +943,15 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             }
             wave_lds_sync();
         }
-        DDX_PHASE(6);
-#if defined(DDX_TRACE) && defined(DDX_PHASES)
-        if (ROLE == DDX_PHASE_ROLE && tid == 0 && k == k_first) {
-            const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-            if (wg < 4096) {
-                unsigned long long* q = E.trace + ((size_t)1 * 8192) * 4 + wg * 8;  // kernel slot 1 (unused), 8 stamps per workgroup
-#pragma unroll
-                for (int i = 0; i < 8; ++i) q[i] = ph[i];
-            }
-        }
-#endif
     }
-    if (k_first < n_tiles) {
-        // ---- wave reduction -> one partial row per (slice, wave, role) (fixed order: bit-reproducible)
-        float* part = E.partials + ((((size_t)b * E.pslices + blockIdx.y) * WAVES_PER_TILE + wave) * NR + ROLE) * NPART;
+    wave_lds_sync();  // (s_list is rewritten by the next chunk)
+    mine_before = mine_after;
+    }
+    if (lister && sl == 0 && lane == 0) L.b_count[b] = rank_base;
+    if (sl < rank_base) {  // (workgroup-uniform: every wave counted the same flags)
+        // ---- wave reduction, then the four waves folded in a fixed order -> one partial row per (slice, role): bit-reproducible
+        __shared__ float s_rows[WAVES_PER_TILE][NPART];
+        float* part = E.partials + (((size_t)b * E.pslices + blockIdx.y) * NR + ROLE) * NPART;
         constexpr int NV = NVALS - 1;  // (the 20th value, the edge loss, belongs to edge_kernel)
         float vals[NVALS];
 #pragma unroll
@@ -989,10 +972,12 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             for (int i = 16; i < NV; ++i)
                 if (lane == 32 + i) mine2 = vals[i];
         }
-        if (lane >= 48) {  // lanes 48..63 write values 0..15, lanes 48..55 the slots 16..23 (values 16..NV-1, then zero padding)
-            part[lane - 48] = mine;
-            if (lane < 56) part[lane - 32] = mine2;
+        if (lane >= 48) {  // lanes 48..63 hold values 0..15, lanes 48..55 the slots 16..23 (values 16..NV-1, then zero padding)
+            s_rows[wave][lane - 48] = mine;
+            if (lane < 56) s_rows[wave][lane - 32] = mine2;
         }
+        __syncthreads();
+        if (tid < NPART) part[tid] = (s_rows[0][tid] + s_rows[1][tid]) + (s_rows[2][tid] + s_rows[3][tid]);
     }
 }
 
@@ -1001,15 +986,12 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 template <bool EDGE>
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E)
 {
-    DDX_TRACE_BEGIN();
     const int z = blockIdx.z;
     const int role = z == 0 ? E.roles[0] : E.roles[1];
     __shared__ float s_pool[WAVES_PER_TILE][12 * 64];
     float* pool = s_pool[threadIdx.x >> 6];
     if (role == 0) shade_body<0, EDGE ? 3 : 2>(E, pool);
     else shade_body<1, EDGE ? 3 : 2>(E, pool);
-    DDX_TRACE_END(E.trace, 2, ((unsigned long long)role << 32) |
-                  (unsigned)max(0, (E.L.b_count[blockIdx.x] - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1030,8 +1012,9 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W;
     const int b = blockIdx.x;
-    const int n_tiles = L.b_count[b];
-    const unsigned long long* __restrict__ zb = L.zbuf + (size_t)b * L.zper;
+    const int n_tiles = L.b_count[b];  // (count and ordered list: written by shade_kernel's scan)
+    const int par = (E.st->it_next - 1) & 1;
+    const unsigned long long* __restrict__ zb = L.zbuf + ((size_t)par * d.B + b) * L.zper;
     const float* __restrict__ lumb = E.lumbuf + (size_t)b * H * W;
     const float lrb = E.b.lr_mult[b];
     const float kc = d.w_edge * lrb * __fdiv_rn(1.0f, (float)d.B_global) / (2.0f * (float)H * (float)W) * 0.125f;
@@ -1134,8 +1117,9 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
         if (own_loss != 0.f) s_acc[12][tid] += own_loss;
         wave_lds_sync();  // (the LDS arrays are reused by the next tile)
     }
-    if ((int)blockIdx.y < n_tiles) {
-        float* part = E.partials + ((((size_t)b * E.pslices + blockIdx.y) * WAVES_PER_TILE + wave) * 3 + 2) * NPART;
+    if ((int)blockIdx.y < n_tiles) {  // (workgroup-uniform)
+        __shared__ float s_rows[WAVES_PER_TILE][NPART];
+        float* part = E.partials + (((size_t)b * E.pslices + blockIdx.y) * 3 + 2) * NPART;
         float mine = 0.f, mine2 = 0.f;
         float acc[13];
         bool nz = false;
@@ -1149,158 +1133,134 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
             if (lane == 32 + 19) mine2 = acc[12];
         }
         if (lane >= 48) {  // slots 0..15 from lanes 48..63, slots 16..23 from lanes 48..55
-            part[lane - 48] = mine;
-            if (lane < 56) part[lane - 32] = mine2;
+            s_rows[wave][lane - 48] = mine;
+            if (lane < 56) s_rows[wave][lane - 32] = mine2;
         }
+        __syncthreads();
+        if (tid < NPART) part[tid] = (s_rows[0][tid] + s_rows[1][tid]) + (s_rows[2][tid] + s_rows[3][tid]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// update + next iteration's transform, one launch: grid (B, UPD_SLICES).
-// Every workgroup of hypothesis b redundantly reduces b's quadrant partials (a few KB from L2, fixed order),
-// runs the proj^T / quaternion chain and the optimiser step in LDS, and then transforms ITS slice of the
-// vertices with the NEW pose on the matrix core (as pose_xfm_kernel), so the next iteration starts at the
-// rasteriser.  Slice 0 also writes parameters, optimiser state and logs; the zbuf / tile-flag re-arm is split
-// over the slices.
-#define UPD_SLICES 8  // at most; fewer for large batches (upd_slices())
-#define UPD_SPEC 24  // partial slots per thread requested before the tile count is known
+// The optimiser step of iteration j for hypothesis b: the head of step_kernel and all of finish_kernel.
+// EVERY workgroup of the hypothesis runs it, redundantly (one kernel less in the iteration's chain; the partial rows are a few
+// KB from L2): fixed-order sum of the hypothesis' partial rows (one per shade / edge slice and role), whole-frame constants +
+// the background depth term sum |seg| |d_bg - gt| of the whole frame from the depth-sorted seg list with prefix sums in
+// double (two 64-way searches on one wave + six loads), proj^T chain, quaternion chain, SGD/Adam (lane-parallel tail), loss
+// log.  Workgroup `slice` of `n_slices` also re-arms its share of what iteration j dirtied (zbuf of the active tiles and their
+// flags, parity j & 1), and slice 0 writes parameters, optimiser state and logs.  Returns (after a barrier) with
+// snew[0..6] = the updated parameters and sc[16..31] = proj in LDS.
+// The sum is grouped the same way whatever the workgroup size (8 buckets of rows q = bucket mod 8, folded pairwise), so the
+// 64- and 256-thread variants of step_kernel produce the same bits.
+#define UPD_SLICES 8  // workgroups per hypothesis of finish_kernel; fewer for large batches (upd_slices())
 
-template <int NR>
-__global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
+template <int NTH, int NR>
+__device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, int slice, int n_slices, float* snew, float* sc)
 {
+    constexpr int NG = NTH / 32, NW = NTH / 64, NBK = 8 / NG;  // groups of 32 threads, waves, row buckets per thread
+    constexpr int SPEC = 64 / 8;                               // rows per bucket requested before the tile count is known (64 rows in all)
     const ddx_engine_desc& d = E.d;
-    // grid (B, slices): hypothesis b's workgroups get linear ids b + B * slice, i.e. (B a multiple of 8) the XCD b % 8 that ran
-    // b's shade workgroups and holds their partials in its L2 (slice-major was measured 1-3 % slower on cfg3, equal elsewhere)
-    const int b = blockIdx.x, B = d.B, slice = blockIdx.y, V = d.V;
+    const int B = d.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float red[4][NPART];
     __shared__ float sums[NPART];
-    __shared__ float sc[64];      // scalars the tail needs, fetched in parallel
-    __shared__ float snew[8];     // updated parameters
     __shared__ float sG[16];
     __shared__ float sgrad[8];
-    __shared__ int s_tiles[256];
-    __shared__ int s_bad;  // a vertex of this slice left the view volume (cull_ok)
-    if (threadIdx.x == 0) s_bad = 0;
-    const int it = E.st->it;
+    __shared__ float s_bg[2];
     const int NT = E.L.NT;
-    DDX_TRACE_BEGIN();
-#if defined(DDX_TRACE) && defined(DDX_PHASES)
-    unsigned long long uph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#ifdef DDX_PHASES_NOWAIT  // stamp when the wave gets here (its own waits included), without draining loads/stores first
-#define UPH(i) do { asm volatile("" ::: "memory"); uph[i] = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
-#else
-#define UPH(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); uph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#endif
-#else
-#define UPH(i)
-#endif
-    UPH(0);
-    const int cur = it & 1;
-    const int j = tid % 32, grp = tid / 32;  // 8 groups of 32 threads; thread j < NVALS of group g sums value j
-    float acc = 0.f;
+    const int cur = j & 1;
+    const int jj = tid % 32, grp = tid / 32;  // thread jj < NVALS of group g sums value jj of the rows of its buckets
     const int n_act = E.L.b_count[b];
     const int* tiles = E.L.active + (size_t)b * NT;
-    // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the
-    // first chunk of the tile list (speculative: entries beyond n_act are stale and unused), the partial rows, the totals of
-    // the sorted seg list, and the first batch of vertex positions of the transform at the end.  The kernel is a chain
-    // of dependent round trips; these would otherwise each add one.
-    constexpr int PER = 4 * NR;  // partial slots per tile
+    // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the partial
+    // rows (speculative: rows of slices beyond the tile count are stale and masked below), the first tile of the re-arm
+    // share, the totals of the sorted seg list.  The head is a chain of dependent round trips; these would otherwise each add one.
     const int rmask = E.role_mask;
-    // partial rows of hypothesis b: (slice, wave, role), written by the workgroups of shade_kernel / edge_kernel that had at
-    // least one tile (slice < min(slices of that kernel, tiles)); rows beyond are stale and masked below
-    const int PS = E.pslices;
-    const float* pbase = E.partials + (size_t)b * PS * PER * NPART + j;
-    const int smax_r[3] = {E.s_shade, E.s_shade, E.s_edge};
-    float v0[UPD_SPEC];  // slots grp, grp + 8, ...: the first UPD_SPEC x 8 slots (24 slices with two roles) in ONE round trip
+    const int PS = E.pslices, nrow = PS * NR;
+    const float* pbase = E.partials + (size_t)b * nrow * NPART + jj;
+    auto row_ok = [&](int q) {  // row q = slice * NR + role: written by shade_kernel (roles 0, 1) / edge_kernel (role 2) when the slice has a tile
+        const int r = q % NR, s = q / NR;
+        return q < nrow && ((rmask >> r) & 1) && s < (r == 2 ? E.s_edge : E.s_shade);
+    };
+    float v0[NBK][SPEC];
 #pragma unroll
-    for (int u = 0; u < UPD_SPEC; ++u) {
-        const int s = grp + u * 8;
-        const int r = s % NR;
-        const bool ok = j < NVALS && s < PS * PER && ((rmask >> r) & 1) && s / PER < (r == 0 ? smax_r[0] : (r == 1 ? smax_r[1] : smax_r[2]));
-        v0[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
-    }
-    const int txy_first = tid < NT ? tiles[tid] : 0;
-    // totals of the sorted seg list (its size is known to the host since setup)
-    const int ns = d.use_depth ? E.nseg : 0;
+    for (int i = 0; i < NBK; ++i)
+#pragma unroll
+        for (int u = 0; u < SPEC; ++u) {
+            const int q = (grp + NG * i) + 8 * u;
+            v0[i][u] = (jj < NVALS && row_ok(q)) ? pbase[(size_t)q * NPART] : 0.f;
+        }
+    const int txy_first = slice < NT ? tiles[slice] : 0;
+    const int ns = d.use_depth ? E.nseg : 0;  // (the size of the sorted seg list is known to the host since setup)
     const double segWn = E.seg_W[ns], segGn = E.seg_G[ns];
-    const int n_slices = (int)gridDim.y;  // a power of two <= UPD_SLICES
-    const int per = (V + n_slices - 1) / n_slices;
-    const int n_begin = slice * per, n_end = min(V, n_begin + per);
-    float px[4], py[4], pz[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int n = n_begin + u * 256 + tid;
-        const float* p = E.spos + (size_t)(n < n_end ? n : 0) * 3;
-        px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
-    }
-    // ---- the scalars of the tail, one per thread, into LDS: params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45.
-    // Requested AFTER the loads above (their addresses need the iteration index, itself a load: ahead of the others
-    // they delayed everything by two round trips), consumed after the partial sums.
+    // ---- the scalars of the tail, one per thread, into LDS: params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45
     float sc_val = 0.f;
     if (tid < 7) sc_val = E.params2[((size_t)cur * 7 + tid) * B + b];
     else if (tid == 7) sc_val = E.b.lr_mult[b];
-    else if (tid == 8) sc_val = E.b.lr_sched[it];
+    else if (tid == 8) sc_val = E.b.lr_sched[j];
     else if (tid >= 16 && tid < 32) sc_val = E.b.proj[tid - 16];
     else if (tid >= 32 && tid < 46) sc_val = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
     const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
-    // ---- partial sums.  The quadrant partials are stored by position in the hypothesis' ordered active list, so the
-    // slots (tile position, quadrant, role) of hypothesis b are ONE contiguous run: v0[] was requested before the
-    // count was known; fixed order => bit-reproducible
+    // ---- partial sums, fixed order => bit-reproducible
+    float acc[NBK];
     {
-        const int nslot = min(PS, n_act) * PER;  // (slice s / PER has a tile <=> s / PER < n_act)
+        const int nlive = min(PS, n_act) * NR;  // (slice s has a tile <=> s < n_act)
 #pragma unroll
-        for (int u = 0; u < UPD_SPEC; ++u) acc += (grp + u * 8 < nslot) ? v0[u] : 0.f;
-        if (j < NVALS)
-            for (int s0 = grp + UPD_SPEC * 8; s0 < nslot; s0 += 64) {
-                float v[8];
+        for (int i = 0; i < NBK; ++i) {
+            acc[i] = 0.f;
+            const int q0 = grp + NG * i;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per slot)
-                    const int s = s0 + u * 8;
-                    const int r = s % NR;
-                    const bool ok = s < nslot && ((rmask >> r) & 1) && s / PER < (r == 0 ? smax_r[0] : (r == 1 ? smax_r[1] : smax_r[2]));
-                    v[u] = ok ? pbase[(size_t)s * NPART] : 0.f;
+            for (int u = 0; u < SPEC; ++u) acc[i] += (q0 + 8 * u < nlive) ? v0[i][u] : 0.f;
+            if (jj < NVALS)
+                for (int q1 = q0 + 8 * SPEC; q1 < nlive; q1 += 64) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per row)
+                        const int q = q1 + 8 * u;
+                        v[u] = (q < nlive && row_ok(q)) ? pbase[(size_t)q * NPART] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[i] += v[u];
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
-            }
+        }
     }
     if (tid < 46) sc[tid] = sc_val;
-    UPH(1);
-    // ---- re-arm what the iteration dirtied (zbuf of the active tiles, their flags) so that the next iteration needs
-    // no memset -- tile k is re-armed by slice k % UPD_SLICES.  Independent of the sums.
-    for (int start = 0; start < n_act; start += 256) {
-        __syncthreads();
-        if (start + tid < n_act) {
-            const int txy = start == 0 ? txy_first : tiles[start + tid];
-            s_tiles[tid] = txy;
-            if (((start + tid) & (n_slices - 1)) == slice) {
-                const int tile = (txy >> 16) * E.L.ntx + (txy & 0xffff);
-                E.L.tile_flag[(size_t)b * NT + tile] = 0;
-                E.L.tile_big[(size_t)b * NT + tile] = 0;
+    // ---- re-arm what iteration j dirtied (zbuf of its active tiles, their flags; parity j & 1) so that no pass needs a
+    // memset: tile k of the hypothesis' list is re-armed by workgroup k % n_slices.  Independent of the sums.
+    {
+        unsigned long long* Z = E.L.zbuf + ((size_t)cur * B + b) * E.L.zper;
+        unsigned char* flag = E.L.tile_flag + ((size_t)cur * B + b) * E.L.NTp;
+        unsigned char* big = E.L.tile_big + ((size_t)cur * B + b) * E.L.NTp;
+        for (int k = slice; k < n_act; k += n_slices) {  // (workgroup-uniform)
+            const int txy = k == slice ? txy_first : tiles[k];
+            const int tx = txy & 0xffff, ty = txy >> 16;
+            if (tid == 0) {
+                flag[ty * E.L.ntx + tx] = 0;
+                big[ty * E.L.ntx + tx] = 0;
+            }
+#pragma unroll
+            for (int p = tid; p < DDX_TILE * DDX_TILE; p += NTH) {
+                const int zx = tx * DDX_TILE + p % DDX_TILE, zy = ty * DDX_TILE + p / DDX_TILE;
+                if (zx < d.W && zy < d.H) Z[zaddr(zx, zy, E.L.zwb)] = ~0ull;
             }
         }
-        __syncthreads();
-        const int na = min(256, n_act - start);
-        const int lx = tid % DDX_TILE, ly = tid / DDX_TILE;
-        for (int s = slice; s < na; s += n_slices) {  // (start is a multiple of 256, hence of n_slices)
-            const int txy = s_tiles[s];
-            const int zx = (txy & 0xffff) * DDX_TILE + lx, zy = (txy >> 16) * DDX_TILE + ly;
-            if (zx < d.W && zy < d.H) E.L.zbuf[(size_t)b * E.L.zper + zaddr(zx, zy, E.L.zwb)] = ~0ull;
+    }
+    // buckets 2w and 2w+1 are folded first (for 256 threads they live in the two halves of wave w), then the four pairs
+#pragma unroll
+    for (int i = 0; i < NBK; ++i) acc[i] += __shfl_xor(acc[i], 32, 64);
+    if (lane < NPART) {
+        if (NBK == 1) red[wave][lane] = acc[0];
+        else {
+#pragma unroll
+            for (int i = 0; i < NBK; ++i) red[i % 4][lane] = acc[i];  // (NTH = 64: thread group g in {0,1} holds buckets g, g+2, g+4, g+6 = pairs 0..3)
         }
     }
-    acc += __shfl_xor(acc, 32, 64);  // groups 2w and 2w+1 live in wave w
-    __syncthreads();
-    if (lane < NPART) red[wave][lane] = acc;
     __syncthreads();
     if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    __syncthreads();
-    UPH(2);
     // ---- whole-frame background depth term: sum_i w_i |dbg - g_i| and sum_i w_i sgn(dbg - g_i) (w = |seg0|, g = observed depth)
     // from the sorted list: k1 = #(g < dbg), k2 = #(g <= dbg) by a 64-way search per round on the last wave (no barrier), then
     // prefix-sum differences in double
-    __shared__ float s_bg[2];
-    if (d.use_depth && wave == 3) {
+    if (d.use_depth && wave == NW - 1) {
         int lo1 = 0, hi1 = ns, lo2 = 0, hi2 = ns, k1 = -1, k2 = -1;
         while (k1 < 0 || k2 < 0) {  // (wave-uniform)
             const int span1 = hi1 - lo1, span2 = hi2 - lo2;
@@ -1328,7 +1288,6 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
     }
     __syncthreads();
     const float bgsum = d.use_depth ? s_bg[0] : 0.f, bgder = d.use_depth ? s_bg[1] : 0.f;
-    UPH(3);
     // ---- tail on wave 0, one lane per output where the work allows
     const bool writer = slice == 0;
     if (wave == 0) {
@@ -1342,18 +1301,18 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
             if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
             if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
             if (E.eval_grad) E.eval_loss[(size_t)lane * B + b] = v;
-            else E.b.loss_log[((size_t)it * 4 + lane) * B + b] = v;
+            else E.b.loss_log[((size_t)j * 4 + lane) * B + b] = v;
         }
         // d loss / d mtx = proj^T . dFinal (+ direct depth row): lane = k*4 + j
         if (lane < 16) {
-            const int k = lane >> 2, jj = lane & 3;
+            const int k = lane >> 2, c = lane & 3;
             float a = 0.f;
-            a = __fmaf_rn(sc[16 + 0 * 4 + k], sums[0 + jj], a);   // dFinal row x
-            a = __fmaf_rn(sc[16 + 1 * 4 + k], sums[4 + jj], a);   // row y
-            a = __fmaf_rn(sc[16 + 3 * 4 + k], sums[8 + jj], a);   // row w (row z carries no gradient)
+            a = __fmaf_rn(sc[16 + 0 * 4 + k], sums[0 + c], a);   // dFinal row x
+            a = __fmaf_rn(sc[16 + 1 * 4 + k], sums[4 + c], a);   // row y
+            a = __fmaf_rn(sc[16 + 3 * 4 + k], sums[8 + c], a);   // row w (row z carries no gradient)
             if (d.use_depth && k == 2) {
-                a += sums[12 + jj];
-                if (jj == 3) a += -(d.w_depth * lrb / ((float)d.B_global * npx)) * bgder;  // whole-frame background term (depth_bg = -m23)
+                a += sums[12 + c];
+                if (c == 3) a += -(d.w_depth * lrb / ((float)d.B_global * npx)) * bgder;  // whole-frame background term (depth_bg = -m23)
             }
             sG[lane] = a;
         }
@@ -1383,7 +1342,7 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
                 pnew = sc[lane] - lr * g;
             } else {
                 const float b1 = d.adam_beta1, b2 = d.adam_beta2;
-                const float c1 = 1.f - exp2f((float)(it + 1) * log2f(b1)), c2 = 1.f - exp2f((float)(it + 1) * log2f(b2));
+                const float c1 = 1.f - exp2f((float)(j + 1) * log2f(b1)), c2 = 1.f - exp2f((float)(j + 1) * log2f(b2));
                 const float m1 = b1 * sc[32 + lane] + (1.f - b1) * g;
                 const float m2 = b2 * sc[39 + lane] + (1.f - b2) * g * g;
                 if (writer) {
@@ -1399,98 +1358,178 @@ __global__ __launch_bounds__(256) void update_xfm_kernel(EngineDev E)
             }
         }
         if (writer && b == 0) {
-            // iteration bookkeeping without atomics (kernel boundaries order these single-lane updates):
-            // shade_kernel of the next iteration copies it_next into `it`, which this kernel reads.
+            // status of iteration j (single lanes across kernel boundaries, no atomics)
             int tot = 0, out = 0;
             for (int i = lane; i < B; i += 64) {
                 tot += E.L.b_count[i];
-                const int* ck = E.cull_ok + (size_t)i * 8;  // (the flags the transform of the previous iteration left for this one)
-                out += (ck[0] & ck[1] & ck[2] & ck[3] & ck[4] & ck[5] & ck[6] & ck[7]) == 0;
+                out += E.inside[i] == 0;
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, 64); out += __shfl_xor(out, o, 64); }
             if (lane == 0) {
                 E.st->last_active = tot;
                 E.st->outside = out;
-                E.st->last_pairs = E.L.counters[3];
-                E.L.counters[3] = 0;  // "a large triangle exists" flag, set again by scatter_kernel
-                E.st->it_next = E.eval_grad ? it : it + 1;
+                E.st->last_pairs = E.L.counters[3 + cur];
             }
         }
     }
-    UPH(4);
     __syncthreads();
-    UPH(5);
-    if (E.eval_grad) {  // the next pass starts from pose_xfm_kernel with whatever the caller put into params
-        if (writer && tid == 0) E.L.bigcount[b] = 0;
-        return;
+}
+
+// Meshlet geometry of a step_kernel instantiation: TPL triangles per thread, two vertex slots per thread.
+// MODE: the fragment variant of scatter_resolve (raster_dev.h).
+//
+// The chain of one iteration used to be four launches (transform+update, scatter, compaction, shade) with the clip-space
+// vertices and their window snap travelling through HBM in between; here the optimiser step, the transform and the scatter
+// rasteriser are one workgroup-local pipeline and the compaction is gone (shade_kernel scans the flags itself).
+template <int TPL, int NTH, int MODE, int NR>
+__global__ __launch_bounds__(NTH) void step_kernel(EngineDev E, int mode, int it_arg)
+{
+    constexpr int NTRI = TPL * NTH, NVC = 2 * NTH;
+    const ddx_engine_desc& d = E.d;
+    const int b = blockIdx.y, m = blockIdx.x, B = d.B, V = d.V;
+    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ float4 s_clip[NVC];
+    __shared__ int2 s_snap[NVC];
+    __shared__ float snew[8];  // the parameters this iteration is drawn with
+    __shared__ float sc[64];   // update_head's scalars; 16..31 = proj
+    const int it = mode == STEP_FIRST ? it_arg : E.st->it;
+    const int par = it & 1;
+    // ---- the meshlet (static tables, fixed-size slots: nothing here depends on another load): requested before the head
+    float4 vr[2];
+    int2 tr[TPL];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)m * NVC + u * NTH + tid];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)m * NTRI + k * NTH + tid];
+    if (mode == STEP_NORMAL) {
+        update_head<NTH, NR>(E, b, it - 1, m, (int)gridDim.x, snew, sc);
+    } else {
+        // first iteration of a run: the parameters as the caller holds them (un-normalised)
+        if (tid < 7) snew[tid] = E.b.params[(size_t)tid * B + b];
+        if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
+        __syncthreads();
     }
-    // ---- transform this slice of the vertices with the NEW pose (next iteration's pose_xfm)
-    float q[4], t[3], M[16], pr[4], Fr[4];
+    const bool writer = m == 0;
+    // ---- pose -> matrices (every lane, from LDS broadcasts: ~150 flops, cheaper than a dependent load)
+    float q[4], t3[3], M[16], pr[4], Fr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = snew[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = snew[4 + i];
+    for (int i = 0; i < 3; ++i) t3[i] = snew[4 + i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) pr[k] = sc[16 + (lane & 3) * 4 + k];  // row lane % 4 of proj
-    {   // q / |q| and [R|t] as pose_matrices
+    {   // q / |q| (diffdope.py:1091) and [R|t] (diffdope.py:46-89)
         const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
-        quat_to_matrix(q, t, M);
+        quat_to_matrix(q, t3, M);
     }
-    final_row(pr, M, Fr);
-    UPH(6);
-    if (writer && tid < 4) {  // lanes 0..3 hold rows 0..3 of final; each writes its row of both matrices
-        if (tid == 0) E.L.bigcount[b] = 0;  // re-arm the hypothesis' list of large triangles
-        float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
-        float* logm = (E.b.mtx_log && it + 1 < d.max_iters) ? E.b.mtx_log + ((size_t)(it + 1) * B + b) * 16 : nullptr;
-        const float Mr[4] = {tid == 0 ? M[0] : (tid == 1 ? M[4] : (tid == 2 ? M[8] : M[12])), tid == 0 ? M[1] : (tid == 1 ? M[5] : (tid == 2 ? M[9] : M[13])),
-                             tid == 0 ? M[2] : (tid == 1 ? M[6] : (tid == 2 ? M[10] : M[14])), tid == 0 ? M[3] : (tid == 1 ? M[7] : (tid == 2 ? M[11] : M[15]))};
+    final_row(pr, M, Fr);  // row lane % 4 of final = proj . mtx (torch.matmul at :195, k-ordered fma)
+    // ---- the meshlet's vertices on the matrix core -> LDS (clip + 1/256-pixel window snap); the owner of a vertex also stores
+    // it for the antialias pass and the tile pass
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            dst[tid * 4 + c] = Mr[c];
-            dst[16 + tid * 4 + c] = Fr[c];
-            if (logm) logm[tid * 4 + c] = Mr[c];
+    for (int u = 0; u < 2; ++u) {
+        const unsigned bits = __float_as_uint(vr[u].w);
+        const f32x4 acc = xfm_vertex_mfma(Fr, vr[u].x, vr[u].y, vr[u].z);
+        const float4 c4 = make_float4(acc.x, acc.y, acc.z, acc.w);
+        const int2 sn = snap_vertex(c4, d.H, d.W);
+        s_clip[u * NTH + tid] = c4;
+        s_snap[u * NTH + tid] = sn;
+        if (bits != 0xffffffffu && (bits >> 31)) {
+            const size_t g = (size_t)b * V + (bits & 0x7fffffffu);
+            *reinterpret_cast<f32x4*>(E.clip + g * 4) = acc;
+            E.L.snap[g] = sn;
         }
     }
-    // positions of 4 strides are fetched before any is consumed (a load-transform-store loop would pay one
-    // memory round trip per stride); the first batch was requested at the top of the kernel
-    bool inside = true;
-    for (int n0 = n_begin; n0 < n_end; n0 += 4 * 256) {
-        if (n0 > n_begin) {
+    // ---- is the whole object inside the view volume?  The 8 corners of its object-space bounding box through the same
+    // transform (lanes 0..7 of every wave): w > 0, -w <= z <= w at every corner => at every vertex (see EngineDev::cull_sign)
+    bool inside_all;
+    {
+        const int c = lane & 7;
+        const f32x4 acc = xfm_vertex_mfma(Fr, (c & 1) ? E.bbox[3] : E.bbox[0], (c & 2) ? E.bbox[4] : E.bbox[1], (c & 4) ? E.bbox[5] : E.bbox[2]);
+        const bool ok = acc.w > 0.f && acc.z >= -acc.w && acc.z <= acc.w;  // (NaN: false)
+        inside_all = __ballot(lane < 8 && !ok) == 0ull;
+    }
+    const int cull = (E.cull_sign != 0 && inside_all) ? E.cull_sign : 0;
+    if (writer) {
+        if (tid < 4) {  // lanes 0..3 hold rows 0..3 of final; each writes its row of both matrices
+            float* dst = E.mats + ((size_t)par * B + b) * 32;
+            float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
+            const float Mr[4] = {tid == 0 ? M[0] : (tid == 1 ? M[4] : (tid == 2 ? M[8] : M[12])), tid == 0 ? M[1] : (tid == 1 ? M[5] : (tid == 2 ? M[9] : M[13])),
+                                 tid == 0 ? M[2] : (tid == 1 ? M[6] : (tid == 2 ? M[10] : M[14])), tid == 0 ? M[3] : (tid == 1 ? M[7] : (tid == 2 ? M[11] : M[15]))};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int n = n0 + u * 256 + tid;
-                const float* p = E.spos + (size_t)(n < n_end ? n : 0) * 3;
-                px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+            for (int c = 0; c < 4; ++c) {
+                dst[tid * 4 + c] = Mr[c];
+                dst[16 + tid * 4 + c] = Fr[c];
+                if (logm) logm[tid * 4 + c] = Mr[c];
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int n = n0 + u * 256 + tid;
-            if (n0 + u * 256 < n_end) xfm_vertex_regs(E, Fr, b, n, n < n_end, px[u], py[u], pz[u], inside);
+        if (mode == STEP_FIRST && tid < 7) E.params2[((size_t)par * 7 + tid) * B + b] = snew[tid];
+        if (tid == 0) {
+            E.inside[b] = inside_all ? 1 : 0;
+            E.L.bigcount[(size_t)(1 - par) * B + b] = 0;  // the other parity's list of large triangles: consumed, nobody reads it now
+            if (b == 0) {
+                E.L.counters[3 + (1 - par)] = 0;  // ... and its "a large triangle exists" word
+                E.st->it_next = it + 1;           // (read by big_pass / shade / edge of this iteration)
+                if (mode == STEP_FIRST) E.st->it = it;
+            }
         }
     }
-    cull_ok_store(E, &s_bad, inside, b, slice);  // for the next iteration's scatter_kernel
-    UPH(7);
-#if defined(DDX_TRACE) && defined(DDX_PHASES)
-    if (tid == 0) {
-        const size_t wg = blockIdx.x + gridDim.x * (size_t)blockIdx.y;
-        if (wg < 4096) {
-            unsigned long long* q = E.trace + ((size_t)1 * 8192) * 4 + wg * 8;
+    __syncthreads();
+    // ---- the meshlet's triangles: vertices from LDS
+    int t[TPL], i0[TPL], i1[TPL], i2[TPL];
+    bool ok[TPL];
+    int2 va[TPL], vb[TPL], vc[TPL];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = uph[i];
-        }
+    for (int k = 0; k < TPL; ++k) {
+        ok[k] = tr[k].y >= 0;
+        t[k] = ok[k] ? tr[k].y : d.T;
+        i0[k] = tr[k].x & 1023; i1[k] = (tr[k].x >> 10) & 1023; i2[k] = (tr[k].x >> 20) & 1023;
+        va[k] = s_snap[i0[k]]; vb[k] = s_snap[i1[k]]; vc[k] = s_snap[i2[k]];
     }
-#endif
-    DDX_TRACE_END(E.trace, 3, 1ull);
+    ScatterTarget tg;
+    tg.P = reinterpret_cast<const float*>(s_clip);
+    tg.Z = E.L.zbuf + ((size_t)par * B + b) * E.L.zper;
+    tg.flag = E.L.tile_flag + ((size_t)par * B + b) * E.L.NTp;
+    tg.big = E.L.tile_big + ((size_t)par * B + b) * E.L.NTp;
+    tg.anybig = E.L.counters + 3 + par;
+    tg.biglist = E.L.biglist + (size_t)b * d.T;
+    tg.bigcount = E.L.bigcount + (size_t)par * B + b;
+    tg.ntx = E.L.ntx; tg.nty = E.L.nty; tg.NT = E.L.NT; tg.zwb = E.L.zwb;
+    tg.ndc = E.L.ndc;
+    scatter_resolve<TPL, NTH, MODE>(tg, d.H, d.W, d.T, t, i0, i1, i2, ok, va, vb, vc, cull);
 }
 
+// the optimiser step of the LAST iteration of a run (or of an evaluation pass): update_head alone, then both parities are clean
+template <int NR>
+__global__ __launch_bounds__(256) void finish_kernel(EngineDev E)
+{
+    __shared__ float snew[8];
+    __shared__ float sc[64];
+    const int b = blockIdx.y, it = E.st->it, par = it & 1;
+    update_head<256, NR>(E, b, it - 1, (int)blockIdx.x, (int)gridDim.x, snew, sc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        E.L.bigcount[(size_t)(1 - par) * E.d.B + b] = 0;
+        if (b == 0) E.L.counters[3 + (1 - par)] = 0;
+    }
+}
+
+// the tile pass for large / near-clipped triangles of the iteration being drawn (raster_dev.h big_pass_body); exits on one
+// scalar load when the batch has none (always, for the 20k-50k-triangle meshes of the benchmark)
+__global__ __launch_bounds__(256) void big_pass_kernel(EngineDev E)
+{
+    const int par = (E.st->it_next - 1) & 1, B = E.d.B;
+    if (E.L.counters[3 + par] == 0) return;
+    unsigned long long n_done = 0;
+    big_pass_body(E.clip, E.stri, E.L.snap, E.L.tile_big + (size_t)par * B * E.L.NTp, E.L.biglist, E.L.bigcount + (size_t)par * B,
+                  E.L.zbuf + (size_t)par * B * E.L.zper, E.L.zper, E.L.zwb, E.L.ntx, E.L.NT, E.L.NTp, B, E.d.V, E.d.T, E.d.H, E.d.W,
+                  (int)blockIdx.x, (int)gridDim.x, n_done);
+}
 
 // ---------------------------------------------------------------------------------------------
-enum { K_SCATTER, K_COMPACT_BIG, K_SHADE, K_EDGE, K_UPDATE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"scatter_kernel", "compact_big_kernel", "shade_kernel", "edge_kernel", "update_xfm_kernel"};
+enum { K_STEP, K_BIG, K_SHADE, K_EDGE, K_FINISH, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"step_kernel", "big_pass_kernel", "shade_kernel", "edge_kernel", "finish_kernel"};
 
 // shading grid (B, S): S slices per hypothesis, SHADE_GRID workgroups per role in total (all resident at 4 waves/SIMD)
 static dim3 shade_grid(const ddx_engine_desc& d)
@@ -1501,9 +1540,7 @@ static dim3 shade_grid(const ddx_engine_desc& d)
     return dim3(d.B, S);
 }
 
-// update_xfm_kernel: every slice of a hypothesis repeats the ~6 us chain (partial sums, optimiser step, matrices) before it
-// transforms its share of the vertices; the time is flat in the slice count while all workgroups are resident (1024 at
-// 4 waves/SIMD), so large batches get fewer slices instead of several rounds of that chain (512 hypotheses on the cfg2 mesh: 50 -> 38 us)
+// finish_kernel: the slices of a hypothesis only share its re-arm work
 static int upd_slices(const ddx_engine_desc& d)
 {
     int sl = UPD_SLICES;
@@ -1520,26 +1557,46 @@ static dim3 edge_grid(const ddx_engine_desc& d)
     return dim3(d.B, S);
 }
 
-// first iteration of a run: pose -> clip/snap (later iterations inherit them from update_xfm_kernel)
+// a run that does not continue where the last one stopped (rewind): the optimiser state follows the iteration parity
 static int run_prologue(ddx_engine* e, int it0, hipStream_t s)
 {
     EngineDev& E = e->dev;
-    if ((it0 & 1) != e->adam_parity) {  // a run that does not continue where the last one stopped (rewind)
+    if ((it0 & 1) != e->adam_parity) {
         const size_t half = (size_t)14 * E.d.B;
         DDX_HIP(hipMemcpyAsync(E.adam + (size_t)(it0 & 1) * half, E.adam + (size_t)e->adam_parity * half, half * sizeof(float),
                                hipMemcpyDeviceToDevice, s));
         e->adam_parity = it0 & 1;
     }
-    pose_xfm_kernel<<<dim3(E.d.B, upd_slices(E.d)), 256, 0, s>>>(E, it0);
+    return 0;
+}
+
+// step_kernel: grid (meshlets, hypotheses).  mode STEP_FIRST draws iteration `it` from the caller's parameters; STEP_NORMAL
+// steps the optimiser for the iteration before the one the device counter names and draws that one.
+static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
+{
+    EngineDev& E = e->dev;
+    const dim3 g(E.n_meshlets, E.d.B);
+#define STEP_LAUNCH(TPL, NTH, MODE)                                                          \
+    do {                                                                                     \
+        if (E.d.use_edge) step_kernel<TPL, NTH, MODE, 3><<<g, NTH, 0, s>>>(E, mode, it);     \
+        else step_kernel<TPL, NTH, MODE, 2><<<g, NTH, 0, s>>>(E, mode, it);                  \
+    } while (0)
+    if (e->small_mesh) STEP_LAUNCH(1, 64, 1);
+    else if (E.scatter_mode == 3) STEP_LAUNCH(2, 256, 3);
+    else if (E.scatter_mode == 2) STEP_LAUNCH(2, 256, 2);
+    else STEP_LAUNCH(2, 256, 0);
+#undef STEP_LAUNCH
     DDX_LAUNCH_CHECK();
     return 0;
 }
 
-static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
+// the rest of an iteration after its step_kernel: tile pass for large triangles, shading (+ edge term)
+static int launch_rest(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
 {
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
-    if (int err = raster_run(E.clip, E.stri, d.B, d.V, d.T, d.H, d.W, E.L, s, false, ev ? ev + K_SCATTER : nullptr)) return err;
+    if (ev) DDX_HIP(hipEventRecord(ev[K_BIG], s));
+    big_pass_kernel<<<RASTER_BIG_GRID, 256, 0, s>>>(E);
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
     {
         dim3 g = shade_grid(d);
@@ -1547,17 +1604,27 @@ static int run_iteration(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT
         if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E);
         else shade_kernel<false><<<g, 256, 0, s>>>(E);
     }
-    if (d.use_edge) {
-        if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
-        edge_kernel<<<edge_grid(d), 256, 0, s>>>(E);
-    }
-    if (ev) DDX_HIP(hipEventRecord(ev[K_UPDATE], s));
-#define UPD_GRID dim3(d.B, upd_slices(d))
-    if (d.use_edge) update_xfm_kernel<3><<<UPD_GRID, 256, 0, s>>>(E);
-    else update_xfm_kernel<2><<<UPD_GRID, 256, 0, s>>>(E);
-    if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
+    if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
+    if (d.use_edge) edge_kernel<<<edge_grid(d), 256, 0, s>>>(E);
+    if (ev) DDX_HIP(hipEventRecord(ev[K_FINISH], s));
     DDX_LAUNCH_CHECK();
     return 0;
+}
+
+static int launch_finish(ddx_engine* e, hipStream_t s)
+{
+    EngineDev& E = e->dev;
+    const dim3 g(upd_slices(E.d), E.d.B);
+    if (E.d.use_edge) finish_kernel<3><<<g, 256, 0, s>>>(E);
+    else finish_kernel<2><<<g, 256, 0, s>>>(E);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+static int run_iteration(ddx_engine* e, hipStream_t s)  // one iteration after the first of a run
+{
+    if (int err = launch_step(e, STEP_NORMAL, 0, s)) return err;
+    return launch_rest(e, s, nullptr);
 }
 
 static int check_desc(const ddx_engine_desc* d)
@@ -1622,17 +1689,17 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         E.s_shade = (int)shade_grid(*desc).y;
         E.s_edge = desc->use_edge ? (int)edge_grid(*desc).y : 0;
         E.pslices = E.s_shade > E.s_edge ? E.s_shade : E.s_edge;
+        E.cull_sign = 0;
+        E.scatter_mode = 0;
+        E.n_meshlets = 0;
+        for (int c = 0; c < 6; ++c) E.bbox[c] = 0.f;
     }
+    e->small_mesh = mesh_is_small(*desc);
     const size_t need = engine_layout(e->dev, *desc, b.scratch);
     if (b.scratch_bytes < need) {
         delete e;
         DDX_REQUIRE(false, DDX_E_SCRATCH, "engine_create: scratch %zu < required %zu bytes", b.scratch_bytes, need);
     }
-#ifdef DDX_TRACE
-    DDX_HIP(hipMalloc(&e->dev.trace, (size_t)4 * 8192 * 4 * 8));
-    DDX_HIP(hipMemset(e->dev.trace, 0, (size_t)4 * 8192 * 4 * 8));
-    e->dev.L.trace = e->dev.trace;
-#endif
     *out = e;
     return 0;
 }
@@ -1702,18 +1769,25 @@ __global__ __launch_bounds__(256) void build_texq_kernel(EngineDev E)
     Q[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+static inline float __uint_as_float_host(unsigned u)
+{
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 static int engine_setup(ddx_engine* e, hipStream_t s)
 {
     EngineDev& E = e->dev;
     DDX_HIP(hipMemsetAsync(E.st, 0, sizeof(EngineState), s));
     DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)2 * 14 * E.d.B * sizeof(float), s));
-    DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // kept zero by update_xfm_kernel afterwards
-    DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // re-armed per active tile by update_xfm_kernel
+    DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // (both parities) kept zero by update_head afterwards
+    DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // (both parities) re-armed per active tile by update_head
     setup_kernel<<<1, 1024, 0, s>>>(E);
     if (E.d.use_edge) edge_setup_kernel<<<1, 1024, 0, s>>>(E);
     if (!e->mesh_done && E.texq && E.b.tex) build_texq_kernel<<<ddx_cdiv((long long)E.d.Th * E.d.Tw, 256), 256, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
-    DDX_HIP(hipMemsetD32Async((hipDeviceptr_t)E.cull_ok, 1, (size_t)E.d.B * 8, s));
+    DDX_HIP(hipMemsetD32Async((hipDeviceptr_t)E.inside, 1, (size_t)E.d.B, s));
     // ---- internal sorted mesh (host, once per engine).  (1) Vertices renumbered in Morton order of their object-space
     // position: the vertex data of neighbouring triangles and pixels become neighbours in memory whatever order the mesh
     // file had.  (2) Processing order of the rasteriser: triangles sorted by the Morton code of their centroid -- the 64-bit
@@ -1766,20 +1840,72 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             keys[(size_t)t] = ((unsigned long long)morton(m) << 32) | (unsigned)t;
         }
         std::sort(keys.begin(), keys.begin() + T);
-        std::vector<int4> hrec((size_t)T);
-        auto rm = [&](int i) { return (i >= 0 && i < V) ? vnew[(size_t)i] : i; };
-        for (int i = 0; i < T; ++i) {
-            const int t = (int)(unsigned)(keys[(size_t)i] & 0xffffffffull);
-            hrec[(size_t)i] = make_int4(rm(htri[(size_t)t * 3 + 0]), rm(htri[(size_t)t * 3 + 1]), rm(htri[(size_t)t * 3 + 2]), t);
+        // ---- meshlets: the triangles in Morton order of their centroids (the fragments of a wave's triangles then share zbuf
+        // lines: the 64-bit atomicMin stream is bound by distinct lines per instruction), cut greedily into runs of at most
+        // mesh_ntri triangles over at most mesh_nvc distinct vertices.  Triangles with an index outside [0, V) are left out
+        // (they draw nothing).  A vertex is OWNED by the first meshlet that uses it: that workgroup stores its clip / snap.
+        {
+            const int NTRI = E.mesh_ntri, NVC = E.mesh_nvc;
+            auto rm = [&](int i) { return vnew[(size_t)i]; };
+            std::vector<float4> hv;
+            std::vector<int2> ht;
+            std::vector<int> slot_of((size_t)V, -1), stamp((size_t)V, -1);
+            std::vector<char> owned((size_t)V, 0);
+            std::vector<float> spos((size_t)V * 3);
+            for (int n = 0; n < V; ++n)
+                for (int c = 0; c < 3; ++c) spos[(size_t)n * 3 + c] = hpos[(size_t)vold[(size_t)n] * 3 + c];
+            int M = 0, nt = 0, nv = 0;
+            auto open_meshlet = [&]() {
+                hv.resize((size_t)(M + 1) * NVC, make_float4(0.f, 0.f, 0.f, __uint_as_float_host(0xffffffffu)));
+                ht.resize((size_t)(M + 1) * NTRI, make_int2(0, -1));
+                nt = 0; nv = 0;
+            };
+            open_meshlet();
+            for (int i = 0; i < T; ++i) {
+                const int t = (int)(unsigned)(keys[(size_t)i] & 0xffffffffull);
+                const int o[3] = {htri[(size_t)t * 3 + 0], htri[(size_t)t * 3 + 1], htri[(size_t)t * 3 + 2]};
+                if (o[0] < 0 || o[1] < 0 || o[2] < 0 || o[0] >= V || o[1] >= V || o[2] >= V) continue;
+                const int v[3] = {rm(o[0]), rm(o[1]), rm(o[2])};
+                int fresh = 0;
+                for (int k = 0; k < 3; ++k) {
+                    bool seen = stamp[(size_t)v[k]] == M;
+                    for (int k2 = 0; k2 < k; ++k2) seen = seen || v[k2] == v[k];
+                    fresh += !seen;
+                }
+                if (nt == NTRI || nv + fresh > NVC) {
+                    ++M;
+                    open_meshlet();
+                }
+                int l[3];
+                for (int k = 0; k < 3; ++k) {
+                    if (stamp[(size_t)v[k]] != M) {
+                        stamp[(size_t)v[k]] = M;
+                        slot_of[(size_t)v[k]] = nv;
+                        unsigned bits = (unsigned)v[k];
+                        if (!owned[(size_t)v[k]]) { owned[(size_t)v[k]] = 1; bits |= 0x80000000u; }
+                        hv[(size_t)M * NVC + nv] = make_float4(spos[(size_t)v[k] * 3], spos[(size_t)v[k] * 3 + 1], spos[(size_t)v[k] * 3 + 2], __uint_as_float_host(bits));
+                        ++nv;
+                    }
+                    l[k] = slot_of[(size_t)v[k]];
+                }
+                ht[(size_t)M * NTRI + nt] = make_int2(l[0] | (l[1] << 10) | (l[2] << 20), t);
+                ++nt;
+            }
+            E.n_meshlets = M + 1;
+            DDX_HIP(hipMemcpyAsync(E.mvert, hv.data(), hv.size() * sizeof(float4), hipMemcpyHostToDevice, s));
+            DDX_HIP(hipMemcpyAsync(E.mtri, ht.data(), ht.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+            DDX_HIP(hipMemcpyAsync(E.vold, vold.data(), vold.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            DDX_HIP(hipMemcpyAsync(E.vnew, vnew.data(), vnew.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            remap_vertices_kernel<<<ddx_cdiv(V, 256), 256, 0, s>>>(E);
+            remap_triangles_kernel<<<ddx_cdiv(T, 256), 256, 0, s>>>(E);
+            DDX_LAUNCH_CHECK();
+            DDX_HIP(hipStreamSynchronize(s));  // (the host vectors above are the copy sources)
         }
-        DDX_HIP(hipMemcpyAsync(E.trisort, hrec.data(), hrec.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        DDX_HIP(hipMemcpyAsync(E.vold, vold.data(), vold.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        DDX_HIP(hipMemcpyAsync(E.vnew, vnew.data(), vnew.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        remap_vertices_kernel<<<ddx_cdiv(V, 256), 256, 0, s>>>(E);
-        remap_triangles_kernel<<<ddx_cdiv(T, 256), 256, 0, s>>>(E);
-        DDX_LAUNCH_CHECK();
-        DDX_HIP(hipStreamSynchronize(s));  // (the host vectors above are the copy sources)
-        E.L.trisort = E.trisort;
+        // object-space bounding box of ALL vertices (the view-volume test of the culling rule, EngineDev::cull_sign)
+        bool finite = true;
+        for (int v = 0; v < V; ++v)
+            for (int c = 0; c < 3; ++c) finite = finite && std::isfinite(hpos[(size_t)v * 3 + c]);
+        for (int c = 0; c < 3; ++c) { E.bbox[c] = finite ? lo[c] : 0.f; E.bbox[3 + c] = finite ? hi[c] : 0.f; }
         // ---- back-face culling (RasterScratch::cull_sign): only for a CLOSED, consistently oriented surface.  Vertices are
         // welded by position (bit-equal coordinates: uv seams duplicate vertices), triangles with two welded corners equal are
         // ignored (they have no area in any view), and every welded edge must then belong to exactly two triangles that run
@@ -1787,9 +1913,8 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         // det [p0; p1; p2] > 0 exactly when its counter-clockwise normal points away from the camera; the projection maps that
         // determinant to the screen orientation times det A, A = the x, y, w rows of proj (their 4th column must be zero, as
         // in any pinhole projection); and counter-clockwise is outward when the signed volume is positive.
-        E.L.cull_sign = 0;
-        E.L.cull_ok = E.cull_ok;
-        bool want = !E.d.no_backface_cull;
+        E.cull_sign = 0;
+        bool want = !E.d.no_backface_cull && finite;
         if (const char* ov = getenv("DDX_NO_CULL")) want = want && !atoi(ov);
         if (want) {
             std::vector<unsigned long long> vk((size_t)V);
@@ -1865,7 +1990,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             const bool pinhole = hp[3] == 0.f && hp[7] == 0.f && hp[15] == 0.f;
             if (getenv("DDX_DEBUG_CULL")) fprintf(stderr, "ddx cull: closed %d pinhole %d vol6 %g detA %g edges %zu\n", (int)closed, (int)pinhole, vol6, detA, ek.size());
             if (closed && pinhole && vol6 != 0.0 && detA != 0.0 && std::isfinite(vol6) && std::isfinite(detA))
-                E.L.cull_sign = ((vol6 > 0.0) == (detA > 0.0)) ? 1 : -1;
+                E.cull_sign = ((vol6 > 0.0) == (detA > 0.0)) ? 1 : -1;
         }
         e->mesh_done = true;
     }
@@ -1901,13 +2026,13 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         DDX_HIP(hipMemcpyAsync(E.seg_G, hG.data(), hG.size() * sizeof(double), hipMemcpyHostToDevice, s));
         DDX_HIP(hipStreamSynchronize(s));  // (host vectors are the copy sources)
         const double per_tri = 2.0 * (hst.c_mask / 3.0) / (double)std::max(E.d.T, 1);
-        E.L.scatter_exchange = per_tri > SCATTER_EXCHANGE_PER_TRI ? 1 : 0;
+        E.scatter_mode = per_tri > SCATTER_EXCHANGE_PER_TRI ? 2 : 0;
         // micro-polygon regime on a launch of three or more rounds of resident workgroups (cfg3: 12 800 workgroups, cfg50k64: 6 400):
-        // the compacting variant (2) -- survivors of the bbox / area / back-face tests packed into full waves before the coverage
-        // and fragment code: scatter 32.7 -> 31.5 us on cfg3, 33.6 -> 32.0 on cfg3ref, 19.5 -> 19.2 on cfg50k64; on shorter
-        // launches (cfg2, cfg4: 2 560 / 3 776 workgroups, latency-bound) it costs 0.8 us
-        if (!E.L.scatter_exchange && (long long)ddx_cdiv(E.d.T, 512) * E.d.B >= 6000) E.L.scatter_exchange = 2;
-        if (const char* ov = getenv("DDX_SCATTER_EXCHANGE")) { const int v = atoi(ov); E.L.scatter_exchange = v < 0 ? 0 : (v > 2 ? 2 : v); }
+        // the compacting variant (3) -- survivors of the bbox / area / back-face tests packed into full waves before the coverage
+        // and fragment code
+        if (!E.scatter_mode && (long long)E.n_meshlets * E.d.B >= 6000) E.scatter_mode = 3;
+        if (const char* ov = getenv("DDX_SCATTER_EXCHANGE")) { const int v = atoi(ov); E.scatter_mode = v <= 0 ? 0 : (v >= 2 ? 3 : 2); }  // 0 plain, 1 hybrid, 2 compacting
+        if (const char* ov = getenv("DDX_SCATTER_MODE")) { const int v = atoi(ov); E.scatter_mode = (v == 2 || v == 3) ? v : 0; }
     }
     e->setup_done = true;
     return 0;
@@ -1924,13 +2049,17 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
         if (int err = engine_setup(e, s)) return err;
     if (n == 0) return 0;
     if (int err = run_prologue(e, it0, s)) return err;
-    if (use_graph && !e->exec) {
+    // iteration it0 is drawn from the caller's parameters; each later step_kernel first steps the optimiser for the iteration
+    // before it; finish_kernel steps it for the last one
+    if (int err = launch_step(e, STEP_FIRST, it0, s)) return err;
+    if (int err = launch_rest(e, s, nullptr)) return err;
+    if (use_graph && !e->exec && n > 1) {
         hipStream_t cs;
         DDX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         DDX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int err = 0;
         e->graph_chunk = std::max(1, std::min(use_graph, 64));  // use_graph = iterations per captured graph
-        for (int k = 0; k < e->graph_chunk && !err; ++k) err = run_iteration(e, cs, nullptr);
+        for (int k = 0; k < e->graph_chunk && !err; ++k) err = run_iteration(e, cs);
         hipError_t ce = hipStreamEndCapture(cs, &e->graph);
         if (err || ce != hipSuccess) {
             (void)hipStreamDestroy(cs);
@@ -1940,32 +2069,19 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
         DDX_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
         DDX_HIP(hipStreamDestroy(cs));
     }
-    for (int i = 0; i < n;) {
-        if (use_graph && i + e->graph_chunk <= n) {
+    for (int i = 1; i < n;) {
+        if (use_graph && e->exec && i + e->graph_chunk <= n) {
             DDX_HIP(hipGraphLaunch(e->exec, s));
             i += e->graph_chunk;
         } else {
-            if (int err = run_iteration(e, s, nullptr)) return err;
+            if (int err = run_iteration(e, s)) return err;
             ++i;
         }
     }
+    if (int err = launch_finish(e, s)) return err;
     e->adam_parity = (it0 + n) & 1;
     return 0;
 }
-
-#ifdef DDX_TRACE
-extern "C" int ddx_engine_trace_dump(ddx_engine* e, const char* path)
-{
-    std::vector<unsigned long long> h((size_t)4 * 8192 * 4);
-    DDX_HIP(hipDeviceSynchronize());
-    DDX_HIP(hipMemcpy(h.data(), e->dev.trace, h.size() * 8, hipMemcpyDeviceToHost));
-    FILE* f = fopen(path, "wb");
-    if (!f) return -1;
-    fwrite(h.data(), 8, h.size(), f);
-    fclose(f);
-    return 0;
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // get_argmin / get_pose (diffdope.py:1488-1513,1618-1632) for the local hypotheses, on the device: mean over the used
@@ -2022,9 +2138,11 @@ extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* lo
     if (!e->setup_done)
         if (int err = engine_setup(e, s)) return err;
     if (int err = run_prologue(e, it, s)) return err;
-    e->dev.eval_grad = grad_out;
+    int err = launch_step(e, STEP_FIRST, it, s);
+    if (!err) err = launch_rest(e, s, nullptr);
+    e->dev.eval_grad = grad_out;  // (finish_kernel in evaluation mode: hands out gradient and losses, steps nothing)
     e->dev.eval_loss = loss_out;
-    const int err = run_iteration(e, s, nullptr);
+    if (!err) err = launch_finish(e, s);
     e->dev.eval_grad = nullptr;
     e->dev.eval_loss = nullptr;
     return err;
@@ -2051,7 +2169,7 @@ extern "C" int ddx_render_loss_bwd(ddx_engine* e, int it, float* grad_out, void*
     return ddx_engine_eval(e, it, grad_out, nullptr, stream);
 }
 
-// stand-alone optimiser steps over n floats (the engine's own loop has them fused into update_xfm_kernel)
+// stand-alone optimiser steps over n floats (the engine's own loop has them fused into step_kernel)
 __global__ void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g, float lr, int n)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -2063,7 +2181,7 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    // (the expressions of update_xfm_kernel, so a caller stepping with this gets the engine's trajectory bit for bit)
+    // (the expressions of update_head, so a caller stepping with this gets the engine's trajectory bit for bit)
     const float c1 = 1.f - exp2f((float)step * log2f(b1)), c2 = 1.f - exp2f((float)step * log2f(b2));
     const float gi = g[i];
     const float m1 = b1 * m[i] + (1.f - b1) * gi;
@@ -2108,7 +2226,7 @@ extern "C" int ddx_engine_new_observation(ddx_engine* e)
     return 0;
 }
 
-extern "C" int ddx_engine_cull_sign(ddx_engine* e) { return (e && e->setup_done) ? e->dev.L.cull_sign : 0; }
+extern "C" int ddx_engine_cull_sign(ddx_engine* e) { return (e && e->setup_done) ? e->dev.cull_sign : 0; }
 
 extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_out, const char** names_out, int max_k, void* stream)
 {
@@ -2122,22 +2240,32 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     hipEvent_t ev[K_COUNT + 1];
     for (auto& x : ev) DDX_HIP(hipEventCreate(&x));
     for (int k = 0; k < K_COUNT; ++k) ms_out[k] = 0.f;
+    // iteration it0 is drawn by the first-iteration form of step_kernel (no optimiser step in it): timed only when it is the
+    // only one; the later iterations are the steady state
+    int timed = 0;
     for (int i = 0; i < iters; ++i) {
-        if (int err = run_iteration(e, s, ev)) return err;
-        DDX_HIP(hipEventSynchronize(ev[K_COUNT]));
-        for (int k = 0; k < K_COUNT; ++k) {
-            if (k == K_EDGE && !e->dev.d.use_edge) continue;  // not launched, no event recorded: 0
-            const int k_end = (k + 1 == K_EDGE && !e->dev.d.use_edge) ? K_UPDATE : k + 1;
+        DDX_HIP(hipEventRecord(ev[K_STEP], s));
+        if (int err = launch_step(e, i == 0 ? STEP_FIRST : STEP_NORMAL, it0, s)) return err;
+        if (int err = launch_rest(e, s, ev)) return err;
+        DDX_HIP(hipEventSynchronize(ev[K_FINISH]));
+        if (i == 0 && iters > 1) continue;
+        ++timed;
+        for (int k = K_STEP; k < K_FINISH; ++k) {
             float ms = 0.f;
-            DDX_HIP(hipEventElapsedTime(&ms, ev[k], ev[k_end]));
+            DDX_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             ms_out[k] += ms;
         }
     }
+    DDX_HIP(hipEventRecord(ev[K_FINISH], s));
+    if (int err = launch_finish(e, s)) return err;
+    DDX_HIP(hipEventRecord(ev[K_COUNT], s));
+    DDX_HIP(hipEventSynchronize(ev[K_COUNT]));
     e->adam_parity = (it0 + iters) & 1;
-    for (int k = 0; k < K_COUNT; ++k) {
-        ms_out[k] /= (float)iters;
+    for (int k = K_STEP; k < K_FINISH; ++k) ms_out[k] /= (float)timed;
+    if (!e->dev.d.use_edge) ms_out[K_EDGE] = 0.f;  // (not launched)
+    DDX_HIP(hipEventElapsedTime(&ms_out[K_FINISH], ev[K_FINISH], ev[K_COUNT]));  // once per run, not per iteration
+    for (int k = 0; k < K_COUNT; ++k)
         if (names_out) names_out[k] = kKernelNames[k];
-    }
     for (auto& x : ev) (void)hipEventDestroy(x);
     return K_COUNT;
 }

@@ -181,12 +181,13 @@ class RefineEngine:
         self.it = it
 
     def status(self):
-        """dict(overflow (always 0), big_triangles (0/1: the tile pass ran), active_tiles, it, n_seg, outside_view_volume (hypotheses
-        of the last iteration with a vertex at w <= 0 or |z| > w: near-plane clipping and two-sided drawing for those)) -- synchronises."""
+        """dict(overflow (always 0), big_triangles (0/1: the tile pass ran), active_tiles, it (the last iteration drawn), n_seg,
+        outside_view_volume (hypotheses of the last iteration whose bounding box had a corner at w <= 0 or |z| > w: near-plane
+        clipping and two-sided drawing for those)) -- synchronises."""
         p = self.lib.ddx_engine_status_ptr(self.handle)
         off = p - self.scratch.data_ptr()
         st = self.scratch[off:off + 32].view(torch.int32).cpu().tolist()
-        return dict(overflow=st[0], big_triangles=st[1], active_tiles=st[2], it=st[3], n_seg=st[4], outside_view_volume=st[6])
+        return dict(overflow=st[0], big_triangles=st[1], active_tiles=st[2], it=st[5] - 1, n_seg=st[4], outside_view_volume=st[6])
 
     def check(self):
         st = self.status()

@@ -257,9 +257,10 @@ int ddx_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
  * pose row-major): this rank's row of the [world,18] table that ONE all_reduce(SUM) exchanges. */
 int ddx_select_best(const float* loss_rows, int row_mask, int B, const float* mtx, int lo, float* out18, void* stream);
 /* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
- * iteration, [2] active tiles of the last iteration, [3] next iteration index, [4] pixels with seg != 0, [5] internal,
- * [6] hypotheses of the last iteration with a vertex outside the view volume (w <= 0 or |z| > w): their triangles with a vertex
- * at w <= 0 took the near-plane clipping path and their back faces were drawn -- 0 in any sane refinement */
+ * iteration, [2] active tiles of the last iteration, [3] internal, [4] pixels with seg != 0, [5] last iteration drawn + 1,
+ * [6] hypotheses of the last iteration whose object-space bounding box had a corner outside the view volume (w <= 0 or
+ * |z| > w): their triangles with a vertex at w <= 0 took the near-plane clipping path and their back faces were drawn -- 0 in any
+ * sane refinement */
 const int32_t* ddx_engine_status_ptr(ddx_engine* e);
 /* 0: the engine draws both faces (mesh not closed, projection not a pinhole, no_backface_cull, or not set up yet: the
  * decision is taken by the first run / eval); +1 / -1: triangles whose snapped screen area has this sign are culled as back

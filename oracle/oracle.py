@@ -126,13 +126,32 @@ def argmin_losses(losses_values):
 
 # --------------------------------------------------------------------------------------------
 # renderer ops (nvdiffrast semantics at diffdope.py:143-231) -- parity unpinned
-def rasterize_fwd(pos, tri, H, W, cull_sign=0):
+def rasterize_fwd(pos, tri, H, W, cull=None):
+    """cull: None (both faces, dr.rasterize) or int32 [B]: per hypothesis 0 or the snapped-area sign of the back faces to skip
+    (deviation D5, see view_volume_cull)."""
     dt = pos.dtype
     pos, tri = _c(pos, dt), _i32(tri)
     B, V = pos.shape[:2]
     rast = np.empty((B, H, W, 4), dt)
-    _lib(dt).orc_rasterize_fwd(_p(pos), B, V, _p(tri), tri.shape[0], H, W, _p(rast), int(cull_sign))
+    cb = None if cull is None else np.ascontiguousarray(np.broadcast_to(np.asarray(cull, np.int32), (B,)))
+    _lib(dt).orc_rasterize_fwd(_p(pos), B, V, _p(tri), tri.shape[0], H, W, _p(rast), _p(cb) if cb is not None else None)
     return rast
+
+
+def view_volume_cull(pos, final, cull_sign):
+    """Per-hypothesis culling decision of the fused engine (deviation D5): cull_sign where the 8 corners of the object-space
+    bounding box of ALL vertices, taken through the same k-ordered fma transform as the vertices (xfm_fwd), have w > 0 and
+    -w <= z <= w -- the three conditions are half-spaces of object space, so they then hold at every vertex and the closed
+    surface is drawn whole -- else 0.  A mesh with a non-finite coordinate never culls."""
+    dt = final.dtype
+    B = final.shape[0]
+    if not cull_sign or not np.all(np.isfinite(pos)):
+        return np.zeros(B, np.int32)
+    lo, hi = pos.min(0), pos.max(0)
+    corners = np.array([[hi[0] if c & 1 else lo[0], hi[1] if c & 2 else lo[1], hi[2] if c & 4 else lo[2]] for c in range(8)], dt)
+    cc = xfm_fwd(corners[None], final, True)  # [B,8,4]
+    ok = (cc[..., 3] > 0) & (cc[..., 2] >= -cc[..., 3]) & (cc[..., 2] <= cc[..., 3])
+    return np.where(ok.all(1), np.int32(cull_sign), np.int32(0)).astype(np.int32)
 
 
 def mesh_cull_sign(pos, tri, proj):
@@ -345,7 +364,8 @@ class RenderOracle:
         pos_clip = xfm_fwd(self.pos[None], final, True)  # :196
         if self._cull_sign is None:
             self._cull_sign = mesh_cull_sign(self.pos, self.tri, self.proj)
-        rast = rasterize_fwd(pos_clip, self.tri, self.H, self.W, self._cull_sign if self.cull_backfaces else 0)  # :198
+        cull = view_volume_cull(self.pos, final, self._cull_sign) if self.cull_backfaces else None
+        rast = rasterize_fwd(pos_clip, self.tri, self.H, self.W, cull)  # :198
         posw = np.concatenate([self.pos, np.ones((self.pos.shape[0], 1), dt)], axis=1)[None]
         gb_pos = interpolate_fwd(posw, rast, self.tri)  # :203
         gb3 = np.ascontiguousarray(gb_pos[..., :3]).reshape(B, -1, 3)

@@ -140,7 +140,7 @@ def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
     assert a[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and a[-7].endswith("bench.py")
     # and the byte models the JSON line carries are self-consistent
     c = bench.compulsory_bytes(10449, 20480, 307200, 64, 1600, 228000.0, True, 2, 16, dict(rgb=True, depth=False, mask=True, edge=False))
-    assert abs(c["iteration"] - (c["scatter_kernel"] + c["shade_kernel"] + c["update_xfm_kernel"])) < 1e-6
+    assert abs(c["iteration"] - (c["step_kernel"] + c["shade_kernel"])) < 1e-6
     assert 0 < c["shade_kernel"] < bench.algorithmic_bytes(10449, 20480, 307200, 64)["shade_kernel"]
 
 

@@ -196,7 +196,8 @@ def test_d5_backface_culling_only_on_closed_meshes_and_invisible_there():
     their back-facing triangles.  nvdiffrast draws both faces; on a closed surface every pixel centre is covered by as many
     front as back faces and the nearest is a front face, so the drawn image is the same: zero pixels change owner over a
     sweep of poses here.  The rule switches itself off for open / inconsistently oriented meshes, non-pinhole projections and
-    for any hypothesis with a vertex outside the view volume (where the drawn surface may be open)."""
+    for any hypothesis whose object-space bounding box has a corner outside the view volume (w <= 0 or |z| > w; inside at the 8
+    corners means inside at every vertex: the drawn surface is whole)."""
     from diffdope_amd import synthetic as syn
 
     pos, tri, uv = syn.blob_mesh(12, 16, seed=0)
@@ -227,25 +228,34 @@ def test_d5_backface_culling_only_on_closed_meshes_and_invisible_there():
         q = syn.random_quat(rng)
         t = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), -rng.uniform(1.2, 3.0)])
         mtx = orc.pose_fwd(np.concatenate([q, t])[:, None].astype(np.float32))
-        clip = orc.xfm_fwd(pos[None], np.matmul(proj[None].astype(np.float32), mtx), True)
-        a = orc.rasterize_fwd(clip, tri, H, W, 0)
-        b = orc.rasterize_fwd(clip, tri, H, W, -1)
+        final = np.matmul(proj[None].astype(np.float32), mtx)
+        clip = orc.xfm_fwd(pos[None], final, True)
+        cull = orc.view_volume_cull(pos, final, -1)
+        assert cull.tolist() == [-1]  # the whole bounding box is in front of the near plane: the rule is on
+        a = orc.rasterize_fwd(clip, tri, H, W)
+        b = orc.rasterize_fwd(clip, tri, H, W, cull)
         assert (a[..., 3] > 0).sum() > 50
         changed += int((a[..., 3] != b[..., 3]).sum())
         np.testing.assert_allclose(a[..., 2], b[..., 2], rtol=0, atol=0)  # same depth image
     assert changed == 0
     # a hypothesis poking through the near plane is NOT culled (its drawn surface is open: the inside is visible)
     mtx = orc.pose_fwd(np.array([[0.0], [0.0], [0.0], [1.0], [0.0], [0.0], [-0.3]], np.float32))
-    clip = orc.xfm_fwd(pos[None], np.matmul(proj[None].astype(np.float32), mtx), True)
+    final = np.matmul(proj[None].astype(np.float32), mtx)
+    clip = orc.xfm_fwd(pos[None], final, True)
     assert (clip[0, :, 3] <= 0).any() or (np.abs(clip[0, :, 2]) > clip[0, :, 3]).any()
-    a = orc.rasterize_fwd(clip, tri, H, W, 0)
-    b = orc.rasterize_fwd(clip, tri, H, W, -1)
-    assert np.array_equal(a, b)
+    assert orc.view_volume_cull(pos, final, -1).tolist() == [0]  # a vertex outside => a box corner outside: both faces drawn
+    # the box test is conservative: an object whose box pokes through the near plane while its vertices do not is not culled either
+    near = orc.pose_fwd(np.array([[0.0], [0.0], [0.0], [1.0], [0.0], [0.0], [-(float(np.abs(pos).max()) + 0.012)]], np.float32))
+    fin2 = np.matmul(proj[None].astype(np.float32), near)
+    c2 = orc.xfm_fwd(pos[None], fin2, True)[0]
+    if ((c2[:, 3] > 0) & (c2[:, 2] >= -c2[:, 3]) & (c2[:, 2] <= c2[:, 3])).all():
+        assert orc.view_volume_cull(pos, fin2, -1).tolist() in ([0], [-1])
+    assert orc.view_volume_cull(np.concatenate([pos, [[np.nan, 0, 0]]]).astype(np.float32), final, -1).tolist() == [0]  # non-finite mesh: never
     # what the rule avoids: FORCING it on an open surface removes what is seen through the hole
     open_tri = tri[np.linalg.norm(pos[tri].mean(1) - pos[tri].mean(1)[0], axis=1) > 0.35]  # cut a cap off
     mtx = orc.pose_fwd(np.concatenate([syn.random_quat(np.random.RandomState(0)), [0, 0, -2.0]])[:, None].astype(np.float32))
     clip = orc.xfm_fwd(pos[None], np.matmul(proj[None].astype(np.float32), mtx), True)
-    both = np.stack([orc.rasterize_fwd(clip, open_tri, H, W, s)[0, ..., 3] > 0 for s in (0, -1)])
+    both = np.stack([orc.rasterize_fwd(clip, open_tri, H, W, None if s == 0 else np.array([s], np.int32))[0, ..., 3] > 0 for s in (0, -1)])
     assert orc.mesh_cull_sign(pos, open_tri, proj) == 0 and both[0].sum() >= both[1].sum()
 
 
