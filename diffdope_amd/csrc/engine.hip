@@ -111,6 +111,8 @@ struct EngineDev {
                       // for an unused slot.  Every referenced vertex is owned by exactly one meshlet (the first that uses it).
     int2* mtri;       // [M, mesh_ntri] (l0 | l1 << 10 | l2 << 20 local vertex slots, original triangle id or -1 for an unused slot)
     int n_meshlets, mesh_ntri, mesh_nvc;
+    unsigned long long* trace;  // DDX_TRACE=1: [3 kernels][TRACE_WG workgroups][8] s_memrealtime stamps of thread 0 (tools/trace_kernels.py), else null
+    int step_xcd;     // step_kernel grid: 0 = (slots, B); 1 = (B, slots): all workgroups of hypothesis b on XCD b % 8 (observed placement)
     int scatter_mode; // scatter_resolve MODE of the dense variant: 0 plain, 2 hybrid, 3 compacting (the small-mesh variant is MODE 1)
     // Back-face culling for CLOSED meshes (deviation D5).  A closed, consistently oriented surface that lies
     // entirely inside the view volume covers every pixel centre with as many front- as back-facing triangles, and the nearest one
@@ -142,6 +144,14 @@ struct EngineDev {
     float* eval_tmp;         // [7,B] gradient sink of ddx_render_loss_fwd
 };
 
+#define TRACE_WG 4096
+// stamp i of kernel slot k (0 step, 1 shade, 2 other) for this workgroup: 100 MHz constant clock
+#define STAMP(E, k, wg, i)                                                                                  \
+    do {                                                                                                    \
+        if ((E).trace && threadIdx.x == 0 && (wg) < TRACE_WG)                                               \
+            (E).trace[((size_t)(k) * TRACE_WG + (wg)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();         \
+    } while (0)
+
 struct ddx_engine {
     EngineDev dev;
     hipGraph_t graph = nullptr;
@@ -149,6 +159,7 @@ struct ddx_engine {
     int graph_chunk = 1;  // iterations per captured graph
     bool setup_done = false;
     bool mesh_done = false;  // the mesh half of the setup (sorted copies, meshlets, triangle / texel records, closedness) survives ddx_engine_new_observation
+    int step_resident = 0;     // step_kernel workgroups the chip holds at once (step_capacity, asked once); DDX_STEP_RESIDENT overrides
     bool small_mesh = false; // step_kernel variant: one triangle per lane in 64-thread workgroups (few triangles x hypotheses)
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
@@ -439,7 +450,7 @@ __device__ __forceinline__ void acc_vertex_regs(PixAcc& A, float x, float y, flo
 
 
 #ifndef SHADE_GRID
-#define SHADE_GRID 1024  // shade workgroups per role (slices x hypotheses): measured flat 512..1536, worse above
+#define SHADE_GRID 512  // shade workgroups per role (slices x hypotheses): both roles resident at once (2 x 512 at 128 registers); with the flag scan paid once per workgroup 512 beats 384 / 640 / 768 / 1024 on cfg2-cfg5
 #endif
 #ifndef EDGE_GRID
 #define EDGE_GRID 1792  // edge_kernel workgroups (hypotheses x slices)
@@ -447,8 +458,7 @@ __device__ __forceinline__ void acc_vertex_regs(PixAcc& A, float x, float y, flo
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 4  // waves per SIMD the shade kernel is compiled for (128 VGPRs)
 #endif
-#define SCAN_U 16          // shade_kernel's flag scan: dwords per lane and chunk at most (4096 flags)
-#define SCAN_LIST 256      // ... tiles of one workgroup per chunk at most
+#define SCAN_LIST 256      // ... tiles of one workgroup held in LDS at a time (a power of two)
 #define QUAD 8             // one wave shades one 8x8 quadrant of a 16x16 tile
 #define QH (QUAD + 2)      // quadrant + 1-pixel halo
 #define PAIR_CAP 160       // >= 2*64 + 8 + 8 candidate antialias pairs per quadrant
@@ -502,6 +512,9 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     const int ov[3] = {r0.w, r1.x, r1.y};
     const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
     const float fx = (float)cx + 0.5f - hw, fy = (float)cy + 0.5f - hh;
+    // (recomputing the six clip-space vertices from the object-space table and the hypothesis' matrix instead -- so that step_kernel
+    // need not store clip at all -- was built and measured: 12 more uniform registers in this role, 34 spills, shade +1.1 us on
+    // cfg2, and step_kernel did not get faster without its 24 MB of stores: they are off its critical path)
     float4 p[3], q[3];
     float ps[3][3];
 #pragma unroll
@@ -592,6 +605,60 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     }
 }
 
+// A hypothesis' tile-flag row (shade_kernel), scanned by ONE wave in pieces of 1 KB = 1024 flags: lane l loads 16 bytes -- the flags
+// of 16 consecutive tiles -- so a piece is one coalesced request of 8 lines (lane-contiguous runs of 64 bytes were measured first:
+// 16 strided dword loads per lane made the scan 5 us of the kernel, one L1 line per cycle and CU), turns them into a 16-bit mask,
+// and the exclusive prefix of the lanes' counts comes from five ballots (no LDS).  Four pieces are in flight per trip.  The tiles
+// whose rank is sl mod S are this slice's: those numbered [win, win + SCAN_LIST) among them go to list[] (ty << 8 | tx); g_active
+// (nullable) receives the whole ordered list.  Returns the number of set flags of the row.  Kept out of line: inlined, its loop
+// nest around the shading loop cost the kernel 34 spilled registers.
+__device__ __attribute__((noinline)) static int tile_scan(const unsigned* __restrict__ frow, int n_dw, int S, int sl, float invS, int ntx, int win,
+                                                          unsigned short* list, int* g_active)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rank_base = 0;
+    for (int d0 = 0; d0 < n_dw; d0 += 4 * 256) {  // (wave-uniform; one trip up to 4096 tiles)
+        uint4 dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int di = d0 + u * 256 + lane * 4;
+            dd[u] = di < n_dw ? *reinterpret_cast<const uint4*>(frow + di) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (d0 + u * 256 >= n_dw) break;  // (wave-uniform)
+            auto nib = [](unsigned w) { return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u); };
+            unsigned fm = nib(dd[u].x) | (nib(dd[u].y) << 4) | (nib(dd[u].z) << 8) | (nib(dd[u].w) << 12);
+            const int cnt = __popc(fm);  // <= 16
+            int pre = 0, tot = 0;
+#pragma unroll
+            for (int bit = 0; bit < 5; ++bit) {
+                const unsigned long long m = __ballot((cnt >> bit) & 1);
+                pre += __popcll(m & below) << bit;
+                tot += __popcll(m) << bit;
+            }
+            if (tot == 0) continue;  // (wave-uniform)
+            int rank = rank_base + pre;
+            const int fbase = (d0 + u * 256 + lane * 4) * 4;  // tile index of the lane's first flag
+            while (fm) {  // (a few set flags on a few lanes: the object's tiles)
+                const int kbit = __ffs(fm) - 1;
+                fm &= fm - 1;
+                const int q = (int)(((float)rank + 0.5f) * invS);  // rank / S, exact for rank < 2^16
+                if (rank - q * S == sl) {
+                    const int tile = fbase + kbit;
+                    const int ty = tile / ntx, tx = tile - ty * ntx;
+                    if (q >= win && q < win + SCAN_LIST) list[q - win] = (unsigned short)((ty << 8) | tx);
+                    if (g_active) g_active[rank] = (ty << 16) | tx;
+                }
+                ++rank;
+            }
+            rank_base += tot;
+        }
+    }
+    return rank_base;
+}
+
 // ROLE 0: colour + depth terms (per covered pixel).  ROLE 1: antialiased-coverage (mask) term (silhouette
 // pairs).  The two roles only share the zbuf they read, so they are separate workgroups of ONE launch
 // (blockIdx.z picks the role): they overlap on the chip, and each body keeps its own, smaller register
@@ -601,8 +668,18 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
 
 // `pool`: per-wave LDS scratch owned by the kernel (one allocation shared by the roles, which are different
 // workgroups): 12 x 64 floats for the mask role, 24 x 64 for the edge role.
+// what a wave knows after scanning its hypothesis' tile flags (shade_kernel)
+struct TileWork {
+    int b, par, sl, S;         // hypothesis, iteration parity, slice and slices per hypothesis
+    int n_flags, n_mine;       // active tiles of the hypothesis, and of this slice
+    const unsigned* frow;      // the flag row (for further windows of the list)
+    int n_dw;
+    float invS;
+    unsigned short* list;      // LDS, this wave's: tiles [win, win + SCAN_LIST) of the slice, ty << 8 | tx
+};
+
 template <int ROLE, int NR>
-__device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict__ pool)
+__device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict__ pool, const TileWork& tw)
 {
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
     __shared__ float s_m[WAVES_PER_TILE][64];           // antialias contributions received by each pixel
@@ -614,28 +691,8 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     const RasterScratch& L = E.L;
     const float* __restrict__ pos = E.spos;
     int* ids = s_ids[wave];
-    // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's active tiles in ascending tile order.  There is no list kernel:
-    // every WAVE scans the hypothesis' row of tile flags itself (bytes written by step_kernel; NTp / 4 dwords, 5 loads per lane at
-    // 640x480, all in flight), ranks the set flags with ballots and keeps the tiles whose rank is s mod S -- no atomics, no
-    // barrier, and the first dependent level of this kernel is the flag row instead of count -> list entry.  The z = 0 role's
-    // first wave also writes the ordered list and the count for the kernels that come later (edge_kernel, update_head).
-    // grid (B, S, roles): x = hypothesis, y = slice.  Workgroups are dispatched in linear-id order and land on CUs
-    // in a fixed pattern of that id (XCD = id % 8, CU = f(id/8 % 32), measured): slice-major order sends the
-    // working slices of every hypothesis first and the idle ones (slice >= n_tiles) last, so the tail of the launch
-    // is made of workgroups that exit at once, and every CU sees the same mix of slices.
-    __shared__ unsigned short s_list[WAVES_PER_TILE][SCAN_LIST];
-    const int b = blockIdx.x;
-    const int it_cur = E.st->it_next - 1;  // the iteration being drawn (it_next is stable during this launch)
-    const int par = it_cur & 1;
-    if (ROLE == E.st_role && blockIdx.y == 0 && b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
-    const int sl = blockIdx.y, S = gridDim.y;
-    const unsigned* __restrict__ frow = reinterpret_cast<const unsigned*>(L.tile_flag + ((size_t)par * d.B + b) * L.NTp);
-    const int nu_all = L.NTp >> 8;   // dwords per lane for the whole row
-    const int UCH = min(SCAN_U, S);  // dwords per lane per chunk: a chunk holds 256 UCH flags, i.e. at most 256 UCH / S <= SCAN_LIST tiles of this slice
-    const float invS = __frcp_rn((float)S);
-    const bool lister = ROLE == E.st_role && wave == 0;
-    int* __restrict__ g_active = L.active + (size_t)b * L.NT;
-    // colour role: rows x, y, w of this hypothesis' final = proj . mtx (uniform: scalar loads, requested with the flag row)
+    const int b = tw.b, par = tw.par;
+    // colour role: rows x, y, w of this hypothesis' final = proj . mtx (uniform: scalar loads)
     float Fx[4] = {0.f, 0.f, 0.f, 0.f}, Fy[4] = {0.f, 0.f, 0.f, 0.f}, Fw[4] = {0.f, 0.f, 0.f, 0.f};
     if (ROLE == 0) {
         const float* Fm = E.mats + ((size_t)par * d.B + b) * 32 + 16;
@@ -652,43 +709,14 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     A.L[0] = A.L[1] = A.L[2] = A.L[3] = 0.f;
     const float lrb = E.b.lr_mult[b];
     const float inv_b = __fdiv_rn(1.0f, (float)d.B_global);
-    int rank_base = 0, mine_before = 0;  // set flags / tiles of this slice before the chunk (wave-uniform)
-    for (int u0 = 0; u0 < nu_all; u0 += UCH) {
-    int mine_after;
-    {
-        unsigned dw[SCAN_U];
-#pragma unroll
-        for (int u = 0; u < SCAN_U; ++u) dw[u] = (u < UCH && u0 + u < nu_all) ? frow[(size_t)(u0 + u) * 64 + lane] : 0u;
-        int cnt = 0;
-        const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-        for (int u = 0; u < SCAN_U; ++u) {
-            const unsigned dd = dw[u];
-            const unsigned long long m0 = __ballot((dd & 0xffu) != 0u), m1 = __ballot((dd & 0xff00u) != 0u), m2 = __ballot((dd & 0xff0000u) != 0u),
-                                     m3 = __ballot((dd & 0xff000000u) != 0u);
-            const int c_u = (__popcll(m0) + __popcll(m1)) + (__popcll(m2) + __popcll(m3));
-            if (c_u == 0) continue;  // (wave-uniform)
-            int r = rank_base + cnt + (__popcll(m0 & below) + __popcll(m1 & below)) + (__popcll(m2 & below) + __popcll(m3 & below));
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
-                if ((dd >> (8 * jb)) & 0xffu) {
-                    const int rank = r++;
-                    const int q = (int)(((float)rank + 0.5f) * invS);  // rank / S, exact for rank < 2^16
-                    if (rank - q * S == sl) {
-                        const int tile = ((u0 + u) * 64 + lane) * 4 + jb;
-                        const int ty = tile / L.ntx, tx = tile - ty * L.ntx;
-                        s_list[wave][q - mine_before] = (unsigned short)((ty << 8) | tx);
-                        if (lister) g_active[rank] = (ty << 16) | tx;
-                    }
-                }
-            cnt += c_u;
+    const int n_mine = tw.n_mine;
+    for (int k = 0; k < n_mine; ++k) {
+        if ((k & (SCAN_LIST - 1)) == 0 && k > 0) {  // further windows (a frame-filling object with few slices) on demand
+            wave_lds_sync();
+            tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, k, tw.list, nullptr);
+            wave_lds_sync();
         }
-        rank_base += cnt;
-        mine_after = rank_base > sl ? (rank_base - sl + S - 1) / S : 0;
-        wave_lds_sync();
-    }
-    for (int k = 0; k < mine_after - mine_before; ++k) {
-        const int txy8 = s_list[wave][k];
+        const int txy8 = tw.list[k & (SCAN_LIST - 1)];
         const int tcx = txy8 & 0xff, tcy = txy8 >> 8;
         const int qx = tcx * DDX_TILE + (wave & 1) * QUAD, qy = tcy * DDX_TILE + (wave >> 1) * QUAD;
         const float* __restrict__ P = E.clip + (size_t)b * V * 4;
@@ -944,14 +972,10 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             wave_lds_sync();
         }
     }
-    wave_lds_sync();  // (s_list is rewritten by the next chunk)
-    mine_before = mine_after;
-    }
-    if (lister && sl == 0 && lane == 0) L.b_count[b] = rank_base;
-    if (sl < rank_base) {  // (workgroup-uniform: every wave counted the same flags)
+    if (tw.sl < tw.n_flags) {  // (workgroup-uniform: every wave counted the same flags)
         // ---- wave reduction, then the four waves folded in a fixed order -> one partial row per (slice, role): bit-reproducible
         __shared__ float s_rows[WAVES_PER_TILE][NPART];
-        float* part = E.partials + (((size_t)b * E.pslices + blockIdx.y) * NR + ROLE) * NPART;
+        float* part = E.partials + (((size_t)b * E.pslices + tw.sl) * NR + ROLE) * NPART;
         constexpr int NV = NVALS - 1;  // (the 20th value, the edge loss, belongs to edge_kernel)
         float vals[NVALS];
 #pragma unroll
@@ -984,14 +1008,49 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 // Two builds of the same kernel: without and with the edge role, so that the register allocation (and scratch
 // footprint) of the reference-loss configurations does not depend on the extension.
 template <bool EDGE>
-__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E)
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E, int it_arg)
 {
-    const int z = blockIdx.z;
-    const int role = z == 0 ? E.roles[0] : E.roles[1];
+    // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's active tiles in ascending tile order.  There is no list kernel:
+    // every WAVE scans the hypothesis' row of tile flags itself (tile_scan: bytes written by step_kernel, 1.2 KB at 640x480),
+    // ranks the set flags with ballots and keeps the tiles whose rank is s mod S -- no atomics, no barrier.  The first wave of the
+    // z = 0 workgroups also writes the ordered list and the count for the kernels that come later (edge_kernel, update_head).
+    // grid (B, S, z): x = hypothesis, y = slice.  Workgroups are dispatched in linear-id order and land on CUs
+    // in a fixed pattern of that id (XCD = id % 8, CU = f(id/8 % 32), measured): slice-major order sends the
+    // working slices of every hypothesis first and the idle ones (slice >= n_tiles) last, so the tail of the launch
+    // is made of workgroups that exit at once, and every CU sees the same mix of slices.
+    // z = role (the mask role first: it takes the cold misses on zbuf).  (One workgroup running the mask role and then the colour
+    // role of its tiles -- one scan, half the workgroups -- was measured: the two roles' tile loops simply add up, 21 -> 21 us.)
     __shared__ float s_pool[WAVES_PER_TILE][12 * 64];
-    float* pool = s_pool[threadIdx.x >> 6];
-    if (role == 0) shade_body<0, EDGE ? 3 : 2>(E, pool);
-    else shade_body<1, EDGE ? 3 : 2>(E, pool);
+    __shared__ unsigned short s_list[WAVES_PER_TILE][SCAN_LIST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* pool = s_pool[wave];
+    const RasterScratch& L = E.L;
+    TileWork tw;
+    tw.b = blockIdx.x;
+    const int it_cur = it_arg >= 0 ? it_arg : E.st->it_next - 1;  // the iteration being drawn (it_next is stable during this launch)
+    tw.par = it_cur & 1;
+    if (blockIdx.z == 0 && blockIdx.y == 0 && tw.b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
+    tw.sl = blockIdx.y;
+    tw.S = gridDim.y;
+    tw.frow = reinterpret_cast<const unsigned*>(L.tile_flag + ((size_t)tw.par * E.d.B + tw.b) * L.NTp);
+    tw.n_dw = L.NTp >> 2;  // dwords of the row
+    tw.invS = __frcp_rn((float)tw.S);
+    tw.list = s_list[wave];
+    const bool lister = blockIdx.z == 0 && wave == 0;
+    const int wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    STAMP(E, 1, wg_id, 0);
+    tw.n_flags = tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, 0, tw.list, lister ? L.active + (size_t)tw.b * L.NT : nullptr);
+    tw.n_mine = tw.n_flags > tw.sl ? (tw.n_flags - tw.sl + tw.S - 1) / tw.S : 0;
+    wave_lds_sync();
+    if (lister && tw.sl == 0 && lane == 0) L.b_count[tw.b] = tw.n_flags;
+    STAMP(E, 1, wg_id, 1);
+    constexpr int NR = EDGE ? 3 : 2;
+    const int role = blockIdx.z == 0 ? E.roles[0] : E.roles[1];
+    if (role == 0) shade_body<0, NR>(E, pool, tw);
+    else shade_body<1, NR>(E, pool, tw);
+    STAMP(E, 1, wg_id, 2);
+    STAMP(E, 1, wg_id, 3);
+    if (tid == 0 && E.trace && wg_id < TRACE_WG) E.trace[((size_t)TRACE_WG + wg_id) * 8 + 4] = ((unsigned long long)blockIdx.z << 32) | (unsigned)tw.n_mine;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1003,7 +1062,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
 // texture fetch, no barycentrics -- the old edge role re-shaded the 100 halo pixels of every quadrant in two rounds.
 #define EH (QUAD + 4)  // 12: luminance halo
 #define ET (QUAD + 2)  // 10: loss terms
-__global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
+__global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg)
 {
     __shared__ float s_l[WAVES_PER_TILE][EH * EH];
     __shared__ float s_cx[WAVES_PER_TILE][ET * ET + 4], s_cy[WAVES_PER_TILE][ET * ET + 4];
@@ -1013,7 +1072,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E)
     const int H = d.H, W = d.W;
     const int b = blockIdx.x;
     const int n_tiles = L.b_count[b];  // (count and ordered list: written by shade_kernel's scan)
-    const int par = (E.st->it_next - 1) & 1;
+    const int par = (it_arg >= 0 ? it_arg : E.st->it_next - 1) & 1;
     const unsigned long long* __restrict__ zb = L.zbuf + ((size_t)par * d.B + b) * L.zper;
     const float* __restrict__ lumb = E.lumbuf + (size_t)b * H * W;
     const float lrb = E.b.lr_mult[b];
@@ -1382,64 +1441,82 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
 // The chain of one iteration used to be four launches (transform+update, scatter, compaction, shade) with the clip-space
 // vertices and their window snap travelling through HBM in between; here the optimiser step, the transform and the scatter
 // rasteriser are one workgroup-local pipeline and the compaction is gone (shade_kernel scans the flags itself).
+#ifndef STEP_MIN_WAVES
+#define STEP_MIN_WAVES 6  // waves per SIMD step_kernel is compiled for (<= 80 registers): 1536 resident 256-thread workgroups
+#endif
 template <int TPL, int NTH, int MODE, int NR>
-__global__ __launch_bounds__(NTH) void step_kernel(EngineDev E, int mode, int it_arg)
+__global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, int mode, int it_arg)
 {
     constexpr int NTRI = TPL * NTH, NVC = 2 * NTH;
     const ddx_engine_desc& d = E.d;
-    const int b = blockIdx.y, m = blockIdx.x, B = d.B, V = d.V;
+    // grid (slots, B), or (B, slots) with E.step_xcd: workgroup `slot` of hypothesis b takes the meshlets slot, slot + SL, ... --
+    // the head is paid once per workgroup, and SL is chosen so that all workgroups are resident (launch_step)
+    const int b = E.step_xcd ? blockIdx.x : blockIdx.y, slot = E.step_xcd ? blockIdx.y : blockIdx.x;
+    const int SL = E.step_xcd ? gridDim.y : gridDim.x;
+    const int B = d.B, V = d.V, M = E.n_meshlets;
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ float4 s_clip[NVC];
     __shared__ int2 s_snap[NVC];
     __shared__ float snew[8];  // the parameters this iteration is drawn with
     __shared__ float sc[64];   // update_head's scalars; 16..31 = proj
-    const int it = mode == STEP_FIRST ? it_arg : E.st->it;
+    const int wg_id = b * SL + slot;
+    STAMP(E, 0, wg_id, 0);
+    // (it_arg >= 0: the host names the iteration -- plain stream launches -- and the kernel starts without a dependent scalar load;
+    // -1: replayed from a captured graph, whose arguments are frozen: the device counter says which iteration this is)
+    const int it = it_arg >= 0 ? it_arg : E.st->it;
     const int par = it & 1;
-    // ---- the meshlet (static tables, fixed-size slots: nothing here depends on another load): requested before the head
+    // ---- the first meshlet (static tables, fixed-size slots: nothing here depends on another load): requested before the head
     float4 vr[2];
     int2 tr[TPL];
+    // workgroup `slot` draws the meshlets [slot npw, (slot + 1) npw) of the INTERLEAVED order (engine_setup: front / back of the
+    // Morton curve alternate, so a workgroup's meshlets lie on opposite sides of the object and one of each pair is culled whatever
+    // the pose: the launch used to wait for the workgroups whose meshlets were all visible).  (Handing meshlets out through a
+    // per-hypothesis ticket counter instead was built and measured: 64 hot words of returning device-scope atomics made every
+    // workgroup slower -- head 5.1 -> 9.4 us, cfg2 44.4 -> 54 us per iteration.)
+    const int npw = (M + SL - 1) / SL, m_begin = slot * npw, m_end = min(M, m_begin + npw);
+    const int m0 = min(m_begin, M - 1);  // (a slot beyond the meshlets only shares the head's re-arm work; the loop below is empty for it)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)m * NVC + u * NTH + tid];
+    for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)m0 * NVC + u * NTH + tid];
 #pragma unroll
-    for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)m * NTRI + k * NTH + tid];
+    for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)m0 * NTRI + k * NTH + tid];
     if (mode == STEP_NORMAL) {
-        update_head<NTH, NR>(E, b, it - 1, m, (int)gridDim.x, snew, sc);
+        update_head<NTH, NR>(E, b, it - 1, slot, SL, snew, sc);
     } else {
         // first iteration of a run: the parameters as the caller holds them (un-normalised)
         if (tid < 7) snew[tid] = E.b.params[(size_t)tid * B + b];
         if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
         __syncthreads();
     }
-    const bool writer = m == 0;
+    const bool writer = slot == 0;
+    STAMP(E, 0, wg_id, 1);
     // ---- pose -> matrices (every lane, from LDS broadcasts: ~150 flops, cheaper than a dependent load)
-    float q[4], t3[3], M[16], pr[4], Fr[4];
+    float Fr[4];
+    {
+        float q[4], t3[3], M4[16], pr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = snew[i];
+        for (int i = 0; i < 4; ++i) q[i] = snew[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t3[i] = snew[4 + i];
+        for (int i = 0; i < 3; ++i) t3[i] = snew[4 + i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pr[k] = sc[16 + (lane & 3) * 4 + k];  // row lane % 4 of proj
-    {   // q / |q| (diffdope.py:1091) and [R|t] (diffdope.py:46-89)
-        const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int k = 0; k < 4; ++k) pr[k] = sc[16 + (lane & 3) * 4 + k];  // row lane % 4 of proj
+        {   // q / |q| (diffdope.py:1091) and [R|t] (diffdope.py:46-89)
+            const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
-        quat_to_matrix(q, t3, M);
-    }
-    final_row(pr, M, Fr);  // row lane % 4 of final = proj . mtx (torch.matmul at :195, k-ordered fma)
-    // ---- the meshlet's vertices on the matrix core -> LDS (clip + 1/256-pixel window snap); the owner of a vertex also stores
-    // it for the antialias pass and the tile pass
+            for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
+            quat_to_matrix(q, t3, M4);
+        }
+        final_row(pr, M4, Fr);  // row lane % 4 of final = proj . mtx (torch.matmul at :195, k-ordered fma)
+        if (writer && tid < 4) {  // lanes 0..3 hold rows 0..3 of final; each writes its row of both matrices
+            float* dst = E.mats + ((size_t)par * B + b) * 32;
+            float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
+            const float Mr[4] = {tid == 0 ? M4[0] : (tid == 1 ? M4[4] : (tid == 2 ? M4[8] : M4[12])), tid == 0 ? M4[1] : (tid == 1 ? M4[5] : (tid == 2 ? M4[9] : M4[13])),
+                                 tid == 0 ? M4[2] : (tid == 1 ? M4[6] : (tid == 2 ? M4[10] : M4[14])), tid == 0 ? M4[3] : (tid == 1 ? M4[7] : (tid == 2 ? M4[11] : M4[15]))};
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const unsigned bits = __float_as_uint(vr[u].w);
-        const f32x4 acc = xfm_vertex_mfma(Fr, vr[u].x, vr[u].y, vr[u].z);
-        const float4 c4 = make_float4(acc.x, acc.y, acc.z, acc.w);
-        const int2 sn = snap_vertex(c4, d.H, d.W);
-        s_clip[u * NTH + tid] = c4;
-        s_snap[u * NTH + tid] = sn;
-        if (bits != 0xffffffffu && (bits >> 31)) {
-            const size_t g = (size_t)b * V + (bits & 0x7fffffffu);
-            *reinterpret_cast<f32x4*>(E.clip + g * 4) = acc;
-            E.L.snap[g] = sn;
+            for (int c = 0; c < 4; ++c) {
+                dst[tid * 4 + c] = Mr[c];
+                dst[16 + tid * 4 + c] = Fr[c];
+                if (logm) logm[tid * 4 + c] = Mr[c];
+            }
         }
     }
     // ---- is the whole object inside the view volume?  The 8 corners of its object-space bounding box through the same
@@ -1453,18 +1530,6 @@ __global__ __launch_bounds__(NTH) void step_kernel(EngineDev E, int mode, int it
     }
     const int cull = (E.cull_sign != 0 && inside_all) ? E.cull_sign : 0;
     if (writer) {
-        if (tid < 4) {  // lanes 0..3 hold rows 0..3 of final; each writes its row of both matrices
-            float* dst = E.mats + ((size_t)par * B + b) * 32;
-            float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
-            const float Mr[4] = {tid == 0 ? M[0] : (tid == 1 ? M[4] : (tid == 2 ? M[8] : M[12])), tid == 0 ? M[1] : (tid == 1 ? M[5] : (tid == 2 ? M[9] : M[13])),
-                                 tid == 0 ? M[2] : (tid == 1 ? M[6] : (tid == 2 ? M[10] : M[14])), tid == 0 ? M[3] : (tid == 1 ? M[7] : (tid == 2 ? M[11] : M[15]))};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dst[tid * 4 + c] = Mr[c];
-                dst[16 + tid * 4 + c] = Fr[c];
-                if (logm) logm[tid * 4 + c] = Mr[c];
-            }
-        }
         if (mode == STEP_FIRST && tid < 7) E.params2[((size_t)par * 7 + tid) * B + b] = snew[tid];
         if (tid == 0) {
             E.inside[b] = inside_all ? 1 : 0;
@@ -1476,18 +1541,6 @@ __global__ __launch_bounds__(NTH) void step_kernel(EngineDev E, int mode, int it
             }
         }
     }
-    __syncthreads();
-    // ---- the meshlet's triangles: vertices from LDS
-    int t[TPL], i0[TPL], i1[TPL], i2[TPL];
-    bool ok[TPL];
-    int2 va[TPL], vb[TPL], vc[TPL];
-#pragma unroll
-    for (int k = 0; k < TPL; ++k) {
-        ok[k] = tr[k].y >= 0;
-        t[k] = ok[k] ? tr[k].y : d.T;
-        i0[k] = tr[k].x & 1023; i1[k] = (tr[k].x >> 10) & 1023; i2[k] = (tr[k].x >> 20) & 1023;
-        va[k] = s_snap[i0[k]]; vb[k] = s_snap[i1[k]]; vc[k] = s_snap[i2[k]];
-    }
     ScatterTarget tg;
     tg.P = reinterpret_cast<const float*>(s_clip);
     tg.Z = E.L.zbuf + ((size_t)par * B + b) * E.L.zper;
@@ -1498,31 +1551,76 @@ __global__ __launch_bounds__(NTH) void step_kernel(EngineDev E, int mode, int it
     tg.bigcount = E.L.bigcount + (size_t)par * B + b;
     tg.ntx = E.L.ntx; tg.nty = E.L.nty; tg.NT = E.L.NT; tg.zwb = E.L.zwb;
     tg.ndc = E.L.ndc;
-    scatter_resolve<TPL, NTH, MODE>(tg, d.H, d.W, d.T, t, i0, i1, i2, ok, va, vb, vc, cull);
+    STAMP(E, 0, wg_id, 2);
+    for (int m = m_begin; m < m_end; ++m) {  // (workgroup-uniform)
+        // ---- the meshlet's vertices on the matrix core -> LDS (clip + 1/256-pixel window snap); the owner of a vertex also
+        // stores it for the antialias pass and the tile pass
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned bits = __float_as_uint(vr[u].w);
+            const f32x4 acc = xfm_vertex_mfma(Fr, vr[u].x, vr[u].y, vr[u].z);
+            const float4 c4 = make_float4(acc.x, acc.y, acc.z, acc.w);
+            const int2 sn = snap_vertex(c4, d.H, d.W);
+            s_clip[u * NTH + tid] = c4;
+            s_snap[u * NTH + tid] = sn;
+            if (bits != 0xffffffffu && (bits >> 31)) {
+                const size_t g = (size_t)b * V + (bits & 0x7fffffffu);
+                *reinterpret_cast<f32x4*>(E.clip + g * 4) = acc;
+                E.L.snap[g] = sn;
+            }
+        }
+        __syncthreads();
+        // ---- the meshlet's triangles: vertices from LDS
+        int t[TPL], i0[TPL], i1[TPL], i2[TPL];
+        bool ok[TPL];
+        int2 va[TPL], vb[TPL], vc[TPL];
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+            ok[k] = tr[k].y >= 0;
+            t[k] = ok[k] ? tr[k].y : d.T;
+            i0[k] = tr[k].x & 1023; i1[k] = (tr[k].x >> 10) & 1023; i2[k] = (tr[k].x >> 20) & 1023;
+            va[k] = s_snap[i0[k]]; vb[k] = s_snap[i1[k]]; vc[k] = s_snap[i2[k]];
+        }
+        // the next meshlet of this workgroup is requested now and lands while this one is rasterised
+        if (m + 1 < m_end) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)(m + 1) * NVC + u * NTH + tid];
+#pragma unroll
+            for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)(m + 1) * NTRI + k * NTH + tid];
+        }
+        STAMP(E, 0, wg_id, m == m_begin ? 3 : 5);
+        scatter_resolve<TPL, NTH, MODE>(tg, d.H, d.W, d.T, t, i0, i1, i2, ok, va, vb, vc, cull);
+        STAMP(E, 0, wg_id, m == m_begin ? 4 : 6);
+        __syncthreads();  // (s_clip / s_snap are rewritten by the next meshlet)
+    }
+    STAMP(E, 0, wg_id, 7);
 }
 
 // the optimiser step of the LAST iteration of a run (or of an evaluation pass): update_head alone, then both parities are clean
 template <int NR>
-__global__ __launch_bounds__(256) void finish_kernel(EngineDev E)
+__global__ __launch_bounds__(256) void finish_kernel(EngineDev E, int it_arg)
 {
     __shared__ float snew[8];
     __shared__ float sc[64];
-    const int b = blockIdx.y, it = E.st->it, par = it & 1;
+    const int b = blockIdx.y, it = it_arg >= 0 ? it_arg : E.st->it, par = it & 1;
     update_head<256, NR>(E, b, it - 1, (int)blockIdx.x, (int)gridDim.x, snew, sc);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         E.L.bigcount[(size_t)(1 - par) * E.d.B + b] = 0;
+
         if (b == 0) E.L.counters[3 + (1 - par)] = 0;
     }
 }
 
 // the tile pass for large / near-clipped triangles of the iteration being drawn (raster_dev.h big_pass_body); exits on one
 // scalar load when the batch has none (always, for the 20k-50k-triangle meshes of the benchmark)
-__global__ __launch_bounds__(256) void big_pass_kernel(EngineDev E)
+#define BIG_WAVES 16
+#define BIG_GRID 256
+__global__ __launch_bounds__(BIG_WAVES * 64) void big_pass_kernel(EngineDev E, int it_arg)
 {
-    const int par = (E.st->it_next - 1) & 1, B = E.d.B;
+    const int par = (it_arg >= 0 ? it_arg : E.st->it_next - 1) & 1, B = E.d.B;
     if (E.L.counters[3 + par] == 0) return;
     unsigned long long n_done = 0;
-    big_pass_body(E.clip, E.stri, E.L.snap, E.L.tile_big + (size_t)par * B * E.L.NTp, E.L.biglist, E.L.bigcount + (size_t)par * B,
+    big_pass_body<BIG_WAVES>(E.clip, E.stri, E.L.snap, E.L.tile_big + (size_t)par * B * E.L.NTp, E.L.biglist, E.L.bigcount + (size_t)par * B,
                   E.L.zbuf + (size_t)par * B * E.L.zper, E.L.zper, E.L.zwb, E.L.ntx, E.L.NT, E.L.NTp, B, E.d.V, E.d.T, E.d.H, E.d.W,
                   (int)blockIdx.x, (int)gridDim.x, n_done);
 }
@@ -1534,7 +1632,9 @@ static const char* const kKernelNames[K_COUNT] = {"step_kernel", "big_pass_kerne
 // shading grid (B, S): S slices per hypothesis, SHADE_GRID workgroups per role in total (all resident at 4 waves/SIMD)
 static dim3 shade_grid(const ddx_engine_desc& d)
 {
-    int S = d.shade_slices > 0 ? d.shade_slices : SHADE_GRID / d.B;
+    int grid = SHADE_GRID;
+    if (const char* ov = getenv("DDX_SHADE_GRID")) grid = atoi(ov);  // (tuning)
+    int S = d.shade_slices > 0 ? d.shade_slices : grid / d.B;
     if (S < 1) S = 1;
     if (S > 64) S = 64;
     return dim3(d.B, S);
@@ -1570,61 +1670,92 @@ static int run_prologue(ddx_engine* e, int it0, hipStream_t s)
     return 0;
 }
 
-// step_kernel: grid (meshlets, hypotheses).  mode STEP_FIRST draws iteration `it` from the caller's parameters; STEP_NORMAL
-// steps the optimiser for the iteration before the one the device counter names and draws that one.
+// step_kernel: mode STEP_FIRST draws iteration `it` from the caller's parameters; STEP_NORMAL steps the optimiser for iteration
+// it - 1 and draws iteration it (it = -1: the device counter names it -- launches captured into a graph).
+#define STEP_DISPATCH(CALL)                                            \
+    do {                                                               \
+        if (e->small_mesh) { CALL(1, 64, 1); }                         \
+        else if (e->dev.scatter_mode == 3) { CALL(2, 256, 3); }        \
+        else if (e->dev.scatter_mode == 2) { CALL(2, 256, 2); }        \
+        else { CALL(2, 256, 0); }                                      \
+    } while (0)
+
+// workgroups of the engine's step_kernel variant the chip holds at once (registers, LDS and the SGPR rule included: the
+// runtime's own occupancy answer)
+static int step_capacity(ddx_engine* e)
+{
+    int per_cu = 0, cus = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+#define STEP_OCC(TPL, NTH, MODE)                                                                                                   \
+    do {                                                                                                                           \
+        if (e->dev.d.use_edge) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<TPL, NTH, MODE, 3>, NTH, 0); \
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<TPL, NTH, MODE, 2>, NTH, 0);                   \
+    } while (0)
+    STEP_DISPATCH(STEP_OCC);
+#undef STEP_OCC
+    if (per_cu < 1) per_cu = 4;
+    return per_cu * cus;
+}
+
 static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
 {
     EngineDev& E = e->dev;
-    const dim3 g(E.n_meshlets, E.d.B);
+    // slots (workgroups) per hypothesis: every workgroup the same number of meshlets, all of them resident -- a second round of
+    // workgroups would pay the head's chain again -- and at least a few, because the slots also share the re-arm of the tiles the
+    // previous iteration dirtied (a slot beyond the meshlet count does just that)
+    if (e->step_resident <= 0) e->step_resident = step_capacity(e);
+    int SL = std::max(1, std::min(E.n_meshlets, e->step_resident / E.d.B));
+    SL = ddx_cdiv(E.n_meshlets, ddx_cdiv(E.n_meshlets, SL));  // (npw = ceil(M / SL) meshlets each; step_kernel computes the same npw)
+    SL = std::max(SL, std::min(UPD_SLICES, std::max(1, e->step_resident / E.d.B)));
+    const dim3 g = E.step_xcd ? dim3(E.d.B, SL) : dim3(SL, E.d.B);
 #define STEP_LAUNCH(TPL, NTH, MODE)                                                          \
     do {                                                                                     \
         if (E.d.use_edge) step_kernel<TPL, NTH, MODE, 3><<<g, NTH, 0, s>>>(E, mode, it);     \
         else step_kernel<TPL, NTH, MODE, 2><<<g, NTH, 0, s>>>(E, mode, it);                  \
     } while (0)
-    if (e->small_mesh) STEP_LAUNCH(1, 64, 1);
-    else if (E.scatter_mode == 3) STEP_LAUNCH(2, 256, 3);
-    else if (E.scatter_mode == 2) STEP_LAUNCH(2, 256, 2);
-    else STEP_LAUNCH(2, 256, 0);
+    STEP_DISPATCH(STEP_LAUNCH);
 #undef STEP_LAUNCH
     DDX_LAUNCH_CHECK();
     return 0;
 }
 
 // the rest of an iteration after its step_kernel: tile pass for large triangles, shading (+ edge term)
-static int launch_rest(ddx_engine* e, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
+static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
 {
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
     if (ev) DDX_HIP(hipEventRecord(ev[K_BIG], s));
-    big_pass_kernel<<<RASTER_BIG_GRID, 256, 0, s>>>(E);
+    big_pass_kernel<<<BIG_GRID, BIG_WAVES * 64, 0, s>>>(E, it);
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
     {
         dim3 g = shade_grid(d);
         g.z = E.n_roles;
-        if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E);
-        else shade_kernel<false><<<g, 256, 0, s>>>(E);
+        if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E, it);
+        else shade_kernel<false><<<g, 256, 0, s>>>(E, it);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
-    if (d.use_edge) edge_kernel<<<edge_grid(d), 256, 0, s>>>(E);
+    if (d.use_edge) edge_kernel<<<edge_grid(d), 256, 0, s>>>(E, it);
     if (ev) DDX_HIP(hipEventRecord(ev[K_FINISH], s));
     DDX_LAUNCH_CHECK();
     return 0;
 }
 
-static int launch_finish(ddx_engine* e, hipStream_t s)
+static int launch_finish(ddx_engine* e, int it /* the iteration after the last one drawn */, hipStream_t s)
 {
     EngineDev& E = e->dev;
     const dim3 g(upd_slices(E.d), E.d.B);
-    if (E.d.use_edge) finish_kernel<3><<<g, 256, 0, s>>>(E);
-    else finish_kernel<2><<<g, 256, 0, s>>>(E);
+    if (E.d.use_edge) finish_kernel<3><<<g, 256, 0, s>>>(E, it);
+    else finish_kernel<2><<<g, 256, 0, s>>>(E, it);
     DDX_LAUNCH_CHECK();
     return 0;
 }
 
-static int run_iteration(ddx_engine* e, hipStream_t s)  // one iteration after the first of a run
+static int run_iteration(ddx_engine* e, int it, hipStream_t s)  // one iteration after the first of a run (it = -1: for a graph)
 {
-    if (int err = launch_step(e, STEP_NORMAL, 0, s)) return err;
-    return launch_rest(e, s, nullptr);
+    if (int err = launch_step(e, STEP_NORMAL, it, s)) return err;
+    return launch_rest(e, it, s, nullptr);
 }
 
 static int check_desc(const ddx_engine_desc* d)
@@ -1690,11 +1821,20 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         E.s_edge = desc->use_edge ? (int)edge_grid(*desc).y : 0;
         E.pslices = E.s_shade > E.s_edge ? E.s_shade : E.s_edge;
         E.cull_sign = 0;
+        E.trace = nullptr;
+        if (const char* ov = getenv("DDX_TRACE"))
+            if (atoi(ov)) {
+                DDX_HIP(hipMalloc(&E.trace, (size_t)3 * TRACE_WG * 8 * 8));
+                DDX_HIP(hipMemset(E.trace, 0, (size_t)3 * TRACE_WG * 8 * 8));
+            }
+        E.step_xcd = 0;
+        if (const char* ov = getenv("DDX_STEP_XCD")) E.step_xcd = atoi(ov) != 0;
         E.scatter_mode = 0;
         E.n_meshlets = 0;
         for (int c = 0; c < 6; ++c) E.bbox[c] = 0.f;
     }
     e->small_mesh = mesh_is_small(*desc);
+    if (const char* ov = getenv("DDX_STEP_RESIDENT")) e->step_resident = std::max(1, atoi(ov));
     const size_t need = engine_layout(e->dev, *desc, b.scratch);
     if (b.scratch_bytes < need) {
         delete e;
@@ -1892,6 +2032,21 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
                 ++nt;
             }
             E.n_meshlets = M + 1;
+            // interleave the two ends of the Morton curve: 0, M-1, 1, M-2, ...  The bit-complement of a Morton code is the point
+            // reflection through the centre of the bounding box, so consecutive meshlets of the new order are (roughly) antipodes
+            // of the object: a workgroup's consecutive meshlets are one front-facing and one back-facing patch in any pose
+            {
+                const int Mn = E.n_meshlets;
+                std::vector<float4> hv2(hv.size());
+                std::vector<int2> ht2(ht.size());
+                for (int i = 0; i < Mn; ++i) {
+                    const int src = (i & 1) ? Mn - 1 - i / 2 : i / 2;
+                    std::copy(hv.begin() + (size_t)src * NVC, hv.begin() + (size_t)(src + 1) * NVC, hv2.begin() + (size_t)i * NVC);
+                    std::copy(ht.begin() + (size_t)src * NTRI, ht.begin() + (size_t)(src + 1) * NTRI, ht2.begin() + (size_t)i * NTRI);
+                }
+                hv.swap(hv2);
+                ht.swap(ht2);
+            }
             DDX_HIP(hipMemcpyAsync(E.mvert, hv.data(), hv.size() * sizeof(float4), hipMemcpyHostToDevice, s));
             DDX_HIP(hipMemcpyAsync(E.mtri, ht.data(), ht.size() * sizeof(int2), hipMemcpyHostToDevice, s));
             DDX_HIP(hipMemcpyAsync(E.vold, vold.data(), vold.size() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -2052,14 +2207,14 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
     // iteration it0 is drawn from the caller's parameters; each later step_kernel first steps the optimiser for the iteration
     // before it; finish_kernel steps it for the last one
     if (int err = launch_step(e, STEP_FIRST, it0, s)) return err;
-    if (int err = launch_rest(e, s, nullptr)) return err;
+    if (int err = launch_rest(e, it0, s, nullptr)) return err;
     if (use_graph && !e->exec && n > 1) {
         hipStream_t cs;
         DDX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         DDX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int err = 0;
         e->graph_chunk = std::max(1, std::min(use_graph, 64));  // use_graph = iterations per captured graph
-        for (int k = 0; k < e->graph_chunk && !err; ++k) err = run_iteration(e, cs);
+        for (int k = 0; k < e->graph_chunk && !err; ++k) err = run_iteration(e, -1, cs);
         hipError_t ce = hipStreamEndCapture(cs, &e->graph);
         if (err || ce != hipSuccess) {
             (void)hipStreamDestroy(cs);
@@ -2074,11 +2229,11 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
             DDX_HIP(hipGraphLaunch(e->exec, s));
             i += e->graph_chunk;
         } else {
-            if (int err = run_iteration(e, s)) return err;
+            if (int err = run_iteration(e, it0 + i, s)) return err;
             ++i;
         }
     }
-    if (int err = launch_finish(e, s)) return err;
+    if (int err = launch_finish(e, it0 + n, s)) return err;
     e->adam_parity = (it0 + n) & 1;
     return 0;
 }
@@ -2139,10 +2294,10 @@ extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* lo
         if (int err = engine_setup(e, s)) return err;
     if (int err = run_prologue(e, it, s)) return err;
     int err = launch_step(e, STEP_FIRST, it, s);
-    if (!err) err = launch_rest(e, s, nullptr);
+    if (!err) err = launch_rest(e, it, s, nullptr);
     e->dev.eval_grad = grad_out;  // (finish_kernel in evaluation mode: hands out gradient and losses, steps nothing)
     e->dev.eval_loss = loss_out;
-    if (!err) err = launch_finish(e, s);
+    if (!err) err = launch_finish(e, it + 1, s);
     e->dev.eval_grad = nullptr;
     e->dev.eval_loss = nullptr;
     return err;
@@ -2245,8 +2400,8 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     int timed = 0;
     for (int i = 0; i < iters; ++i) {
         DDX_HIP(hipEventRecord(ev[K_STEP], s));
-        if (int err = launch_step(e, i == 0 ? STEP_FIRST : STEP_NORMAL, it0, s)) return err;
-        if (int err = launch_rest(e, s, ev)) return err;
+        if (int err = launch_step(e, i == 0 ? STEP_FIRST : STEP_NORMAL, it0 + i, s)) return err;
+        if (int err = launch_rest(e, it0 + i, s, ev)) return err;
         DDX_HIP(hipEventSynchronize(ev[K_FINISH]));
         if (i == 0 && iters > 1) continue;
         ++timed;
@@ -2257,7 +2412,7 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
         }
     }
     DDX_HIP(hipEventRecord(ev[K_FINISH], s));
-    if (int err = launch_finish(e, s)) return err;
+    if (int err = launch_finish(e, it0 + iters, s)) return err;
     DDX_HIP(hipEventRecord(ev[K_COUNT], s));
     DDX_HIP(hipEventSynchronize(ev[K_COUNT]));
     e->adam_parity = (it0 + iters) & 1;
@@ -2270,9 +2425,21 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     return K_COUNT;
 }
 
+// DDX_TRACE=1 builds of the engine object: copies the stamp buffer to the host ([3][TRACE_WG][8] uint64); returns the number of
+// uint64 written, 0 when tracing is off (measurement tool, tools/trace_kernels.py)
+extern "C" int ddx_engine_trace_read(ddx_engine* e, unsigned long long* out, int max_n)
+{
+    if (!e || !e->dev.trace || !out) return 0;
+    const int n = std::min(max_n, 3 * TRACE_WG * 8);
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(out, e->dev.trace, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
 extern "C" void ddx_engine_destroy(ddx_engine* e)
 {
     if (!e) return;
+    if (e->dev.trace) (void)hipFree(e->dev.trace);
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
     delete e;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
     }
     if (L.counters[3] == 0) return;  // no large triangle in the whole batch
     unsigned long long n_done = 0;
-    big_pass_body(pos, tri, L.snap, L.tile_big, L.biglist, L.bigcount, L.zbuf, L.zper, L.zwb, L.ntx, L.NT, L.NTp, B, V, T, H, W,
+    big_pass_body<4>(pos, tri, L.snap, L.tile_big, L.biglist, L.bigcount, L.zbuf, L.zper, L.zwb, L.ntx, L.NT, L.NTp, B, V, T, H, W,
                   (int)blockIdx.x - B, (int)gridDim.x - B, n_done);
 }
 

@@ -248,8 +248,9 @@ __device__ __forceinline__ int select_bit(scatter_mask_t m, int j)
 // fragment code for its 2 x 64 triangles whenever ONE lane survives; the survivors of both triangles of the lanes are packed into
 // consecutive lanes through LDS and resolved in ceil(n / 64) passes: one instead of two, with full lanes.
 // All variants produce bit-identical frames (ids in zbuf are the original ones; atomicMin does not care about order).
+// Returns whether this thread listed a triangle for the tile pass.
 template <int TPL, int NTHREADS, int MODE>
-__device__ __forceinline__ void scatter_resolve(const ScatterTarget& S, int H, int W, int T, const int (&t)[TPL], const int (&i0)[TPL], const int (&i1)[TPL],
+__device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, int W, int T, const int (&t)[TPL], const int (&i0)[TPL], const int (&i1)[TPL],
                                                 const int (&i2)[TPL], const bool (&ok)[TPL], const int2 (&va)[TPL], const int2 (&vb)[TPL],
                                                 const int2 (&vc)[TPL], int cull)
 {
@@ -263,6 +264,7 @@ __device__ __forceinline__ void scatter_resolve(const ScatterTarget& S, int H, i
     __shared__ scatter_mask_t s_mask[EXCHANGE ? NTHREADS / 64 : 1][EXCHANGE ? 64 : 1];
     __shared__ float4 s_rec[EXCHANGE ? NTHREADS / 64 : 1][EXCHANGE ? 64 : 1][4];  // p0, p1, p2, (px0, py0, nxp, id) as bits
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool listed = false;
     unsigned range[TPL];
     ScatterCov cv[TPL];
 #pragma unroll
@@ -365,9 +367,12 @@ __device__ __forceinline__ void scatter_resolve(const ScatterTarget& S, int H, i
         int base = 0;
         if (lane == __ffsll((long long)m) - 1) base = atomicAdd(S.bigcount, __popcll(m));
         base = __shfl(base, __ffsll((long long)m) - 1, 64);
-        if (range[k] != ~0u)  // (bit 31 of the id: a near-plane straddler, clipped again by the tile pass)
+        if (range[k] != ~0u) {  // (bit 31 of the id: a near-plane straddler, clipped again by the tile pass)
             S.biglist[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2((unsigned)t[k] | (cv[k].clipped ? 0x80000000u : 0u), range[k]);
+            listed = true;
+        }
     }
+    return listed;
 }
 
 // clip_near as a real call: inlined into the candidate loop of the tile pass its code (used by the rare near-plane straddlers
@@ -393,15 +398,17 @@ __device__ __attribute__((noinline)) static int clip_near_call(const float4& p0,
 // tile_big [B, NTp] bytes; snap [B,V]; pos [B,V,4]; biglist [B,T]; bigcount [B]; zbuf [B, zper].
 #define BIG_SCAN 1024  // (hypothesis, tile) flags scanned per step of the large-triangle pass
 
+template <int NWB /* waves per workgroup: 4 (op-level, 1024 workgroups) or 16 (engine: 256 workgroups of 1024 threads -- the same number
+                     of tiles in flight, and a launch that exits at once when the batch has no large triangle costs 256 dispatches) */>
 __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, const int* __restrict__ tri, const int2* __restrict__ snap,
                                               const unsigned char* __restrict__ tile_big, const uint2* __restrict__ biglist,
                                               const int* __restrict__ bigcount, unsigned long long* __restrict__ zbuf, size_t zper, int zwb, int ntx,
                                               int NT, int NTp, int B, int V, int T, int H, int W, int g, int G, unsigned long long& n_done)
 {
-    __shared__ int4 s_e0[4][64], s_e1[4][64], s_e2[4][64];  // staged LARGE triangles of each wave's tile: per edge (e.lo, e.hi, step x, step y) at the tile origin
-    __shared__ int s_t[4][64];                              // ... their ids
-    __shared__ int s_cand[4][256];                          // range-test survivors of 256 list entries (per wave)
-    __shared__ float4 s_p0[4][64], s_p1[4][64], s_p2[4][64];  // ... and their clip-space vertices
+    __shared__ int4 s_e0[NWB][64], s_e1[NWB][64], s_e2[NWB][64];  // staged LARGE triangles of each wave's tile: per edge (e.lo, e.hi, step x, step y) at the tile origin
+    __shared__ int s_t[NWB][64];                              // ... their ids
+    __shared__ int s_cand[NWB][256];                          // range-test survivors of 256 list entries (per wave)
+    __shared__ float4 s_p0[NWB][64], s_p1[NWB][64], s_p2[NWB][64];  // ... and their clip-space vertices
     __shared__ int s_big[BIG_SCAN];
     __shared__ int s_nbig;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -411,7 +418,7 @@ __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, con
     __syncthreads();
     if (tid == 0) s_nbig = 0;
     __syncthreads();
-    for (int j = base + tid; j < min(n_cand, base + BIG_SCAN); j += 256) {
+    for (int j = base + tid; j < min(n_cand, base + BIG_SCAN); j += NWB * 64) {
         const int bb = j / per_b, kk = j - bb * per_b;
         int t0 = (g - 13 * bb) % G;
         if (t0 < 0) t0 += G;
@@ -422,7 +429,7 @@ __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, con
     }
     __syncthreads();
     const int nbig = s_nbig;
-    for (int e = wave; e < nbig; e += 4) {  // (wave-uniform)
+    for (int e = wave; e < nbig; e += NWB) {  // (wave-uniform)
         const int flat = s_big[e];
         const int b = flat / NT, tile = flat - b * NT;
         const int tcx = tile % ntx, tcy = tile / ntx;

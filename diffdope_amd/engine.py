@@ -170,7 +170,7 @@ class RefineEngine:
     def slices(self):
         """(shade_slices, edge_slices) this engine runs with: what a shard of this batch passes to reproduce it bitwise."""
         auto = lambda grid: max(1, min(64, grid // self.B))
-        return (self.desc.shade_slices or auto(1024), self.desc.edge_slices or auto(1792))
+        return (self.desc.shade_slices or auto(512), self.desc.edge_slices or auto(1792))
 
     @property
     def cull_sign(self):

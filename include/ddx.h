@@ -181,7 +181,7 @@ typedef struct ddx_engine_desc {
     int32_t max_iters; /* rows available in lr_sched / loss_log / mtx_log */
     int32_t use_edge;  /* EXTENSION (no reference counterpart): Sobel-gradient L1 term, needs gt_rgb and a colour source */
     float w_edge;
-    /* Slices (workgroups) per hypothesis of the shading / edge launches; 0 = chosen from B (1024 / B and 1792 / B, at most
+    /* Slices (workgroups) per hypothesis of the shading / edge launches; 0 = chosen from B (512 / B and 1792 / B, at most
      * 64).  Each slice contributes one partial row per wave to the fixed-order sum of a hypothesis' gradient, so the last
      * bits of that sum depend on the slice count.  A job sharded over GPUs (B < B_global) that must reproduce the unsharded
      * run BIT FOR BIT passes the unsharded run's counts here (tests/test_gpu_engine.py::test_engine_shard_invariance);
