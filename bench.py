@@ -156,6 +156,17 @@ def _free_port():
     return p
 
 
+def csrc_sha16():
+    """Hash of the kernel sources: counters from a PMC pass of other sources are stale (profiles/summarize_sq.py records it)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "diffdope_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "diffdope_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _latest_profile(suffix):
     d = os.path.join(ROOT, "profiles")
     try:
@@ -175,7 +186,10 @@ def main():
                     help="adam = north_star's outer loop (default); sgd = the reference's optimiser (diffdope.py:1642-1644); the default run reports both")
     ap.add_argument("--distance", type=float, default=None, help="camera distance in scene units (default: the config's, 7.5 = the example's 747 mm); "
                     "smaller = larger object in the frame -- for coverage-sensitivity sweeps, not the headline line")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: a fixed job of this many hypotheses sharded over the ranks (BASELINE "
+                    "configs[3]: --config cfg4 --global-batch 512 --gpus 8); default 0 = weak scaling, the config's batch on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-convergence", action="store_true", help="skip the untimed 200-iteration convergence leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (reference SGD, close-up at distance 3.75, repeats)")
     ap.add_argument("--repeats", type=int, default=5, help="extra timed windows of --steps iterations after the contract's one (median reported beside it)")
     ap.add_argument("--graph", type=int, nargs="?", const=1, default=0, help="replay captured hipGraphs of K iterations (default 1; measured 9 %% slower than plain stream launches at K=1, equal at K=20)")
@@ -217,25 +231,43 @@ def main():
     from diffdope_amd import dist as ddist
     from diffdope_amd import workloads as wl
 
-    Bl = wl.CONFIGS[args.config]["B"]  # hypotheses per GPU (weak scaling)
+    strong = args.global_batch > 0
+    if strong:  # a fixed job sharded over the ranks (rank r owns a contiguous slice)
+        B_job = args.global_batch
+        lo, hi = ddist.shard_range(B_job, rank, world)
+        Bl = hi - lo
+        if Bl < 1:
+            raise SystemExit(f"--global-batch {B_job} leaves rank {rank} of {world} without a hypothesis")
+    else:       # weak scaling: the config's batch on every rank
+        Bl = wl.CONFIGS[args.config]["B"]
+        B_job, lo = Bl * world, rank * Bl
     n_it = args.warmup + args.steps
+    dist_info = {"backend": torch.distributed.get_backend() if use_dist else None, "world_size": world, "device_ids": [dev_index]}
+    if use_dist:
+        ids = torch.zeros(world, dtype=torch.int32, device=dev)
+        ids[rank] = dev_index + 1
+        torch.distributed.all_reduce(ids)  # (also the first collective: RCCL channel set-up happens here, outside every timed window)
+        dist_info["device_ids"] = [int(x) - 1 for x in ids.cpu().tolist()]
+        dist_info["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
 
     def barrier():
         if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(w, optimizer, repeats=0):
+    def timed(w, optimizer, repeats=0, lo_w=None, global_w=None):
         """The contract's measurement on workload w: W warm-up iterations, then EXACTLY K iterations + the arg-min selection
-        (incl. the one all_reduce) between barrier + synchronize, max over ranks.  Optionally `repeats` more K-iteration
-        windows of the same engine (rewound to the same rows of the schedule) for a median."""
+        (incl. the one all_reduce) between barrier + synchronize, max over ranks.  Optionally `repeats` more windows of the
+        same engine, each restarted from the initial poses with a fresh optimiser state and the same W warm-up iterations
+        (the same rows of the schedule, the same work), for a median."""
         lrs = wl.bench_lr_schedule(n_it, optimizer)
-        eng, params = wl.engine_for(w, lrs, optimizer=optimizer, global_batch=Bl * world)
+        lo_w = lo if lo_w is None else lo_w
+        eng, params = wl.engine_for(w, lrs, optimizer=optimizer, global_batch=global_w or w["global_B"])
         used = [i for i, k in enumerate(("rgb", "depth", "mask", "edge")) if w["weights"].get(k) is not None]
         row_mask = sum(1 << i for i in used)
         # the one collective of the job: global arg-min hypothesis + its pose (diffdope.py:1488-1513,1618-1632);
         # local selection by one device kernel, one all_reduce of the [world,18] table, one host synchronisation
-        select_best = lambda it: ddist.global_argmin_fused(eng.loss_log[it], row_mask, eng.mtx_log[it], lo=rank * Bl)
+        select_best = lambda it: ddist.global_argmin_fused(eng.loss_log[it], row_mask, eng.mtx_log[it], lo=lo_w)
 
         def window():
             barrier()
@@ -259,11 +291,12 @@ def main():
         per_hyp = eng.loss_log[n_it - 1][used].mean(0).clone()
         extra = []
         for _ in range(repeats):
-            eng.rewind(args.warmup)
+            eng.new_observation(params=w["params0"])  # initial poses, zero moments, iteration 0
+            eng.run(args.warmup, use_graph=args.graph)
             extra.append(window()[0])
         return dict(elapsed=elapsed, best=best, status=st, params=final, per_hyp=per_hyp, lrs=lrs, repeats=extra, eng=eng)
 
-    w = wl.build(args.config, dev, B=Bl, global_lo=rank * Bl, global_B=Bl * world, distance=args.distance)
+    w = wl.build(args.config, dev, B=Bl, global_lo=lo, global_B=B_job, distance=args.distance)
     extras_on = not args.no_extras and world == 1
     r = timed(w, args.optimizer, repeats=args.repeats if extras_on else 0)
     elapsed = r["elapsed"]
@@ -276,7 +309,7 @@ def main():
         V, T, HW = w["V"], w["T"], w["H"] * w["W"]
         alg = algorithmic_bytes(V, T, HW, Bl)
         # per-kernel launch durations, live, HIP events on the launch stream (a second engine: profiling mutates poses)
-        eng2, _ = wl.engine_for(w, r["lrs"], optimizer=args.optimizer, global_batch=Bl * world)
+        eng2, _ = wl.engine_for(w, r["lrs"], optimizer=args.optimizer, global_batch=B_job)
         eng2.run(min(args.warmup, n_it - 1))
         torch.cuda.synchronize()
         kms_ev = eng2.profile(it0=min(args.warmup, n_it - 1), iters=max(1, min(20, n_it - args.warmup)))
@@ -298,8 +331,12 @@ def main():
         kp = None
         if pmc:
             kp = next((v for k, v in pmc["kernels"].items() if dom in k and v.get("launches", 0) > 4), None)
+        # counters measured on other kernel sources than the ones running now are not this build's: reported as stale, never as frac
+        stale = bool(pmc) and pmc.get("csrc_sha16") != csrc_sha16()
         valu_insts = kp.get("SQ_INSTS_VALU") if kp else None
-        traffic = kp.get("hbm_bytes_per_launch") if kp else None
+        traffic = kp.get("hbm_bytes_per_launch") if kp else None                      # FETCH_SIZE + WRITE_SIZE as reported
+        traffic_x2 = kp.get("hbm_bytes_per_launch_fetch_doubled") if kp else None     # with the guide's x2 on FETCH_SIZE
+        fetch_cal = (pmc or {}).get("fetch_size_calibration")                         # tools/ubench/gather64.hip under --pmc FETCH_SIZE
         uses = {k: w["weights"].get(k) is not None for k in ("rgb", "depth", "mask", "edge")}
         n_roles = int(uses["rgb"] or uses["depth"] or uses["edge"]) + int(uses["mask"])
         comp = compulsory_bytes(V, T, HW, Bl, r["status"]["active_tiles"], w["coverage"] * HW * Bl, w["tex"] is not None,
@@ -308,17 +345,21 @@ def main():
         # The dominant kernels are bound by dependent-latency chains and VALU issue, not by DRAM (traffic_frac below), so the
         # roofline of record is VALU issue: wave-level VALU instructions per launch (PMC) / live launch duration against
         # 1228.8 G wave-instructions/s.  `hbm` holds the byte view (work-proportional compulsory bytes, PMC traffic).
-        valu_ach = (valu_insts / dom_s / 1e9) if valu_insts else None
+        valu_ach = (valu_insts / dom_s / 1e9) if (valu_insts and not stale) else None
         roof = {
             "kernel": dom, "bound": "valu", "achieved": valu_ach, "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
             "frac": (valu_ach / VALU_PEAK_GINST) if valu_ach else None,
             "valu_wave_insts_per_launch": valu_insts, "avg_launch_ms": kms[dom], "counters_source": pmc_src,
-            "traffic": traffic,
+            "counters_stale": stale, "csrc_sha16": csrc_sha16(),
+            "traffic": traffic, "traffic_fetch_doubled": traffic_x2, "fetch_size_calibration": fetch_cal,
             "hbm": {"compulsory_bytes_per_launch": comp[dom], "achieved_GBps": comp[dom] / dom_s / 1e9,
                     "frac": comp[dom] / dom_s / 1e9 / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS,
                     "traffic_bytes_per_launch": traffic,
                     "traffic_frac_of_peak": (traffic / dom_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     "traffic_over_compulsory": (traffic / comp[dom]) if traffic else None,
+                    "traffic_fetch_doubled_bytes_per_launch": traffic_x2,
+                    "traffic_fetch_doubled_frac_of_peak": (traffic_x2 / dom_s / 1e9 / HBM_PEAK_GBS) if traffic_x2 else None,
+                    "traffic_fetch_doubled_over_compulsory": (traffic_x2 / comp[dom]) if traffic_x2 else None,
                     "iteration_compulsory_bytes": comp["iteration"],
                     "iteration_frac": comp["iteration"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "model_8d": {"algorithmic_bytes_per_launch": model_bytes, "achieved_GBps": model_bytes / dom_s / 1e9,
@@ -329,25 +370,49 @@ def main():
             "note": "frac = VALU issue utilisation of the dominant kernel (PMC SQ_INSTS_VALU per launch / live HIP-event launch duration "
                     "/ (1024 SIMD-32 x 2.4 GHz / 2 cycles)); hbm.frac = work-proportional compulsory bytes / duration / 8 TB/s; see DESIGN.md section 6",
         }
+        tex_hw = (int(w["tex"].shape[0]), int(w["tex"].shape[1])) if w["tex"] is not None else (0, 0)
+        job_iters = args.steps / elapsed  # iterations of the whole job per second
         out = {
-            "metric": "render+backward iters/sec at 640x480, 64 hypotheses per iteration",
-            "value": world * args.steps / elapsed,
+            "metric": f"render+backward iters/sec at {w['W']}x{w['H']}, {Bl if not strong else B_job} hypotheses per iteration",
+            # weak scaling: every rank runs its own 64-hypothesis iterations (value = N x the per-rank rate); strong scaling
+            # (--global-batch): one iteration covers the whole fixed job
+            "value": job_iters if strong else world * job_iters,
             "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: seeded blob mesh T={T} V={V}, 2048^2 texture, {w['W']}x{w['H']}, "
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: seeded blob mesh T={T} V={V}, {tex_hw[0]}^2 texture, {w['W']}x{w['H']}, "
                                    f"{Bl} hypotheses/GPU, losses {sorted(w['weights'])}, optimizer {args.optimizer}, "
                                    f"object covers {100 * w['coverage']:.2f}% of the frame",
-                       "hypotheses_per_gpu": Bl, "global_hypotheses": Bl * world, "parallelism": f"hyp-shard x{world}",
+                       "hypotheses_per_gpu": Bl, "global_hypotheses": B_job, "parallelism": f"hyp-shard x{world}",
                        "hipgraph": bool(args.graph)},
-            "hypothesis_iters_per_s": world * Bl * args.steps / elapsed,
+            "dist": dist_info,
+            "hypothesis_iters_per_s": B_job * job_iters,
             "roofline": roof,
             "kernel_ms": kms, "kernel_ms_events": kms_ev, "stage_ms": groups,
-            "final_pose": {"argmin_global_index": gidx, "argmin_loss": gloss,
+            # engine memory that scales with the texture: one 64-byte footprint record per texel (4x the [Th,Tw,3] fp32 texture)
+            "texq_bytes": tex_hw[0] * tex_hw[1] * 64, "engine_scratch_bytes": int(r["eng"].scratch.numel()),
+            "final_pose": {"what": f"SNAPSHOT after the {n_it} iterations of this run (warm-up + timed), not a converged result when that is few: see `convergence`",
+                           "argmin_global_index": gidx, "argmin_loss": gloss,
                            "rot_err_rad_best": float(rot[lbest]), "trans_err_m_best": float(tr[lbest]), "add_m_best": float(add[lbest]),
                            "rot_err_rad_median": float(np.median(rot)), "trans_err_m_median": float(np.median(tr))},
             "engine_status": r["status"],
         }
+        if not args.no_convergence:
+            # the second half of the metric ("final ADD err"): the full schedule on the SAME workload, outside every timed window
+            n_cv = 200
+            lr_cv = wl.bench_lr_schedule(n_cv, args.optimizer)
+            eng_cv, p_cv = wl.engine_for(w, lr_cv, optimizer=args.optimizer, global_batch=B_job)
+            eng_cv.run(n_cv)
+            eng_cv.finish()
+            used_cv = [i for i, k in enumerate(("rgb", "depth", "mask", "edge")) if w["weights"].get(k) is not None]
+            bcv = int(torch.argmin(eng_cv.loss_log[n_cv - 1][used_cv].mean(0)))
+            rot_c, tr_c = wl.pose_errors(p_cv, w["q_gt"], w["t_gt"])
+            add_c = wl.add_error(p_cv, w["pos"], w["q_gt"], w["t_gt"])
+            out["convergence"] = {"iterations": n_cv, "optimizer": args.optimizer, "argmin_local_index": bcv,
+                                  "rot_err_rad_best": float(rot_c[bcv]), "trans_err_m_best": float(tr_c[bcv]), "add_m_best": float(add_c[bcv]),
+                                  "rot_err_rad_median": float(np.median(rot_c)), "trans_err_m_median": float(np.median(tr_c)),
+                                  "within_north_star_tolerance": bool(rot_c[bcv] < 1e-3 and tr_c[bcv] < 1e-3),
+                                  "what": "same workload and engine, full 200-iteration schedule, untimed; errors against the generating pose"}
         if r["repeats"]:
             allw = sorted([elapsed] + r["repeats"])
             med = allw[len(allw) // 2]
@@ -365,6 +430,13 @@ def main():
                 r3 = timed(wc, args.optimizer)
                 out["also"]["cfg2_d3.75"] = {"iters_per_s": args.steps / r3["elapsed"], "ms_per_step": r3["elapsed"] / args.steps * 1e3,
                                              "coverage_pct": 100 * wc["coverage"], "what": "same mesh and losses at half the distance (object 4x the area)"}
+                for name, what in (("cfg50k64", "north_star target sentence: 64 hypotheses of a 51 200-triangle textured mesh at 640x480, rgb+mask"),
+                                   ("cfg3", "BASELINE configs[2]: 128 hypotheses, 51 200 triangles, rgb+depth+edge (edge = this build's extension)")):
+                    wx = wl.build(name, dev)
+                    rx = timed(wx, args.optimizer, lo_w=0)
+                    out["also"][name] = {"iters_per_s": args.steps / rx["elapsed"], "ms_per_step": rx["elapsed"] / args.steps * 1e3,
+                                         "hypotheses": wx["B"], "hypothesis_iters_per_s": wx["B"] * args.steps / rx["elapsed"], "what": what}
+                    del wx, rx
         if not args.no_cpu_baseline and world == 1:  # (the CPU leg is timed on rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

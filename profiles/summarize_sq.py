@@ -24,7 +24,7 @@ import sys
 
 tag, key = sys.argv[1], sys.argv[2]
 root = f"gpurun_out/pmc_{tag}_{key}"
-KEEP = ("scatter_kernel", "compact_big_kernel", "shade_kernel", "edge_kernel", "update_xfm_kernel", "pose_xfm_kernel")
+KEEP = ("step_kernel", "big_pass_kernel", "shade_kernel", "edge_kernel", "finish_kernel")
 short = lambda name: name.split("(")[0].replace("void ", "").strip()
 out = collections.defaultdict(dict)
 for path in glob.glob(f"{root}/*/**/pmc_counter_collection.csv", recursive=True) + glob.glob(f"{root}/*/pmc_counter_collection.csv"):
@@ -66,6 +66,19 @@ try:
             bench = json.loads(line)
 except Exception:
     pass
-print(json.dumps({"tag": tag, "workload_key": key, "workload": bench["config"]["workload"] if bench else None,
+sha = None
+try:
+    sys.path.insert(0, ".")
+    import bench as _bench_py
+
+    sha = _bench_py.csrc_sha16()  # (bench.py refuses counters of other kernel sources: roofline.counters_stale)
+except Exception:
+    pass
+cal = None
+try:
+    cal = json.load(open(f"{root}/fetch_calibration.json"))
+except Exception:
+    pass
+print(json.dumps({"tag": tag, "workload_key": key, "csrc_sha16": sha, "fetch_size_calibration": cal, "workload": bench["config"]["workload"] if bench else None,
                   "bench_under_kernel_trace": {k: bench[k] for k in ("value", "ms_per_step", "kernel_ms", "engine_status")} if bench else None,
                   "kernels": out}, indent=1))

@@ -98,3 +98,28 @@ def test_multi_object_frame_with_two_ranks_sharing_the_gpu():
     assert len(a) == 3 and a == b  # same arg-min hypothesis, loss and pose errors, digit for digit
     owners = [l.split("(owner rank ")[1].rstrip(")") for l in two.stdout.splitlines() if l.startswith("object ")]
     assert owners == ["0", "1", "0"]
+
+
+def test_bench_two_ranks_over_rccl_matches_the_single_process_job():
+    """First contact with RCCL at world size 2 (needs two GPUs: skipped on the 1-GPU test box, runs on the 8-GPU node): bench.py --gpus 2
+    as the driver launches it -- one rank per device, backend nccl (= RCCL), no DDX_BENCH_SHARE_GPU -- on a FIXED job of 128 hypotheses
+    (--global-batch 128: 64 per rank) against the same job in one process on one GPU: same arg-min hypothesis, same loss to fp32
+    rounding of the differently grouped gradient sums, and the JSON line says which backend / devices ran."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DDX_BENCH_SHARE_GPU", None)
+    common = ["--steps", "8", "--warmup", "3", "--global-batch", "128", "--no-cpu-baseline", "--no-extras", "--no-convergence"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["dist"]["backend"] == "nccl" and b["dist"]["world_size"] == 2
+    assert sorted(b["dist"]["device_ids"]) == [0, 1]
+    assert a["config"]["global_hypotheses"] == b["config"]["global_hypotheses"] == 128 and b["config"]["hypotheses_per_gpu"] == 64
+    assert a["final_pose"]["argmin_global_index"] == b["final_pose"]["argmin_global_index"]
+    assert abs(a["final_pose"]["argmin_loss"] - b["final_pose"]["argmin_loss"]) <= 1e-3 * abs(a["final_pose"]["argmin_loss"])

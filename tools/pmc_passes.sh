@@ -25,3 +25,33 @@ for name in sq_insts sq_cycles sq_valu sq_lds tcc fetch write; do
         || echo "pass $name failed (rc $?)" >> "$out/failed.log"
 done
 ls -R "$out" | head -60
+# ---- FETCH_SIZE calibration on a known count of 64-byte record gathers (and a wide coalesced stream of the same size)
+if [ ! -f "$out/fetch_calibration.json" ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/gather64 tools/ubench/gather64.hip 2>/dev/null
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/fetchcal" -o g --output-format csv -- /tmp/gather64 > "$out/fetchcal.log" 2>&1
+  python - "$out" <<'PY'
+import csv, glob, json, statistics, sys
+out = sys.argv[1]
+info = None
+for line in open(f"{out}/fetchcal.log"):
+    if line.startswith("{"):
+        info = json.loads(line)
+vals = {"gather64_kernel": [], "stream_kernel": []}
+for path in glob.glob(f"{out}/fetchcal/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        for k in vals:
+            if k in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+                vals[k].append(float(r["Counter_Value"]))
+if info and vals["gather64_kernel"]:
+    g = statistics.median(vals["gather64_kernel"]) * 1024.0
+    s = statistics.median(vals["stream_kernel"]) * 1024.0 if vals["stream_kernel"] else None
+    cal = {"what": "tools/ubench/gather64.hip under rocprofv3 --pmc FETCH_SIZE: 262 144 random 64-byte records (3 x 16-byte loads each) from a 512 MiB "
+                   "table per launch, and the same bytes as a wide coalesced stream",
+           "gather_true_bytes_64B_sectors": info["bytes_per_gather_launch_64B_records"], "gather_FETCH_SIZE_bytes": g,
+           "gather_true_over_reported": info["bytes_per_gather_launch_64B_records"] / g,
+           "stream_true_bytes": info["bytes_per_stream_launch"], "stream_FETCH_SIZE_bytes": s,
+           "stream_true_over_reported": (info["bytes_per_stream_launch"] / s) if s else None}
+    json.dump(cal, open(f"{out}/fetch_calibration.json", "w"))
+    print(json.dumps(cal))
+PY
+fi
