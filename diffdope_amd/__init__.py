@@ -14,7 +14,7 @@ from .render import (  # noqa: F401
     render_texture_batch,
     texture,
 )
-from .engine import RefineEngine  # noqa: F401
+from .engine import RefineEngine, RefineEngineGroup  # noqa: F401
 from .pose import matrix_batch_44_from_position_quat  # noqa: F401
 from .api import (  # noqa: F401
     Camera,

@@ -77,6 +77,11 @@ _SIGNATURES = {
     "ddx_engine_new_observation": (_I, [_P]),
     "ddx_engine_profile": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I, _P]),
     "ddx_engine_destroy": (None, [_P]),
+    "ddx_engine_group_create": (_I, [ctypes.POINTER(_P), _I, ctypes.POINTER(_P)]),
+    "ddx_engine_group_run": (_I, [_P, _I, _I, _P]),
+    "ddx_engine_group_invalidate": (_I, [_P]),
+    "ddx_engine_group_destroy": (None, [_P]),
+    "ddx_engine_trace_read": (_I, [_P, _P, _I]),
 }
 
 

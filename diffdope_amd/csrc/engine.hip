@@ -50,6 +50,7 @@
 #define NPART 24  // floats per tile partial: 12 dFinal(x,y,w rows) | 4 dMtx row 2 | 4 losses (rgb, depth, mask, edge) | pad
 #define NVALS 20  // of which are used
 #define MAX_ROLES 3
+#define NROLE 3  // partial rows per slice: colour + depth, mask, edge -- always three, so that an engine sums in the same order whatever kernels of a group it runs under
 
 #ifndef SCATTER_EXCHANGE_PER_TRI
 #define SCATTER_EXCHANGE_PER_TRI 1.1  // measured crossover: equal at 0.8-1.0 (cfg2 at 2.6-3.4 % coverage), exchange ahead from 1.3
@@ -83,12 +84,13 @@ struct EngineDev {
                       // (read by the mask role and the tile pass; the colour role recomputes its vertices from crec)
     float* mats;      // [2][B,2,16]: mtx | final, by iteration parity
     float* params2;   // [2][7,B]: the parameters, by iteration parity (b.params is the user-visible copy)
-    float* partials;  // [B, pslices, NR, NPART]: one row per slice (workgroup of the shade / edge grid) and role, NR = 2 (3 with the edge role)
+    float* partials;  // [B, pslices, NROLE, NPART]: one row per slice (workgroup of the shade / edge grid) and role
     float2* gtedge;   // [H*W] Sobel gradients of lum(gt_rgb * seg) (edge extension), or null
     float* lumbuf;    // [B,H*W] luminance of the rendered colour at covered pixels (written by the colour role, read by
     float* ubuf;      // [B,H*W,12] edge_kernel; garbage where zbuf says "background") and U = d lum / d final per pixel
     float* adam;      // [2][2,7,B]: first and second moments, by iteration parity
     float2* seglist;  // [H*W] (gt_depth, seg0) of pixels with seg0 != 0 (setup only)
+    struct SetupPart* setup_part;  // [ceil(H W / SETUP_CHUNK)] per-chunk partials of the observation set-up
     // the same pixels sorted by observed depth, with prefix sums (double) of |seg0| and |seg0| * depth: the whole-frame
     // background depth term sum_i |seg0_i| |d - gt_i| and its derivative for a hypothesis' background depth d are two
     // searches and six loads instead of a pass over the list (10 700 entries per workgroup on cfg5: 10 of the update's 21 us)
@@ -166,6 +168,26 @@ struct ddx_engine {
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
 
+// ENGINE GROUPS (ddx_engine_group_*): several engines -- the objects of one frame, BASELINE config 5 -- advance one iteration with
+// ONE launch of each kernel.  Every member keeps its own scratch, state and launch geometry (slices, partial rows: the same bits as
+// when it runs alone); the group kernels only decode (member, block) from the block index and run the member's body on its
+// EngineDev, read from a device table.  A latency-bound 64-hypothesis launch fills a fraction of the chip; four of them in one
+// grid run in the large-batch regime (tools/large_batch.py).
+#define GROUP_MAX 32
+struct GroupHdr {
+    int n;                     // members of this launch
+    int idx[GROUP_MAX];        // their rows of the device table
+    int bpre[GROUP_MAX + 1];   // prefix sums of their hypothesis counts
+    int sl[GROUP_MAX];         // step_kernel slots per hypothesis of each
+};
+
+__device__ __forceinline__ int group_find(const GroupHdr& G, int g)  // the member that owns hypothesis g of the launch
+{
+    int o = 0;
+    for (int i = 1; i < G.n; ++i) o += g >= G.bpre[i] ? 1 : 0;
+    return o;
+}
+
 // meshlet geometry of the two step_kernel variants (triangles, vertex slots): dense = (2, 256), small = (1, 64) threads
 static inline void mesh_geometry(bool small_mesh, int& ntri, int& nvc)
 {
@@ -198,6 +220,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_inside = carve((size_t)d.B * sizeof(int));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
+    const size_t o_spart = carve(((size_t)d.H * d.W / 4096 + 1) * 40);  // SetupPart per chunk of SETUP_CHUNK = 4096 pixels
     const size_t o_sgd = carve(d.use_depth ? (size_t)d.H * d.W * sizeof(float) : 0);
     const size_t o_sW = carve(d.use_depth ? ((size_t)d.H * d.W + 1) * sizeof(double) : sizeof(double));
     const size_t o_sG = carve(d.use_depth ? ((size_t)d.H * d.W + 1) * sizeof(double) : sizeof(double));
@@ -232,6 +255,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.inside = (int*)(p + o_inside);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
+    E.setup_part = (struct SetupPart*)(p + o_spart);
     E.seg_gd = (float*)(p + o_sgd);
     E.seg_W = (double*)(p + o_sW);
     E.seg_G = (double*)(p + o_sG);
@@ -256,61 +280,13 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
 }
 
 // ---------------------------------------------------------------------------------------------
-// one-time setup: frame constants + compact seg list.  One 1024-thread workgroup, ordered compaction
-// (ballot ranks + wave offsets) and fixed-shape reductions: the result does not depend on scheduling.
-__global__ __launch_bounds__(1024) void setup_kernel(EngineDev E)
-{
-    const int n = E.d.H * E.d.W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ int wcnt[16];
-    __shared__ int carry;
-    __shared__ double red[2][16];
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    double s_rgb = 0.0, s_mask = 0.0;
-    for (int start = 0; start < n; start += 1024) {
-        const int i = start + tid;
-        bool flag = false;
-        float gd = 0.f, s0 = 0.f;
-        if (i < n) {
-            s0 = E.b.gt_seg[i * 3 + 0];
-            const float s1 = E.b.gt_seg[i * 3 + 1], s2 = E.b.gt_seg[i * 3 + 2];
-            s_mask += (double)(fabsf(s0) + fabsf(s1) + fabsf(s2));
-            if (E.b.gt_rgb)
-                s_rgb += (double)(fabsf(E.b.gt_rgb[i * 3 + 0] * s0) + fabsf(E.b.gt_rgb[i * 3 + 1] * s1) + fabsf(E.b.gt_rgb[i * 3 + 2] * s2));
-            if (E.b.gt_depth && s0 != 0.f) { flag = true; gd = E.b.gt_depth[i]; }
-        }
-        const unsigned long long m = __ballot(flag);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = carry;
-        for (int w = 0; w < wave; ++w) off += wcnt[w];
-        if (flag) E.seglist[off + rank] = make_float2(gd, s0);
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wcnt[w];
-            carry += tot;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s_rgb += __shfl_xor(s_rgb, o, 64); s_mask += __shfl_xor(s_mask, o, 64); }
-    if (lane == 0) { red[0][wave] = s_rgb; red[1][wave] = s_mask; }
-    __syncthreads();
-    if (tid == 0) {
-        double a = 0.0, bq = 0.0;
-        for (int w = 0; w < 16; ++w) { a += red[0][w]; bq += red[1][w]; }
-        E.st->c_rgb = a;
-        E.st->c_mask = bq;
-        E.st->n_seg = carry;
-    }
-}
-
-// Edge extension (no reference counterpart; definition: oracle/ddx_oracle.c orc_loss_edge): Sobel gradients of the
-// luminance of the observed image masked by its segmentation, and their whole-frame L1 norm.  One workgroup,
-// fixed-shape reduction.
+// Observation set-up (once per frame): frame constants -- sum |gt_rgb seg|, sum |seg|, and for the edge extension (no reference
+// counterpart; definition: oracle/ddx_oracle.c orc_loss_edge) the Sobel gradients of the luminance of the observed image masked by
+// its segmentation and their whole-frame L1 norm -- and the compact list of pixels with seg0 != 0 for the depth term.
+// Three launches over chunks of SETUP_CHUNK pixels: per-chunk partials, one ordered scan over the chunks, ordered compaction.
+// (One 1024-thread workgroup did all of it at first: 1.3 ms + 3.2 ms for the edge map at 1280x720 -- a quarter of a 58-iteration
+// frame per object.)  Fixed shapes and orders throughout: the result does not depend on scheduling.
+#define SETUP_CHUNK 4096
 __device__ __forceinline__ float lum3(float r, float g, float b) { return ((r + g) + b) * (1.0f / 3.0f); }
 
 __device__ __forceinline__ void sobel3(const float v[3][3], float& gx, float& gy)
@@ -319,40 +295,119 @@ __device__ __forceinline__ void sobel3(const float v[3][3], float& gx, float& gy
     gy = (((v[2][0] - v[0][0]) + 2.0f * (v[2][1] - v[0][1])) + (v[2][2] - v[0][2])) * 0.125f;
 }
 
-__global__ __launch_bounds__(1024) void edge_setup_kernel(EngineDev E)
+struct SetupPart { double s_rgb, s_mask, s_edge; int count, offset; };  // per chunk (EngineDev::setup_part)
+static_assert(sizeof(SetupPart) <= 40, "engine_layout carves 40 bytes per chunk");
+
+// block sum of a double per thread, fixed order: wave shuffles, then the four waves
+__device__ __forceinline__ double block_sum_256(double v, double* red /* LDS [4] */)
 {
-    const int H = E.d.H, W = E.d.W, n = H * W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ double red[16];
-    double s = 0.0;
-    for (int i = tid; i < n; i += 1024) {
-        const int y = i / W, x = i - y * W;
-        float v[3][3];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void setup_part_kernel(EngineDev E)
+{
+    const int H = E.d.H, W = E.d.W, n = H * W, tid = threadIdx.x;
+    __shared__ double red[4];
+    double s_rgb = 0.0, s_mask = 0.0, s_edge = 0.0;
+    int cnt = 0;
+    for (int k = 0; k < SETUP_CHUNK / 256; ++k) {
+        const int i = blockIdx.x * SETUP_CHUNK + k * 256 + tid;
+        if (i >= n) break;
+        const float s0 = E.b.gt_seg[i * 3 + 0], s1 = E.b.gt_seg[i * 3 + 1], s2 = E.b.gt_seg[i * 3 + 2];
+        s_mask += (double)(fabsf(s0) + fabsf(s1) + fabsf(s2));
+        if (E.b.gt_rgb)
+            s_rgb += (double)(fabsf(E.b.gt_rgb[i * 3 + 0] * s0) + fabsf(E.b.gt_rgb[i * 3 + 1] * s1) + fabsf(E.b.gt_rgb[i * 3 + 2] * s2));
+        cnt += (E.b.gt_depth && s0 != 0.f) ? 1 : 0;
+        if (E.gtedge) {
+            const int y = i / W, x = i - y * W;
+            float v[3][3];
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = y + dy, xx = x + dx;
-                float l = 0.f;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                    const size_t q = ((size_t)yy * W + xx) * 3;
-                    l = lum3(E.b.gt_rgb[q] * E.b.gt_seg[q], E.b.gt_rgb[q + 1] * E.b.gt_seg[q + 1], E.b.gt_rgb[q + 2] * E.b.gt_seg[q + 2]);
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    float l = 0.f;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        const size_t q = ((size_t)yy * W + xx) * 3;
+                        l = lum3(E.b.gt_rgb[q] * E.b.gt_seg[q], E.b.gt_rgb[q + 1] * E.b.gt_seg[q + 1], E.b.gt_rgb[q + 2] * E.b.gt_seg[q + 2]);
+                    }
+                    v[dy + 1][dx + 1] = l;
                 }
-                v[dy + 1][dx + 1] = l;
-            }
-        float gx, gy;
-        sobel3(v, gx, gy);
-        E.gtedge[i] = make_float2(gx, gy);
-        s += (double)(fabsf(gx) + fabsf(gy));
+            float gx, gy;
+            sobel3(v, gx, gy);
+            E.gtedge[i] = make_float2(gx, gy);
+            s_edge += (double)(fabsf(gx) + fabsf(gy));
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) red[wave] = s;
+    const double a = block_sum_256(s_rgb, red), bq = block_sum_256(s_mask, red), c = block_sum_256(s_edge, red);
+    const int total = (int)block_sum_256((double)cnt, red);
+    if (tid == 0) {
+        SetupPart& P = E.setup_part[blockIdx.x];
+        P.s_rgb = a; P.s_mask = bq; P.s_edge = c; P.count = total; P.offset = 0;
+    }
+}
+
+// one workgroup: the chunks' partials in chunk order -> frame constants, list size, every chunk's offset into the list
+__global__ __launch_bounds__(256) void setup_scan_kernel(EngineDev E, int n_chunks)
+{
+    const int tid = threadIdx.x;
+    const int per = (n_chunks + 255) / 256, c0 = tid * per, c1 = min(n_chunks, c0 + per);
+    __shared__ double s_a[256], s_b[256], s_c[256];
+    __shared__ int s_n[256];
+    double a = 0.0, bq = 0.0, c = 0.0;
+    int cnt = 0;
+    for (int i = c0; i < c1; ++i) {
+        const SetupPart& P = E.setup_part[i];
+        a += P.s_rgb; bq += P.s_mask; c += P.s_edge; cnt += P.count;
+    }
+    s_a[tid] = a; s_b[tid] = bq; s_c[tid] = c; s_n[tid] = cnt;
     __syncthreads();
     if (tid == 0) {
-        double a = 0.0;
-        for (int w = 0; w < 16; ++w) a += red[w];
-        E.st->c_edge = a;
+        double ta = 0.0, tb = 0.0, tc = 0.0;
+        int run = 0;
+        for (int t = 0; t < 256; ++t) {
+            ta += s_a[t]; tb += s_b[t]; tc += s_c[t];
+            const int m = s_n[t];
+            s_n[t] = run;
+            run += m;
+        }
+        E.st->c_rgb = ta; E.st->c_mask = tb; E.st->c_edge = tc; E.st->n_seg = run;
+    }
+    __syncthreads();
+    int off = s_n[tid];
+    for (int i = c0; i < c1; ++i) {
+        E.setup_part[i].offset = off;
+        off += E.setup_part[i].count;
+    }
+}
+
+// ordered compaction of the pixels with seg0 != 0 (ballot ranks + wave offsets, in pixel order)
+__global__ __launch_bounds__(256) void setup_fill_kernel(EngineDev E)
+{
+    const int n = E.d.H * E.d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int wcnt[4];
+    int carry = E.setup_part[blockIdx.x].offset;
+    for (int k = 0; k < SETUP_CHUNK / 256; ++k) {  // (workgroup-uniform)
+        const int i = blockIdx.x * SETUP_CHUNK + k * 256 + tid;
+        float gd = 0.f, s0 = 0.f;
+        bool flag = false;
+        if (i < n) {
+            s0 = E.b.gt_seg[i * 3 + 0];
+            if (s0 != 0.f) { flag = true; gd = E.b.gt_depth[i]; }
+        }
+        const unsigned long long m = __ballot(flag);
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        if (flag) E.seglist[off + __popcll(m & ((1ull << lane) - 1ull))] = make_float2(gd, s0);
+        carry += (wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]);
     }
 }
 
@@ -678,7 +733,7 @@ struct TileWork {
     unsigned short* list;      // LDS, this wave's: tiles [win, win + SCAN_LIST) of the slice, ty << 8 | tx
 };
 
-template <int ROLE, int NR>
+template <int ROLE, bool WLUM /* edge build: the colour role also feeds the edge term */>
 __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict__ pool, const TileWork& tw)
 {
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
@@ -739,7 +794,10 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             }
             if (__ballot(id > 0) == 0ull) continue;  // nothing drawn in this quadrant: only background terms
         } else {
-            // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn)
+            // ---- stage the 10x10 id halo of this quadrant (zbuf is all ones wherever nothing was drawn).  (Requesting the NEXT
+            // tile's halo entries while this one is shaded -- for workgroups that walk many tiles: an object filling a good part of
+            // the frame, where this role is the longer one -- was built and measured in round 3: +-0 at 4.7 % coverage, -5 % at 21 %:
+            // the other waves of the SIMD already cover the round trip; the texel gathers' DRAM traffic is the limit there.)
             bool anycov = false;
 #pragma unroll
             for (int e = lane; e < QH * QH; e += 64) {
@@ -776,7 +834,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             float gu = 0.f, gv = 0.f;
             // colour of the pixel and its derivatives w.r.t. the barycentrics (u, v), per channel; used by the rgb term
             // and -- in the edge build -- written out as luminance + unit gradient for edge_kernel
-            constexpr bool WLUM = NR == 3;  // edge build: this role also feeds the edge term
             if (d.use_rgb || WLUM) {
                 float col[3], dcu[3], dcv[3];
                 if (d.Th > 0) {
@@ -975,7 +1032,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     if (tw.sl < tw.n_flags) {  // (workgroup-uniform: every wave counted the same flags)
         // ---- wave reduction, then the four waves folded in a fixed order -> one partial row per (slice, role): bit-reproducible
         __shared__ float s_rows[WAVES_PER_TILE][NPART];
-        float* part = E.partials + (((size_t)b * E.pslices + tw.sl) * NR + ROLE) * NPART;
+        float* part = E.partials + (((size_t)b * E.pslices + tw.sl) * NROLE + ROLE) * NPART;
         constexpr int NV = NVALS - 1;  // (the 20th value, the edge loss, belongs to edge_kernel)
         float vals[NVALS];
 #pragma unroll
@@ -1008,7 +1065,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 // Two builds of the same kernel: without and with the edge role, so that the register allocation (and scratch
 // footprint) of the reference-loss configurations does not depend on the extension.
 template <bool EDGE>
-__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E, int it_arg)
+__device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int S, int z, int it_arg)
 {
     // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's active tiles in ascending tile order.  There is no list kernel:
     // every WAVE scans the hypothesis' row of tile flags itself (tile_scan: bytes written by step_kernel, 1.2 KB at 640x480),
@@ -1026,31 +1083,46 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
     float* pool = s_pool[wave];
     const RasterScratch& L = E.L;
     TileWork tw;
-    tw.b = blockIdx.x;
+    tw.b = b;
     const int it_cur = it_arg >= 0 ? it_arg : E.st->it_next - 1;  // the iteration being drawn (it_next is stable during this launch)
     tw.par = it_cur & 1;
-    if (blockIdx.z == 0 && blockIdx.y == 0 && tw.b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
-    tw.sl = blockIdx.y;
-    tw.S = gridDim.y;
+    if (z == 0 && sl == 0 && b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
+    tw.sl = sl;
+    tw.S = S;
     tw.frow = reinterpret_cast<const unsigned*>(L.tile_flag + ((size_t)tw.par * E.d.B + tw.b) * L.NTp);
     tw.n_dw = L.NTp >> 2;  // dwords of the row
     tw.invS = __frcp_rn((float)tw.S);
     tw.list = s_list[wave];
-    const bool lister = blockIdx.z == 0 && wave == 0;
-    const int wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const bool lister = z == 0 && wave == 0;
+    const int wg_id = (z * S + sl) * E.d.B + b;
     STAMP(E, 1, wg_id, 0);
     tw.n_flags = tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, 0, tw.list, lister ? L.active + (size_t)tw.b * L.NT : nullptr);
     tw.n_mine = tw.n_flags > tw.sl ? (tw.n_flags - tw.sl + tw.S - 1) / tw.S : 0;
     wave_lds_sync();
     if (lister && tw.sl == 0 && lane == 0) L.b_count[tw.b] = tw.n_flags;
     STAMP(E, 1, wg_id, 1);
-    constexpr int NR = EDGE ? 3 : 2;
-    const int role = blockIdx.z == 0 ? E.roles[0] : E.roles[1];
-    if (role == 0) shade_body<0, NR>(E, pool, tw);
-    else shade_body<1, NR>(E, pool, tw);
+    const int role = z == 0 ? E.roles[0] : E.roles[1];
+    if (role == 0) shade_body<0, EDGE>(E, pool, tw);
+    else shade_body<1, EDGE>(E, pool, tw);
     STAMP(E, 1, wg_id, 2);
     STAMP(E, 1, wg_id, 3);
-    if (tid == 0 && E.trace && wg_id < TRACE_WG) E.trace[((size_t)TRACE_WG + wg_id) * 8 + 4] = ((unsigned long long)blockIdx.z << 32) | (unsigned)tw.n_mine;
+    if (tid == 0 && E.trace && wg_id < TRACE_WG) E.trace[((size_t)TRACE_WG + wg_id) * 8 + 4] = ((unsigned long long)z << 32) | (unsigned)tw.n_mine;
+}
+
+template <bool EDGE>
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E, int it_arg)
+{
+    shade_wg<EDGE>(E, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, it_arg);
+}
+
+// group form: grid (sum of the members' hypotheses, largest slice count, 2)
+template <bool EDGE>
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
+{
+    const int o = group_find(G, blockIdx.x);
+    const EngineDev& E = tab[G.idx[o]];
+    if ((int)blockIdx.y >= E.s_shade || (int)blockIdx.z >= E.n_roles) return;
+    shade_wg<EDGE>(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_shade, blockIdx.z, it_arg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1062,7 +1134,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
 // texture fetch, no barycentrics -- the old edge role re-shaded the 100 halo pixels of every quadrant in two rounds.
 #define EH (QUAD + 4)  // 12: luminance halo
 #define ET (QUAD + 2)  // 10: loss terms
-__global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg)
+__device__ __forceinline__ void edge_wg(const EngineDev& E, int b, int sl, int S, int it_arg)
 {
     __shared__ float s_l[WAVES_PER_TILE][EH * EH];
     __shared__ float s_cx[WAVES_PER_TILE][ET * ET + 4], s_cy[WAVES_PER_TILE][ET * ET + 4];
@@ -1070,7 +1142,6 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg)
     const RasterScratch& L = E.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = d.H, W = d.W;
-    const int b = blockIdx.x;
     const int n_tiles = L.b_count[b];  // (count and ordered list: written by shade_kernel's scan)
     const int par = (it_arg >= 0 ? it_arg : E.st->it_next - 1) & 1;
     const unsigned long long* __restrict__ zb = L.zbuf + ((size_t)par * d.B + b) * L.zper;
@@ -1082,7 +1153,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg)
     __shared__ float s_acc[13][256];
 #pragma unroll
     for (int i = 0; i < 13; ++i) s_acc[i][tid] = 0.f;
-    for (int k = blockIdx.y; k < n_tiles; k += gridDim.y) {
+    for (int k = sl; k < n_tiles; k += S) {
         const int txy = L.active[(size_t)b * L.NT + k];
         const int qx = (txy & 0xffff) * DDX_TILE + (wave & 1) * QUAD, qy = (txy >> 16) * DDX_TILE + (wave >> 1) * QUAD;
         // ---- everything this quadrant needs is requested up front: the 12x12 (zbuf, lum) halo in 3 rounds of lanes, the
@@ -1176,9 +1247,9 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg)
         if (own_loss != 0.f) s_acc[12][tid] += own_loss;
         wave_lds_sync();  // (the LDS arrays are reused by the next tile)
     }
-    if ((int)blockIdx.y < n_tiles) {  // (workgroup-uniform)
+    if (sl < n_tiles) {  // (workgroup-uniform)
         __shared__ float s_rows[WAVES_PER_TILE][NPART];
-        float* part = E.partials + (((size_t)b * E.pslices + blockIdx.y) * 3 + 2) * NPART;
+        float* part = E.partials + (((size_t)b * E.pslices + sl) * NROLE + 2) * NPART;
         float mine = 0.f, mine2 = 0.f;
         float acc[13];
         bool nz = false;
@@ -1200,6 +1271,17 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg)
     }
 }
 
+__global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg) { edge_wg(E, blockIdx.x, blockIdx.y, gridDim.y, it_arg); }
+
+// group form: grid (sum of the members' hypotheses, largest slice count); members without the edge term leave at once
+__global__ __launch_bounds__(256) void edge_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
+{
+    const int o = group_find(G, blockIdx.x);
+    const EngineDev& E = tab[G.idx[o]];
+    if (!E.d.use_edge || (int)blockIdx.y >= E.s_edge) return;
+    edge_wg(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_edge, it_arg);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The optimiser step of iteration j for hypothesis b: the head of step_kernel and all of finish_kernel.
 // EVERY workgroup of the hypothesis runs it, redundantly (one kernel less in the iteration's chain; the partial rows are a few
@@ -1213,7 +1295,7 @@ __global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg)
 // 64- and 256-thread variants of step_kernel produce the same bits.
 #define UPD_SLICES 8  // workgroups per hypothesis of finish_kernel; fewer for large batches (upd_slices())
 
-template <int NTH, int NR>
+template <int NTH>
 __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, int slice, int n_slices, float* snew, float* sc)
 {
     constexpr int NG = NTH / 32, NW = NTH / 64, NBK = 8 / NG;  // groups of 32 threads, waves, row buckets per thread
@@ -1235,6 +1317,7 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
     // rows (speculative: rows of slices beyond the tile count are stale and masked below), the first tile of the re-arm
     // share, the totals of the sorted seg list.  The head is a chain of dependent round trips; these would otherwise each add one.
     const int rmask = E.role_mask;
+    constexpr int NR = NROLE;
     const int PS = E.pslices, nrow = PS * NR;
     const float* pbase = E.partials + (size_t)b * nrow * NPART + jj;
     auto row_ok = [&](int q) {  // row q = slice * NR + role: written by shade_kernel (roles 0, 1) / edge_kernel (role 2) when the slice has a tile
@@ -1441,18 +1524,13 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
 // The chain of one iteration used to be four launches (transform+update, scatter, compaction, shade) with the clip-space
 // vertices and their window snap travelling through HBM in between; here the optimiser step, the transform and the scatter
 // rasteriser are one workgroup-local pipeline and the compaction is gone (shade_kernel scans the flags itself).
-#ifndef STEP_MIN_WAVES
-#define STEP_MIN_WAVES 6  // waves per SIMD step_kernel is compiled for (<= 80 registers): 1536 resident 256-thread workgroups
-#endif
-template <int TPL, int NTH, int MODE, int NR>
-__global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, int mode, int it_arg)
+template <int TPL, int NTH, int MODE>
+__device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int SL, int mode, int it_arg)
 {
     constexpr int NTRI = TPL * NTH, NVC = 2 * NTH;
     const ddx_engine_desc& d = E.d;
-    // grid (slots, B), or (B, slots) with E.step_xcd: workgroup `slot` of hypothesis b takes the meshlets slot, slot + SL, ... --
-    // the head is paid once per workgroup, and SL is chosen so that all workgroups are resident (launch_step)
-    const int b = E.step_xcd ? blockIdx.x : blockIdx.y, slot = E.step_xcd ? blockIdx.y : blockIdx.x;
-    const int SL = E.step_xcd ? gridDim.y : gridDim.x;
+    // workgroup `slot` of the SL of hypothesis b: the head is paid once per workgroup, and SL is chosen so that all workgroups are
+    // resident (launch_step)
     const int B = d.B, V = d.V, M = E.n_meshlets;
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ float4 s_clip[NVC];
@@ -1480,7 +1558,7 @@ __global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, 
 #pragma unroll
     for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)m0 * NTRI + k * NTH + tid];
     if (mode == STEP_NORMAL) {
-        update_head<NTH, NR>(E, b, it - 1, slot, SL, snew, sc);
+        update_head<NTH>(E, b, it - 1, slot, SL, snew, sc);
     } else {
         // first iteration of a run: the parameters as the caller holds them (un-normalised)
         if (tid < 7) snew[tid] = E.b.params[(size_t)tid * B + b];
@@ -1596,33 +1674,66 @@ __global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, 
     STAMP(E, 0, wg_id, 7);
 }
 
+#ifndef STEP_MIN_WAVES
+#define STEP_MIN_WAVES 6  // waves per SIMD step_kernel is compiled for (<= 80 registers): 1536 resident 256-thread workgroups
+#endif
+// grid (slots, B), or (B, slots) with E.step_xcd
+template <int TPL, int NTH, int MODE>
+__global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, int mode, int it_arg)
+{
+    step_wg<TPL, NTH, MODE>(E, E.step_xcd ? blockIdx.x : blockIdx.y, E.step_xcd ? blockIdx.y : blockIdx.x, E.step_xcd ? gridDim.y : gridDim.x, mode, it_arg);
+}
+
+// group form: grid (largest slot count, sum of the members' hypotheses)
+template <int TPL, int NTH, int MODE>
+__global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int mode, int it_arg)
+{
+    const int o = group_find(G, blockIdx.y);
+    if ((int)blockIdx.x >= G.sl[o]) return;
+    step_wg<TPL, NTH, MODE>(tab[G.idx[o]], (int)blockIdx.y - G.bpre[o], blockIdx.x, G.sl[o], mode, it_arg);
+}
+
 // the optimiser step of the LAST iteration of a run (or of an evaluation pass): update_head alone, then both parities are clean
-template <int NR>
-__global__ __launch_bounds__(256) void finish_kernel(EngineDev E, int it_arg)
+__device__ __forceinline__ void finish_wg(const EngineDev& E, int b, int slice, int n_slices, int it_arg)
 {
     __shared__ float snew[8];
     __shared__ float sc[64];
-    const int b = blockIdx.y, it = it_arg >= 0 ? it_arg : E.st->it, par = it & 1;
-    update_head<256, NR>(E, b, it - 1, (int)blockIdx.x, (int)gridDim.x, snew, sc);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int it = it_arg >= 0 ? it_arg : E.st->it, par = it & 1;
+    update_head<256>(E, b, it - 1, slice, n_slices, snew, sc);
+    if (slice == 0 && threadIdx.x == 0) {
         E.L.bigcount[(size_t)(1 - par) * E.d.B + b] = 0;
-
         if (b == 0) E.L.counters[3 + (1 - par)] = 0;
     }
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(EngineDev E, int it_arg) { finish_wg(E, blockIdx.y, blockIdx.x, gridDim.x, it_arg); }
+
+// group form: grid (slices, sum of the members' hypotheses)
+__global__ __launch_bounds__(256) void finish_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
+{
+    const int o = group_find(G, blockIdx.y);
+    finish_wg(tab[G.idx[o]], (int)blockIdx.y - G.bpre[o], blockIdx.x, gridDim.x, it_arg);
 }
 
 // the tile pass for large / near-clipped triangles of the iteration being drawn (raster_dev.h big_pass_body); exits on one
 // scalar load when the batch has none (always, for the 20k-50k-triangle meshes of the benchmark)
 #define BIG_WAVES 16
 #define BIG_GRID 256
-__global__ __launch_bounds__(BIG_WAVES * 64) void big_pass_kernel(EngineDev E, int it_arg)
+__device__ __forceinline__ void big_wg(const EngineDev& E, int g, int Gn, int it_arg)
 {
     const int par = (it_arg >= 0 ? it_arg : E.st->it_next - 1) & 1, B = E.d.B;
     if (E.L.counters[3 + par] == 0) return;
     unsigned long long n_done = 0;
     big_pass_body<BIG_WAVES>(E.clip, E.stri, E.L.snap, E.L.tile_big + (size_t)par * B * E.L.NTp, E.L.biglist, E.L.bigcount + (size_t)par * B,
-                  E.L.zbuf + (size_t)par * B * E.L.zper, E.L.zper, E.L.zwb, E.L.ntx, E.L.NT, E.L.NTp, B, E.d.V, E.d.T, E.d.H, E.d.W,
-                  (int)blockIdx.x, (int)gridDim.x, n_done);
+                  E.L.zbuf + (size_t)par * B * E.L.zper, E.L.zper, E.L.zwb, E.L.ntx, E.L.NT, E.L.NTp, B, E.d.V, E.d.T, E.d.H, E.d.W, g, Gn, n_done);
+}
+
+__global__ __launch_bounds__(BIG_WAVES * 64) void big_pass_kernel(EngineDev E, int it_arg) { big_wg(E, blockIdx.x, gridDim.x, it_arg); }
+
+// group form: grid (workgroups per member, members)
+__global__ __launch_bounds__(BIG_WAVES * 64) void big_pass_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
+{
+    big_wg(tab[G.idx[blockIdx.y]], blockIdx.x, gridDim.x, it_arg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1690,8 +1801,7 @@ static int step_capacity(ddx_engine* e)
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
 #define STEP_OCC(TPL, NTH, MODE)                                                                                                   \
     do {                                                                                                                           \
-        if (e->dev.d.use_edge) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<TPL, NTH, MODE, 3>, NTH, 0); \
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<TPL, NTH, MODE, 2>, NTH, 0);                   \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<TPL, NTH, MODE>, NTH, 0);                           \
     } while (0)
     STEP_DISPATCH(STEP_OCC);
 #undef STEP_OCC
@@ -1712,8 +1822,7 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
     const dim3 g = E.step_xcd ? dim3(E.d.B, SL) : dim3(SL, E.d.B);
 #define STEP_LAUNCH(TPL, NTH, MODE)                                                          \
     do {                                                                                     \
-        if (E.d.use_edge) step_kernel<TPL, NTH, MODE, 3><<<g, NTH, 0, s>>>(E, mode, it);     \
-        else step_kernel<TPL, NTH, MODE, 2><<<g, NTH, 0, s>>>(E, mode, it);                  \
+        step_kernel<TPL, NTH, MODE><<<g, NTH, 0, s>>>(E, mode, it);                          \
     } while (0)
     STEP_DISPATCH(STEP_LAUNCH);
 #undef STEP_LAUNCH
@@ -1746,8 +1855,7 @@ static int launch_finish(ddx_engine* e, int it /* the iteration after the last o
 {
     EngineDev& E = e->dev;
     const dim3 g(upd_slices(E.d), E.d.B);
-    if (E.d.use_edge) finish_kernel<3><<<g, 256, 0, s>>>(E, it);
-    else finish_kernel<2><<<g, 256, 0, s>>>(E, it);
+    finish_kernel<<<g, 256, 0, s>>>(E, it);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -1923,8 +2031,12 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)2 * 14 * E.d.B * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // (both parities) kept zero by update_head afterwards
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // (both parities) re-armed per active tile by update_head
-    setup_kernel<<<1, 1024, 0, s>>>(E);
-    if (E.d.use_edge) edge_setup_kernel<<<1, 1024, 0, s>>>(E);
+    {
+        const int n_chunks = ddx_cdiv((long long)E.d.H * E.d.W, SETUP_CHUNK);
+        setup_part_kernel<<<n_chunks, 256, 0, s>>>(E);
+        setup_scan_kernel<<<1, 256, 0, s>>>(E, n_chunks);
+        if (E.b.gt_depth) setup_fill_kernel<<<n_chunks, 256, 0, s>>>(E);
+    }
     if (!e->mesh_done && E.texq && E.b.tex) build_texq_kernel<<<ddx_cdiv((long long)E.d.Th * E.d.Tw, 256), 256, 0, s>>>(E);
     DDX_LAUNCH_CHECK();
     DDX_HIP(hipMemsetD32Async((hipDeviceptr_t)E.inside, 1, (size_t)E.d.B, s));
@@ -2423,6 +2535,164 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
         if (names_out) names_out[k] = kKernelNames[k];
     for (auto& x : ev) (void)hipEventDestroy(x);
     return K_COUNT;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Engine groups (see GroupHdr): the members advance in lock step, one launch of each kernel per iteration for all of them.
+struct ddx_engine_group {
+    std::vector<ddx_engine*> members;
+    EngineDev* d_tab = nullptr;        // device table of the members' EngineDev
+    std::vector<EngineDev> h_tab;
+    bool uploaded = false;
+};
+
+extern "C" int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_group** out)
+{
+    DDX_REQUIRE(engines && out, DDX_E_NULL, "engine_group_create: NULL pointer");
+    DDX_REQUIRE(n >= 1 && n <= GROUP_MAX, DDX_E_SHAPE, "engine_group_create: %d members (1..%d)", n, GROUP_MAX);
+    for (int i = 0; i < n; ++i) {
+        DDX_REQUIRE(engines[i], DDX_E_NULL, "engine_group_create: member %d is NULL", i);
+        DDX_REQUIRE(engines[i]->dev.d.max_iters == engines[0]->dev.d.max_iters, DDX_E_SHAPE, "engine_group_create: members differ in max_iters");
+        for (int j = 0; j < i; ++j) DDX_REQUIRE(engines[j] != engines[i], DDX_E_SHAPE, "engine_group_create: member %d listed twice", i);
+    }
+    ddx_engine_group* g = new (std::nothrow) ddx_engine_group();
+    DDX_REQUIRE(g, DDX_E_NULL, "engine_group_create: out of host memory");
+    g->members.assign(engines, engines + n);
+    g->h_tab.resize((size_t)n);
+    if (hipMalloc(&g->d_tab, (size_t)n * sizeof(EngineDev)) != hipSuccess) {
+        delete g;
+        DDX_REQUIRE(false, DDX_E_NULL, "engine_group_create: hipMalloc of the member table failed");
+    }
+    *out = g;
+    return 0;
+}
+
+extern "C" void ddx_engine_group_destroy(ddx_engine_group* g)
+{
+    if (!g) return;
+    if (g->d_tab) (void)hipFree(g->d_tab);
+    delete g;
+}
+
+// the step_kernel variant of a member: members of one variant share a launch
+static int step_variant(const ddx_engine* e) { return e->small_mesh ? 1 : (e->dev.scatter_mode == 3 ? 3 : (e->dev.scatter_mode == 2 ? 2 : 0)); }
+
+static int group_step(ddx_engine_group* g, int mode, int it, hipStream_t s)
+{
+    const int n = (int)g->members.size();
+    long long Btot = 0;
+    for (auto* e : g->members) Btot += e->dev.d.B;
+    for (int variant = 0; variant < 4; ++variant) {
+        GroupHdr H;
+        H.n = 0;
+        H.bpre[0] = 0;
+        int slmax = 1;
+        for (int i = 0; i < n; ++i) {
+            ddx_engine* e = g->members[i];
+            if (step_variant(e) != variant) continue;
+            if (e->step_resident <= 0) e->step_resident = step_capacity(e);
+            // (slots as launch_step chooses them, with the hypotheses of the whole group sharing the chip)
+            int SL = std::max(1, std::min(e->dev.n_meshlets, (int)(e->step_resident / Btot)));
+            SL = ddx_cdiv(e->dev.n_meshlets, ddx_cdiv(e->dev.n_meshlets, SL));
+            SL = std::max(SL, std::min(UPD_SLICES, std::max(1, (int)(e->step_resident / Btot))));
+            H.idx[H.n] = i;
+            H.sl[H.n] = SL;
+            H.bpre[H.n + 1] = H.bpre[H.n] + e->dev.d.B;
+            slmax = std::max(slmax, SL);
+            ++H.n;
+        }
+        if (H.n == 0) continue;
+        const dim3 grid(slmax, H.bpre[H.n]);
+        if (variant == 1) step_group_kernel<1, 64, 1><<<grid, 64, 0, s>>>(g->d_tab, H, mode, it);
+        else if (variant == 3) step_group_kernel<2, 256, 3><<<grid, 256, 0, s>>>(g->d_tab, H, mode, it);
+        else if (variant == 2) step_group_kernel<2, 256, 2><<<grid, 256, 0, s>>>(g->d_tab, H, mode, it);
+        else step_group_kernel<2, 256, 0><<<grid, 256, 0, s>>>(g->d_tab, H, mode, it);
+    }
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+static GroupHdr group_all(const ddx_engine_group* g)
+{
+    GroupHdr H;
+    H.n = (int)g->members.size();
+    H.bpre[0] = 0;
+    for (int i = 0; i < H.n; ++i) {
+        H.idx[i] = i;
+        H.sl[i] = 0;
+        H.bpre[i + 1] = H.bpre[i] + g->members[(size_t)i]->dev.d.B;
+    }
+    return H;
+}
+
+static int group_rest(ddx_engine_group* g, int it, hipStream_t s)
+{
+    const GroupHdr H = group_all(g);
+    int smax = 1, semax = 0;
+    bool edge = false;
+    for (auto* e : g->members) {
+        smax = std::max(smax, e->dev.s_shade);
+        if (e->dev.d.use_edge) { edge = true; semax = std::max(semax, e->dev.s_edge); }
+    }
+    big_pass_group_kernel<<<dim3(BIG_GRID, H.n), BIG_WAVES * 64, 0, s>>>(g->d_tab, H, it);
+    const dim3 gs(H.bpre[H.n], smax, 2);
+    if (edge) shade_group_kernel<true><<<gs, 256, 0, s>>>(g->d_tab, H, it);
+    else shade_group_kernel<false><<<gs, 256, 0, s>>>(g->d_tab, H, it);
+    if (edge) edge_group_kernel<<<dim3(H.bpre[H.n], semax), 256, 0, s>>>(g->d_tab, H, it);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+// Iterations [it0, it0 + n) of every member (rows of each member's own lr_sched / loss_log / mtx_log); asynchronous on `stream`.
+// The result of a member is bit for bit what ddx_engine_run gives it alone.
+extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* stream)
+{
+    DDX_REQUIRE(g, DDX_E_NULL, "engine_group_run: NULL group");
+    hipStream_t s = (hipStream_t)stream;
+    const int max_iters = g->members[0]->dev.d.max_iters;
+    DDX_REQUIRE(it0 >= 0 && n >= 0 && it0 + n <= max_iters, DDX_E_SHAPE, "engine_group_run: iterations [%d,%d) exceed max_iters=%d", it0, it0 + n, max_iters);
+    bool fresh = !g->uploaded;
+    for (auto* e : g->members) {
+        e->fwd_cached_it = -1;
+        if (!e->setup_done) {
+            if (int err = engine_setup(e, s)) return err;
+            fresh = true;
+        }
+    }
+    if (n == 0) return 0;
+    for (auto* e : g->members)
+        if (int err = run_prologue(e, it0, s)) return err;
+    if (fresh) {  // (set-up fills fields of EngineDev: meshlet count, culling sign, scatter variant, bounding box, seg list size)
+        for (size_t i = 0; i < g->members.size(); ++i) {
+            g->h_tab[i] = g->members[i]->dev;
+            g->h_tab[i].eval_grad = nullptr;
+            g->h_tab[i].eval_loss = nullptr;
+        }
+        DDX_HIP(hipMemcpyAsync(g->d_tab, g->h_tab.data(), g->h_tab.size() * sizeof(EngineDev), hipMemcpyHostToDevice, s));
+        DDX_HIP(hipStreamSynchronize(s));  // (pageable source)
+        g->uploaded = true;
+    }
+    if (int err = group_step(g, STEP_FIRST, it0, s)) return err;
+    if (int err = group_rest(g, it0, s)) return err;
+    for (int i = 1; i < n; ++i) {
+        if (int err = group_step(g, STEP_NORMAL, it0 + i, s)) return err;
+        if (int err = group_rest(g, it0 + i, s)) return err;
+    }
+    {
+        const GroupHdr H = group_all(g);
+        finish_group_kernel<<<dim3(UPD_SLICES, H.bpre[H.n]), 256, 0, s>>>(g->d_tab, H, it0 + n);
+        DDX_LAUNCH_CHECK();
+    }
+    for (auto* e : g->members) e->adam_parity = (it0 + n) & 1;
+    return 0;
+}
+
+// a member's observation changed (ddx_engine_new_observation): its table row is uploaded again by the next run
+extern "C" int ddx_engine_group_invalidate(ddx_engine_group* g)
+{
+    DDX_REQUIRE(g, DDX_E_NULL, "engine_group_invalidate: NULL group");
+    g->uploaded = false;
+    return 0;
 }
 
 // DDX_TRACE=1 builds of the engine object: copies the stamp buffer to the host ([3][TRACE_WG][8] uint64); returns the number of

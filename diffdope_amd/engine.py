@@ -215,3 +215,46 @@ class RefineEngine:
                 self.handle = None
         except Exception:
             pass
+
+
+class RefineEngineGroup:
+    """Several RefineEngines advanced in lock step, ONE launch of each kernel per iteration for all of them (ddx_engine_group_*):
+    the objects of one frame (BASELINE config 5: 4 objects x 64 hypotheses per GPU).  Every member ends with bit for bit the
+    result it would get from its own run(); what changes is that the launches are shared, so the chip runs in its large-batch
+    regime instead of one latency-bound 64-hypothesis launch after the other.  Members must have the same number of
+    iterations (lr_sched length) and sit at the same iteration."""
+
+    def __init__(self, engines):
+        self.lib = _lib.load()
+        self.engines = list(engines)
+        if not self.engines:
+            raise ValueError("RefineEngineGroup needs at least one engine")
+        if len({e.max_iters for e in self.engines}) != 1 or len({e.it for e in self.engines}) != 1:
+            raise ValueError("the members of a group must share the schedule length and the current iteration")
+        arr = (ctypes.c_void_p * len(self.engines))(*[e.handle for e in self.engines])
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.ddx_engine_group_create(arr, len(self.engines), ctypes.byref(h)), "ddx_engine_group_create")
+        self.handle = h
+
+    @property
+    def it(self):
+        return self.engines[0].it
+
+    def run(self, n=None):
+        """n iterations (default: all remaining) of every member, asynchronously on the current stream."""
+        e0 = self.engines[0]
+        n = e0.max_iters - e0.it if n is None else n
+        _lib.check(self.lib.ddx_engine_group_run(self.handle, e0.it, n, _lib.stream_ptr()), "ddx_engine_group_run")
+        for e in self.engines:
+            e.it += n
+
+    def finish(self):
+        torch.cuda.current_stream().synchronize()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ddx_engine_group_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

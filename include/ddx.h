@@ -277,6 +277,25 @@ int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_out, const c
                        void* stream);
 void ddx_engine_destroy(ddx_engine* e);
 
+/* ---------------------------------------------------------------------------------------------
+ * Engine groups: several engines advance in lock step with ONE launch of each kernel per iteration for all of them -- the
+ * objects of one frame (examples/run_bop_scene.py:48-89 loops over them one after the other; BASELINE config 5 puts 4 objects x
+ * 64 hypotheses on a GPU).  A 64-hypothesis launch is latency-bound and fills a fraction of the chip; the members of a group
+ * share every grid.  Each member keeps its own buffers, scratch, schedule rows and launch geometry, and ends with bit for bit the
+ * result ddx_engine_run would give it alone.  Members may differ in mesh, texture, frame size, loss set and batch size; they
+ * must agree on max_iters.  The group borrows the engines (destroy the group first).  At most 32 members.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ddx_engine_group ddx_engine_group;
+int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_group** out);
+/* iterations [it0, it0 + n) of every member; asynchronous on `stream` (plain stream launches) */
+int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* stream);
+/* after ddx_engine_new_observation on a member nothing is needed; call this if a member was re-created in place */
+int ddx_engine_group_invalidate(ddx_engine_group* g);
+void ddx_engine_group_destroy(ddx_engine_group* g);
+/* measurement hook (DDX_TRACE=1 in the environment when the engine is created): per-workgroup phase stamps, see
+ * tools/trace_kernels.py; returns the number of uint64 written, 0 when tracing is off */
+int ddx_engine_trace_read(ddx_engine* e, unsigned long long* out, int max_n);
+
 #ifdef __cplusplus
 }
 #endif
