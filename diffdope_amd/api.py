@@ -651,6 +651,19 @@ class DiffDope:
         hp = self.cfg.hyperparameters
         return [hp.base_lr * hp.lr_decay ** (it / hp.nb_iterations + 1) for it in range(hp.nb_iterations + 1)]
 
+    def prepare_optimization(self, optimizer="sgd", global_batch=None, shade_slices=0, edge_slices=0):
+        """First half of run_optimization(wait=False) for callers that run several objects as ONE engine group
+        (bop.refine_frame): resets the logs, builds / refreshes the fused engine and returns it WITHOUT launching anything; after
+        the group has run, finish_optimization() collects the results as usual.  Only for the built-in losses."""
+        self.losses_values = _LossLog()
+        self.optimization_results = []
+        self._refresh_gt()
+        if not (all(f in _BUILTIN_LOSSES for f in self.loss_functions) and len(self.loss_functions) > 0):
+            raise RuntimeError("the fused engine only knows l1_rgb_with_mask / l1_depth_with_mask / l1_mask / l1_edge")
+        eng, params, weights = self._fused_prepare(optimizer, global_batch, shade_slices, edge_slices)
+        self._pending = (eng, params, weights, torch.cuda.current_stream())
+        return eng
+
     def run_optimization(self, fused=None, optimizer="sgd", global_batch=None, wait=True):
         """diffdope.py:1634-1714.  fused=None picks the fused engine when every loss function is a built-in.
         wait=False (fused path only) enqueues the whole optimisation on the current stream and returns; call
@@ -676,7 +689,9 @@ class DiffDope:
         if getattr(self, "_pending", None) is not None:
             self._fused_collect()
 
-    def _fused_enqueue(self, optimizer, global_batch):
+    def _fused_prepare(self, optimizer, global_batch, shade_slices=0, edge_slices=0):
+        """The fused engine for this object, observation and schedule, ready at iteration 0 (built, or the previous run's engine
+        with the new observation copied in); nothing is launched.  Returns (engine, params tensor, weights)."""
         r = self.object3d.mesh()
         lw = self.cfg.losses
         weights = {}
@@ -689,12 +704,12 @@ class DiffDope:
         tex = dict(uv=r["uv"][0], tex=r["tex"][0]) if self.object3d.mesh.has_textured_map else dict(vtx_color=r["vtx_color"][0])
         # the engine of the previous run is kept while everything but the observation and the initial poses is the same (the
         # same object in the next frame, or a second run on the same frame): the mesh half of its set-up -- sorted copies,
-        # triangle / texel records, closedness analysis, ~half of a 100-iteration call -- is then not repeated
+        # meshlets, triangle / texel records, closedness analysis, ~half of a 100-iteration call -- is then not repeated
         from .render import _buffer_key
 
         mesh_t = [r["pos"], r["pos_idx"], self.camera.cam_proj] + list(tex.values())
         sig = (tuple(_buffer_key(t) for t in mesh_t), tuple(self.resolution), self.batchsize, tuple(sorted(weights.items())), optimizer,
-               global_batch, len(self.lr_schedule()), tuple(sorted((k, tuple(v.shape)) for k, v in gt.items())))
+               global_batch, len(self.lr_schedule()), tuple(sorted((k, tuple(v.shape)) for k, v in gt.items())), shade_slices, edge_slices)
         cached = getattr(self, "_engine_cache", None)
         if cached is not None and cached[0] == sig and getattr(self, "_pending", None) is None:
             eng = cached[1]
@@ -702,8 +717,13 @@ class DiffDope:
             params = eng.params
         else:
             eng = RefineEngine(r["pos"][0], r["pos_idx"][0], self.camera.cam_proj[0], self.resolution, gt, params, self.learning_rates,
-                               self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, **tex)
+                               self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, shade_slices=shade_slices,
+                               edge_slices=edge_slices, **tex)
             self._engine_cache = (sig, eng, mesh_t)  # (mesh_t: keeps the keyed buffers alive, see render._buffer_key)
+        return eng, params, weights
+
+    def _fused_enqueue(self, optimizer, global_batch):
+        eng, params, weights = self._fused_prepare(optimizer, global_batch)
         eng.run()
         self._pending = (eng, params, weights, torch.cuda.current_stream())
 

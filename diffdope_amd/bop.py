@@ -29,7 +29,7 @@ def owner_of(obj_index, world):
     return obj_index % world
 
 
-def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, optimizer="sgd", scale=0.01):
+def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, optimizer="sgd", scale=0.01, mode="group"):
     """Refine every object of one frame.
 
     cfg: config mapping (losses / hyperparameters as configs/diffdope.yaml); camera: Camera; scene: Scene with the
@@ -37,28 +37,48 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
     per-object "losses" mapping overrides cfg["losses"] entries -- BASELINE config 5's mixed loss sets); meshes: {obj_id: Mesh};
     masks: list of Image (mask_visib of object i).  Returns (table [n_obj,18] float64 tensor identical on every
     rank: loss, arg-min hypothesis, 4x4 pose row-major, and per-object DiffDope handles for the local objects).
-    """
+
+    mode: how the local objects (4 per GPU in config 5) share the GPU.  "group" (default): ONE engine group -- one launch of each
+    kernel per iteration for all of them (RefineEngineGroup; a 64-hypothesis launch is latency-bound and fills a fraction of
+    the chip); "streams": one HIP stream per object;
+    "sequential": one after the other.  Whatever the mode, an object's result is the same bits."""
     n = len(objects)
     B = cfg["hyperparameters"]["batchsize"]
     dev = torch.device("cuda", torch.cuda.current_device())
     table = torch.zeros((n, 18), dtype=torch.float32, device=dev)
     handles = {}
-    # the local objects run on one stream each: every engine is a chain of four latency-bound kernels per iteration, and
-    # the kernels of another object fill their launch tails (4 objects of BASELINE config 5: 22.6 -> 20.8 ms per frame)
+    local = [i for i in range(n) if owner_of(i, world) == rank]
+    # slices of the shading / edge launches per hypothesis: every engine's own choice from ITS batch size -- not from how many
+    # objects happen to share this GPU -- so that an object's result does not depend on the number of ranks (the gradient sum is
+    # grouped by slices).  (Fewer slices for a fuller GPU measured 5 % faster on 4 x 64 hypotheses at 640x480, equal at 1280x720.)
+    ss, es = int(cfg["hyperparameters"].get("shade_slices", 0)), int(cfg["hyperparameters"].get("edge_slices", 0))
     main = torch.cuda.current_stream()
-    for i, o in enumerate(objects):
-        if owner_of(i, world) != rank:
-            continue
+    engines = []
+    for i in local:
+        o = objects[i]
         obj = Object3D(position=list(o["t_mm"]), rotation=list(np.asarray(o["R"]).reshape(-1)), batchsize=B, scale=scale,
                        mesh=meshes[o["obj_id"]])
         sc = Scene(tensor_rgb=scene.tensor_rgb, tensor_depth=scene.tensor_depth, tensor_segmentation=masks[i])
         cfg_i = cfg if "losses" not in o else {**cfg, "losses": {**cfg["losses"], **o["losses"]}}
         dd = DiffDope(cfg=cfg_i, camera=camera, object3d=obj, scene=sc)
-        st = torch.cuda.Stream()
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            dd.run_optimization(optimizer=optimizer, wait=False)
         handles[i] = dd
+        if mode == "group":
+            engines.append(dd.prepare_optimization(optimizer=optimizer, shade_slices=ss, edge_slices=es))
+        elif mode == "streams":
+            # every engine is a chain of latency-bound kernels per iteration, and the kernels of another object fill their launch tails
+            st = torch.cuda.Stream()
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                eng = dd.prepare_optimization(optimizer=optimizer, shade_slices=ss, edge_slices=es)
+                eng.run()
+        elif mode == "sequential":
+            dd.prepare_optimization(optimizer=optimizer, shade_slices=ss, edge_slices=es).run()
+        else:
+            raise ValueError(f"refine_frame: unknown mode {mode!r}")
+    if mode == "group" and engines:
+        from .engine import RefineEngineGroup
+
+        RefineEngineGroup(engines).run()
     for i, dd in handles.items():
         dd.finish_optimization()
         best = int(dd.get_argmin())

@@ -1,6 +1,7 @@
 """BASELINE configs[4], one GPU's share: 32 objects x 64 hypotheses at 1280x720 over 8 GPUs = FOUR different meshes x 64 hypotheses per
 GPU, refined through bop.refine_frame (the reference's examples/run_bop_scene.py:48-89 flow) with mixed rgb / depth / edge / mask
-loss sets.  Checked here: the multi-stream frame is bit-identical to four engines run one after the other; and every object's engine,
+loss sets.  Checked here: the frame as ONE engine group is bit-identical to one stream per object and to four engines run one
+after the other; and every object's engine,
 as refine_frame built it (mesh of 20 480 triangles, 2048-px frame crop semantics of the API, its own mask and loss set), against the
 oracle on two hypotheses (losses rtol 5e-5, pose gradient 3e-3 of its largest component) with duplicated hypotheses bit-identical."""
 import json
@@ -69,8 +70,15 @@ def test_config5_share_four_objects_64_hypotheses_1280x720(tmp_path, H, W, rows,
     cfg = dict(losses=dict(l1_rgb_with_mask=True, weight_rgb=0.7, l1_depth_with_mask=True, weight_depth=1.0, l1_mask=True, weight_mask=1.0),
                hyperparameters=dict(nb_iterations=n_it, batchsize=B, base_lr=0.05, learning_rates_bound=[0.5, 3.0], learning_rate_base=1,
                                     lr_decay=0.1, seed=5))
-    # ---- the frame as the driver runs it: the four local objects on one stream each
+    # ---- the frame as the driver runs it: the four local objects as ONE engine group (one launch of each kernel per iteration)
     table, handles = bop.refine_frame(cfg, dd.Camera(**intr), scene, objs, meshes, masks, optimizer="sgd")
+    # ... one stream per object gives the same bits
+    table_s, handles_s = bop.refine_frame(cfg, dd.Camera(**intr), scene, objs, meshes, masks, optimizer="sgd", mode="streams")
+    assert torch.equal(table, table_s)
+    for i in range(4):
+        assert torch.equal(handles[i].last_engine.mtx_log, handles_s[i].last_engine.mtx_log)
+        assert torch.equal(handles[i].object3d.params_tensor(), handles_s[i].object3d.params_tensor())
+    del handles_s
     assert tuple(table.shape) == (4, 18) and sorted(handles) == [0, 1, 2, 3]
     want = [{"rgb", "depth", "edge"}, {"rgb", "depth", "mask_selection"}, {"depth", "mask_selection"}, {"rgb", "edge"}]
     for i in range(4):
@@ -80,13 +88,16 @@ def test_config5_share_four_objects_64_hypotheses_1280x720(tmp_path, H, W, rows,
         assert (e.B, e.H, e.W, e.desc.T, e.desc.B_global) == (B, H, W, 2 * rows * cols, B)
         assert e.status()["overflow"] == 0 and e.status()["active_tiles"] > 0
         assert all(torch.isfinite(v).all() for v in h.losses_values.values())
-    # ---- ... is bit-identical to four engines run one after the other on the default stream
+    # ---- ... and is bit-identical to four engines run one after the other on the default stream
+    e0 = handles[0].last_engine
+    ss, es = int(e0.desc.shade_slices), int(e0.desc.edge_slices)
     for i, o in enumerate(objs):
         obj = dd.Object3D(position=list(o["t_mm"]), rotation=list(np.asarray(o["R"]).reshape(-1)), batchsize=B, scale=0.01, mesh=meshes[o["obj_id"]])
         sc = dd.Scene(tensor_rgb=scene.tensor_rgb, tensor_depth=scene.tensor_depth, tensor_segmentation=masks[i])
         seq = dd.DiffDope(cfg={**cfg, "losses": {**cfg["losses"], **o["losses"]}}, camera=dd.Camera(**intr), object3d=obj, scene=sc)
         p0 = seq.object3d.params_tensor().clone()
-        seq.run_optimization(optimizer="sgd")
+        seq.prepare_optimization(optimizer="sgd", shade_slices=ss, edge_slices=es).run()
+        seq.finish_optimization()
         h = handles[i]
         assert set(seq.losses_values) == set(h.losses_values)
         for k in seq.losses_values:
