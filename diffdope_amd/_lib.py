@@ -15,6 +15,8 @@ _lib = None
 
 _I, _LL, _SZ, _P = ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t, ctypes.c_void_p
 
+COMPAT_UNCLAMPED_BARY_GRAD = 1  # ddx.h DDX_COMPAT_UNCLAMPED_BARY_GRAD (deviation D2)
+
 
 class EngineDesc(ctypes.Structure):
     _fields_ = [
@@ -26,7 +28,7 @@ class EngineDesc(ctypes.Structure):
         ("adam_beta1", ctypes.c_float), ("adam_beta2", ctypes.c_float), ("adam_eps", ctypes.c_float),
         ("max_iters", ctypes.c_int32), ("use_edge", ctypes.c_int32), ("w_edge", ctypes.c_float),
         ("shade_slices", ctypes.c_int32), ("edge_slices", ctypes.c_int32), ("no_backface_cull", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 3),
+        ("compat", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -41,6 +43,7 @@ class EngineBuffers(ctypes.Structure):
 _SIGNATURES = {
     "ddx_version": (_I, []),
     "ddx_last_error": (ctypes.c_char_p, []),
+    "ddx_set_compat": (_I, [_I]),
     "ddx_xfm_fwd": (_I, [_P, _LL, _P, _I, _I, _I, _P, _I, _P]),
     "ddx_xfm_bwd_points": (_I, [_P, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_xfm_bwd_mtx": (_I, [_P, _LL, _I, _I, _I, _P, _P, _I, _P]),

@@ -17,6 +17,15 @@ void ddx_set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+static int g_compat = 0;
+int ddx_compat_flags(void) { return g_compat; }
+extern "C" int ddx_set_compat(int flags)
+{
+    const int old = g_compat;
+    g_compat = flags;
+    return old;
+}
+
 extern "C" int ddx_version(void) { return DDX_VERSION; }
 extern "C" const char* ddx_last_error(void) { return g_err; }
 

@@ -9,6 +9,7 @@
 #define DDX_WAVE 64
 
 void ddx_set_error(const char* fmt, ...);
+int ddx_compat_flags(void);  // process-wide DDX_COMPAT_* bits (ddx_set_compat)
 
 #define DDX_REQUIRE(cond, code, ...)          \
     do {                                      \

@@ -886,7 +886,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     const float third = 1.0f / 3.0f;
                     const float gu2 = third * ((dcu[0] + dcu[1]) + dcu[2]), gv2 = third * ((dcv[0] + dcv[1]) + dcv[2]);
                     float gx[3], gy[3], gw[3];
-                    bary_backward(bc, gu2, gv2, gx, gy, gw);
+                    bary_backward(bc, gu2, gv2, gx, gy, gw, (d.compat & DDX_COMPAT_UNCLAMPED_BARY_GRAD) != 0);
                     PixAcc T;
 #pragma unroll
                     for (int i = 0; i < 12; ++i) T.dF[i] = 0.f;
@@ -924,7 +924,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             }
             if (gu != 0.f || gv != 0.f) {
                 float gx[3], gy[3], gw[3];
-                bary_backward(bc, gu, gv, gx, gy, gw);
+                bary_backward(bc, gu, gv, gx, gy, gw, (d.compat & DDX_COMPAT_UNCLAMPED_BARY_GRAD) != 0);
                 acc_vertex_regs(A, x0, y0, z0, gx[0], gy[0], gw[0]);
                 acc_vertex_regs(A, x1, y1, z1, gx[1], gy[1], gw[1]);
                 acc_vertex_regs(A, x2, y2, z2, gx[2], gy[2], gw[2]);

@@ -225,11 +225,12 @@ __device__ __forceinline__ unsigned int depth_key(float zw)
 __device__ __forceinline__ float clamp01(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
 
 // gradient of (u,v) w.r.t. the clip-space (x,y,w) of the three vertices, given upstream (gu,gv).
-// True derivative of the forward: a clamped component passes no gradient.
-__device__ __forceinline__ void bary_backward(const Bary& bc, float gu, float gv, float gx[3], float gy[3], float gw[3])
+// True derivative of the forward: a clamped component passes no gradient (DESIGN.md deviation D2).  unclamped = true
+// (DDX_COMPAT_UNCLAMPED_BARY_GRAD): the derivative of the UNCLAMPED expression, as nvdiffrast's rasterize backward takes it.
+__device__ __forceinline__ void bary_backward(const Bary& bc, float gu, float gv, float gx[3], float gy[3], float gw[3], bool unclamped = false)
 {
-    if (bc.u < 0.f || bc.u > 1.f) gu = 0.f;
-    if (bc.v < 0.f || bc.v > 1.f) gv = 0.f;
+    if (!unclamped && (bc.u < 0.f || bc.u > 1.f)) gu = 0.f;
+    if (!unclamped && (bc.v < 0.f || bc.v > 1.f)) gv = 0.f;
     const float is = __fdiv_rn(1.0f, bc.s);
     const float k = gu * bc.u + gv * bc.v;
     const float A0 = (gu - k) * is, A1 = (gv - k) * is, A2 = (-k) * is;

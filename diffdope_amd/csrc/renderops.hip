@@ -20,7 +20,7 @@ static inline dim3 pix_grid2(long long HW, int B) { return dim3((unsigned)((HW +
 __global__ __launch_bounds__(256) void rasterize_bwd_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
                                                             int V, int T, int B, int H, int W,
                                                             const float* __restrict__ rast,
-                                                            const float* __restrict__ drast, float* __restrict__ dpos)
+                                                            const float* __restrict__ drast, float* __restrict__ dpos, int compat)
 {
     const long long n = (long long)B * H * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void rasterize_bwd_kernel(const float* __restr
         Bary bc;
         if (!pixel_bary(p0, p1, p2, px, py, H, W, bc)) continue;
         float gx[3], gy[3], gw[3];
-        bary_backward(bc, g.x, g.y, gx, gy, gw);
+        bary_backward(bc, g.x, g.y, gx, gy, gw, (compat & DDX_COMPAT_UNCLAMPED_BARY_GRAD) != 0);
         float* D = dpos + (size_t)b * V * 4;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -55,7 +55,7 @@ extern "C" int ddx_rasterize_bwd(const float* pos, const int32_t* tri, int B, in
     hipStream_t s = (hipStream_t)stream;
     DDX_HIP(hipMemsetAsync(dpos, 0, (size_t)B * V * 4 * sizeof(float), s));
     const long long n = (long long)B * H * W;
-    rasterize_bwd_kernel<<<PIX_GRID(n), 256, 0, s>>>(pos, tri, V, T, B, H, W, rast, drast, dpos);
+    rasterize_bwd_kernel<<<PIX_GRID(n), 256, 0, s>>>(pos, tri, V, T, B, H, W, rast, drast, dpos, ddx_compat_flags());
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restric
                                                           const float* __restrict__ tex, int Th, int Tw, const float* __restrict__ vcol,
                                                           int V, int T, int H, int W, const float* __restrict__ drgb,
                                                           const float* __restrict__ ddepth, float* __restrict__ dclip,
-                                                          float* __restrict__ dmtx)
+                                                          float* __restrict__ dmtx, int compat)
 {
     const int HW = H * W;
     __shared__ float s_dm[4][4];
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restric
                     Bary bc;
                     if (pixel_bary(c0, c1, c2, px, py, H, W, bc)) {
                         float gx[3], gy[3], gw[3];
-                        bary_backward(bc, gu, gv, gx, gy, gw);
+                        bary_backward(bc, gu, gv, gx, gy, gw, (compat & DDX_COMPAT_UNCLAMPED_BARY_GRAD) != 0);
                         float* D = dclip + (size_t)bb * V * 4;
                         const int vi[3] = {i0, i1, i2};
 #pragma unroll
@@ -774,8 +774,8 @@ extern "C" int ddx_gbuffer_bwd(const float* rast, const float* clip, const float
     hipStream_t s = (hipStream_t)stream;
     DDX_HIP(hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(dmtx, 0, (size_t)B * 16 * sizeof(float), s));
-    if (uv && tex) gbuffer_bwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H, W, drgb, ddepth, dclip, dmtx);
-    else gbuffer_bwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H, W, drgb, ddepth, dclip, dmtx);
+    if (uv && tex) gbuffer_bwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H, W, drgb, ddepth, dclip, dmtx, ddx_compat_flags());
+    else gbuffer_bwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H, W, drgb, ddepth, dclip, dmtx, ddx_compat_flags());
     DDX_LAUNCH_CHECK();
     return 0;
 }

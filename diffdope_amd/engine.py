@@ -43,13 +43,15 @@ class RefineEngine:
         global_batch: batch size of the whole job when hypotheses are sharded over GPUs
         shade_slices / edge_slices: workgroups per hypothesis of the shading / edge launches (0 = from B).  A shard
             that must reproduce the unsharded run bit for bit passes the unsharded engine's `slices` (ddx.h)
+        compat: None = this build's documented arithmetic; "nvdiffrast" = where a deviation from nvdiffrast's published behaviour is
+            switchable, nvdiffrast's (D2: the rasterize backward differentiates the unclamped barycentrics; ddx.h DDX_COMPAT_*)
         cull_backfaces: skip the back faces of a closed mesh while a hypothesis lies inside the view volume (ddx.h
             no_backface_cull; identical visibility in exact arithmetic).  False = always draw both faces.
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
                  vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True, shade_slices=0,
-                 edge_slices=0, cull_backfaces=True):
+                 edge_slices=0, cull_backfaces=True, compat=None):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":
@@ -92,6 +94,7 @@ class RefineEngine:
         d.max_iters = n_it
         d.shade_slices, d.edge_slices = int(shade_slices), int(edge_slices)
         d.no_backface_cull = int(not cull_backfaces)
+        d.compat = {None: 0, "nvdiffrast": _lib.COMPAT_UNCLAMPED_BARY_GRAD}[compat]
         self.desc = d
         nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))
         if nbytes == 0:

@@ -40,6 +40,15 @@ def _i32c(t, name):
     return t.contiguous()
 
 
+def set_compat(mode=None):
+    """Compatibility switch of the op-level renderer ops (process-wide, ddx.h ddx_set_compat): None = this build's documented
+    arithmetic; "nvdiffrast" = nvdiffrast's published behaviour where a deviation is switchable (D2: rasterize / gbuffer backward
+    differentiate the unclamped barycentrics).  Returns the previous flags."""
+    from . import _lib as L
+
+    return L.load().ddx_set_compat({None: 0, "nvdiffrast": L.COMPAT_UNCLAMPED_BARY_GRAD}[mode])
+
+
 class PixelDerivativesNotComputed(torch.Tensor):
     """Shape-only stand-in for nvdiffrast's screen-space derivative outputs (rast_db of dr.rasterize, the second output of
     dr.interpolate with diff_attrs): inspecting it (shape, dtype, device, repr) and passing it on is fine, computing with it

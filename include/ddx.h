@@ -40,6 +40,14 @@ extern "C" {
 int ddx_version(void);
 const char* ddx_last_error(void);
 
+/* Compatibility switches for the arithmetic this build restates from nvdiffrast's published behaviour (DESIGN.md section 2,
+ * "deviations"): process-wide for the op-level entry points (read at call time), per engine through ddx_engine_desc.compat.
+ * ddx_set_compat returns the previous flags.
+ *   DDX_COMPAT_UNCLAMPED_BARY_GRAD (deviation D2): the rasterize backward differentiates the UNCLAMPED barycentric expression,
+ *   as nvdiffrast does, instead of the forward's true derivative (a component saturated by the [0,1] clamp passes nothing). */
+#define DDX_COMPAT_UNCLAMPED_BARY_GRAD 1
+int ddx_set_compat(int flags);
+
 /* ---------------------------------------------------------------------------------------------
  * xfm: batched 4x4 transform of points / vectors.
  * Replaces torch_bindings.cpp:142-175 (xfm_fwd), :177-203 (xfm_bwd), :242-277 (xfm_bwd_mtx),
@@ -192,7 +200,8 @@ typedef struct ddx_engine_desc {
      * entirely inside the view volume -- they are hidden behind front faces there, so this changes nothing in exact
      * arithmetic (deviation D5) and halves the fragment work.  Environment DDX_NO_CULL=1 also disables. */
     int32_t no_backface_cull;
-    int32_t reserved[3];
+    int32_t compat;   /* DDX_COMPAT_* bits for this engine (0 = this build's documented behaviour) */
+    int32_t reserved[2];
 } ddx_engine_desc;
 
 typedef struct ddx_engine_buffers {

@@ -209,6 +209,15 @@ def mesh_cull_sign(pos, tri, proj):
     return 1 if (vol6 > 0) == (detA > 0) else -1
 
 
+def set_compat(nvdiffrast):
+    """Deviation D2 switch for both precisions: True = the rasterize backward differentiates the unclamped barycentrics
+    (nvdiffrast's published rule); False = the true derivative of the clamped forward (this build).  Returns the old setting."""
+    old = 0
+    for dt in (np.float32, np.float64):
+        old = _lib(dt).orc_set_unclamped_bary_grad(int(bool(nvdiffrast)))
+    return bool(old)
+
+
 def rasterize_bwd(pos, tri, rast, drast):
     dt = pos.dtype
     pos, tri, rast, drast = _c(pos, dt), _i32(tri), _c(rast, dt), _c(drast, dt)

@@ -123,6 +123,27 @@ def test_d2_saturated_barycentric_passes_no_gradient():
     d2[0, 3, 3, 0] = 1.0  # its left neighbour, clear interior (u = 0.25)
     g_int = orc.rasterize_bwd(P, tri, rast, d2)
     assert 0 < rast[0, 3, 3, 0] < 1 and np.abs(g_int[0, :, 0]).max() > 0.2  # d u / d x_clip ~ (W/2) / (width in pixels) = 4 / 4
+    # the compat switch (ddx.h DDX_COMPAT_UNCLAMPED_BARY_GRAD / RefineEngine(compat="nvdiffrast") / oracle.set_compat): the saturated
+    # pixel then carries the derivative of the unclamped u -- the same formula as an interior pixel -- and nothing else changes
+    old = orc.set_compat(True)
+    try:
+        g_nv = orc.rasterize_bwd(P, tri, rast, d)
+        assert np.array_equal(orc.rasterize_bwd(P, tri, rast, d2), g_int)
+    finally:
+        orc.set_compat(old)
+    Pd = P.astype(np.float64)
+    def u_at(Pq):  # unclamped barycentric of vertex 0 at the centre of pixel (4,3): signed areas in clip space (w = 1)
+        x, y = Pq[0, :, 0], Pq[0, :, 1]
+        fx, fy = (4 + 0.5) / W * 2 - 1, (3 + 0.5) / H * 2 - 1
+        a = lambda i, j: (x[i] - fx) * (y[j] - fy) - (y[i] - fy) * (x[j] - fx)
+        return a(1, 2) / (a(1, 2) + a(2, 0) + a(0, 1))
+    for v in range(3):
+        for c in range(2):
+            Pp, Pm = Pd.copy(), Pd.copy()
+            Pp[0, v, c] += 1e-6
+            Pm[0, v, c] -= 1e-6
+            assert abs((u_at(Pp) - u_at(Pm)) / 2e-6 - g_nv[0, v, c]) < 1e-4 * max(1.0, np.abs(g_nv).max())
+    assert np.abs(g_nv).max() > 0.2
     # the deviation is confined to saturated pixels: the analytic gradient at the interior pixel is the true derivative
     eps = 1e-6
     Pp, Pm = P.copy(), P.copy()
