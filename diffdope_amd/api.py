@@ -474,7 +474,9 @@ class _LossLog(dict):
         f.__name__ = name
         return f
 
-    for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "keys", "values", "items", "get", "copy", "pop"):
+    # (writers too: setdefault / update / item assignment on a key with un-flushed rows would otherwise see a dict without them)
+    for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "__reversed__", "__or__", "__ror__", "__ior__", "keys",
+               "values", "items", "get", "copy", "pop", "popitem", "setdefault", "update", "__setitem__", "__delitem__", "clear"):
         locals()[_n] = _reader(_n)
     del _n, _reader
 
@@ -493,6 +495,12 @@ class _LazyResult(dict):
             v = v.cpu()
             dict.__setitem__(self, key, v)
         return v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]  # (through __getitem__ / __missing__: "mtx" comes back on the host, the images are rendered)
+        except KeyError:
+            return default
 
     def __missing__(self, key):
         if key in ("rgb", "depth", "mask"):

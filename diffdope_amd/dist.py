@@ -55,7 +55,7 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
     """global_argmin with the local selection done by one device kernel (ddx_select_best) and ONE host
     synchronisation: loss_rows [4,B] (one iteration's row block of RefineEngine.loss_log), row_mask = bit r set when
     loss row r takes part in the mean, mtx [B,16] or [B,4,4].  Same result as
-    global_argmin(loss_rows[used].mean(0), mtx, lo)."""
+    global_argmin(loss_rows[used].mean(0), mtx, lo), with the pose returned as a HOST tensor at every world size."""
     import torch.distributed as dist
 
     from . import _lib
@@ -67,12 +67,13 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
     if not dist.is_initialized():
         # one process: the kernel stores its 18 floats straight into pinned host memory (mapped into the GPU's address space):
         # no device -> host copy to launch, the stream synchronisation is the only wait
-        table = _pinned_row()
-        _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table.data_ptr(),
-                                       _lib.stream_ptr()), "ddx_select_best")
-        torch.cuda.current_stream().synchronize()
-        t = table.numpy()
-        return int(t[0, 1]), float(t[0, 0]), table[0, 2:].clone().reshape(4, 4)
+        with _PINNED_LOCK:  # (one pinned row per process: held until its 18 floats have been read)
+            table = _pinned_row()
+            _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table.data_ptr(),
+                                           _lib.stream_ptr()), "ddx_select_best")
+            torch.cuda.current_stream().synchronize()
+            t = table.numpy()
+            return int(t[0, 1]), float(t[0, 0]), table[0, 2:].clone().reshape(4, 4)
     table = torch.zeros((world, 18), dtype=torch.float32, device=loss_rows.device)
     _lib.check(lib.ddx_select_best(loss_rows.data_ptr(), int(row_mask), B, mtx.data_ptr(), int(lo), table[rank].data_ptr(),
                                    _lib.stream_ptr()), "ddx_select_best")
@@ -81,10 +82,13 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
     losses, gidx = t[:, 0], t[:, 1]
     cand = [(gidx[r], r) for r in range(world) if losses[r] == losses.min()]  # ties -> lowest global index
     row = min(cand)[1]
-    return int(t[row, 1]), float(t[row, 0]), table[row, 2:].reshape(4, 4)  # (the pose: a view of the table)
+    return int(t[row, 1]), float(t[row, 0]), torch.from_numpy(t[row, 2:].copy()).reshape(4, 4)  # (the pose on the HOST, as in the one-process path)
 
+
+import threading
 
 _PINNED = None
+_PINNED_LOCK = threading.Lock()
 
 
 def _pinned_row():

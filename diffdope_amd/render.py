@@ -54,13 +54,22 @@ class PixelDerivativesNotComputed(torch.Tensor):
     dr.interpolate with diff_attrs): inspecting it (shape, dtype, device, repr) and passing it on is fine, computing with it
     raises."""
 
-    _PASSIVE = {"__get__", "size", "dim", "stride", "__repr__", "__len__", "numel", "is_contiguous", "__format__", "__str__",
+    _PASSIVE_PROPS = {"shape", "dtype", "device", "requires_grad", "ndim", "is_cuda", "layout", "grad_fn", "is_leaf", "grad", "names",
+                      "is_sparse", "is_quantized", "is_meta", "is_mkldnn", "is_nested", "is_cpu", "is_xpu", "is_mps", "is_vulkan", "is_ipu",
+                      "is_xla", "is_maia", "is_mtia", "output_nr", "_version", "_backward_hooks", "retains_grad", "itemsize", "nbytes"}
+    _PASSIVE = {"size", "dim", "stride", "__repr__", "__len__", "numel", "is_contiguous", "__format__", "__str__",
                 "data_ptr", "storage_offset", "is_floating_point", "element_size", "_is_view", "__hash__", "ndimension", "nelement"}
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         name = getattr(func, "__name__", str(func))
-        if name in cls._PASSIVE:
+        if name == "__get__":  # a property: only the ones that describe the tensor (.T / .mT / .data / .real would hand out zeros)
+            prop = getattr(getattr(func, "__self__", None), "__name__", "")
+            if prop in cls._PASSIVE_PROPS:
+                with torch._C.DisableTorchFunctionSubclass():
+                    return func(*args, **(kwargs or {}))
+            name = prop or name
+        elif name in cls._PASSIVE:
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **(kwargs or {}))
         raise RuntimeError(
@@ -261,7 +270,19 @@ def _buffer_key(t):
     in-place write, shared by views).  The cache entries keep the buffer's storage alive, so the caching allocator cannot hand
     its block to a different mesh of the same size while an entry exists -- no device-side fingerprint (and no host
     synchronisation) is needed to trust the address."""
-    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device), t._version)
+    try:
+        ver = t._version
+    except RuntimeError:  # (inference-mode tensors have no version counter)
+        return None
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device), ver)
+
+
+def invalidate_caches():
+    """Forget the cached mesh analyses (edge topology, uv_idx == pos_idx decisions).  The cache key is a buffer's address, layout and
+    autograd version counter: a write that bypasses the counter -- through `.data`, numpy / dlpack views of the same memory, or a
+    raw kernel -- is not seen.  Call this after such a write to an index buffer that stays at the same address."""
+    _topology_cache.clear()
+    _same_index_cache.clear()
 
 
 def build_topology(tri, cached=True):
@@ -269,8 +290,8 @@ def build_topology(tri, cached=True):
     _buffer_key); the first call for a buffer copies it to the host, later calls cost a dictionary lookup."""
     key = None
     if cached:
-        key = _buffer_key(tri)
-        hit = _topology_cache.get(key)
+        key = _buffer_key(tri)  # (None for tensors without a version counter: not cached)
+        hit = _topology_cache.get(key) if key is not None else None
         if hit is not None:
             return hit[1]
     tri_h = np.ascontiguousarray(tri.detach().cpu().numpy().astype(np.int32))
@@ -448,6 +469,8 @@ def _same_indices(a, b):
     if a.data_ptr() == b.data_ptr():
         return True
     key = (_buffer_key(a), _buffer_key(b))
+    if key[0] is None or key[1] is None:  # (no version counter: compare every time)
+        return bool(torch.equal(a, b))
     hit = _same_index_cache.get(key)
     if hit is None:
         if len(_same_index_cache) > 64:
