@@ -45,7 +45,22 @@
 #include <vector>
 #include <cstdio>
 
+#include <roctracer/roctx.h>
+
 #include "raster_dev.h"
+
+// roctx ranges around the runs, iterations and launches of the engine (rocprofv3 --marker-trace): on with
+// DDX_ROCTX=1 in the environment (read once), otherwise a test of a static flag
+static bool ddx_roctx_on()
+{
+    static const int on = [] { const char* v = getenv("DDX_ROCTX"); return (v && atoi(v)) ? 1 : 0; }();
+    return on != 0;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(ddx_roctx_on()) { if (on) roctxRangePushA(name); }
+    ~RoctxRange() { if (on) roctxRangePop(); }
+};
 
 #define NPART 24  // floats per tile partial: 12 dFinal(x,y,w rows) | 4 dMtx row 2 | 4 losses (rgb, depth, mask, edge) | pad
 #define NVALS 20  // of which are used
@@ -53,7 +68,7 @@
 #define NROLE 3  // partial rows per slice: colour + depth, mask, edge -- always three, so that an engine sums in the same order whatever kernels of a group it runs under
 
 #ifndef SCATTER_EXCHANGE_PER_TRI
-#define SCATTER_EXCHANGE_PER_TRI 1.1  // measured crossover: equal at 0.8-1.0 (cfg2 at 2.6-3.4 % coverage), exchange ahead from 1.3
+#define SCATTER_EXCHANGE_PER_TRI 2.0  // measured crossover with the meshlet vertices in LDS (round 3): plain ahead at 1.4 (cfg2 at 4.7 % coverage: 12.7 k vs 12.2 k it/s), the hybrid at 3.1 (10.7 %: 7.6 k vs 6.7 k)
 #endif
 
 struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_status_ptr exposes
@@ -1811,6 +1826,7 @@ static int step_capacity(ddx_engine* e)
 
 static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
 {
+    RoctxRange rr("ddx.step_kernel");
     EngineDev& E = e->dev;
     // slots (workgroups) per hypothesis: every workgroup the same number of meshlets, all of them resident -- a second round of
     // workgroups would pay the head's chain again -- and at least a few, because the slots also share the re-arm of the tiles the
@@ -1836,16 +1852,23 @@ static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
     if (ev) DDX_HIP(hipEventRecord(ev[K_BIG], s));
-    big_pass_kernel<<<BIG_GRID, BIG_WAVES * 64, 0, s>>>(E, it);
+    {
+        RoctxRange rr("ddx.big_pass_kernel");
+        big_pass_kernel<<<BIG_GRID, BIG_WAVES * 64, 0, s>>>(E, it);
+    }
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
     {
+        RoctxRange rr("ddx.shade_kernel");
         dim3 g = shade_grid(d);
         g.z = E.n_roles;
         if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E, it);
         else shade_kernel<false><<<g, 256, 0, s>>>(E, it);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
-    if (d.use_edge) edge_kernel<<<edge_grid(d), 256, 0, s>>>(E, it);
+    if (d.use_edge) {
+        RoctxRange rr("ddx.edge_kernel");
+        edge_kernel<<<edge_grid(d), 256, 0, s>>>(E, it);
+    }
     if (ev) DDX_HIP(hipEventRecord(ev[K_FINISH], s));
     DDX_LAUNCH_CHECK();
     return 0;
@@ -1853,6 +1876,7 @@ static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K
 
 static int launch_finish(ddx_engine* e, int it /* the iteration after the last one drawn */, hipStream_t s)
 {
+    RoctxRange rr("ddx.finish_kernel");
     EngineDev& E = e->dev;
     const dim3 g(upd_slices(E.d), E.d.B);
     finish_kernel<<<g, 256, 0, s>>>(E, it);
@@ -1862,6 +1886,7 @@ static int launch_finish(ddx_engine* e, int it /* the iteration after the last o
 
 static int run_iteration(ddx_engine* e, int it, hipStream_t s)  // one iteration after the first of a run (it = -1: for a graph)
 {
+    RoctxRange rr("ddx.iteration");
     if (int err = launch_step(e, STEP_NORMAL, it, s)) return err;
     return launch_rest(e, it, s, nullptr);
 }
@@ -2315,6 +2340,7 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
     if (!e->setup_done)
         if (int err = engine_setup(e, s)) return err;
     if (n == 0) return 0;
+    RoctxRange rr("ddx_engine_run");
     if (int err = run_prologue(e, it0, s)) return err;
     // iteration it0 is drawn from the caller's parameters; each later step_kernel first steps the optimiser for the iteration
     // before it; finish_kernel steps it for the last one
@@ -2660,6 +2686,7 @@ extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* s
         }
     }
     if (n == 0) return 0;
+    RoctxRange rr("ddx_engine_group_run");
     for (auto* e : g->members)
         if (int err = run_prologue(e, it0, s)) return err;
     if (fresh) {  // (set-up fills fields of EngineDev: meshlet count, culling sign, scatter variant, bounding box, seg list size)
