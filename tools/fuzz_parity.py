@@ -219,7 +219,14 @@ def sweep_soups(n_cases=200, seed0=0, verbose=True):
                 out.backward(T(go))
                 dcol, dpos = orc.antialias_bwd(col, ref, pos, tri, go)
                 ok &= bool(np.abs(c_t.grad.cpu().numpy() - dcol).max() < 2e-4)
-                ok &= bool(np.abs(p_t.grad.cpu().numpy() - dpos).max() <= 1e-2 * max(np.abs(dpos).max(), 1e-6))
+                dpe = np.abs(p_t.grad.cpu().numpy() - dpos).max()
+                if dpe > 1e-2 * max(np.abs(dpos).max(), 1e-6):
+                    # a vertex at w ~ 1e-5 turns the 1/w^2 of the w-gradient into a conditioning problem of the float32
+                    # arithmetic itself (seed 961292: the float32 oracle is 2.07 from its own float64 run, the kernel 0.69): the
+                    # referee is then the float64 oracle, and the kernel may be as far from it as the float32 oracle is
+                    d64 = orc.antialias_bwd(col.astype(np.float64), ref.astype(np.float64), pos.astype(np.float64), tri, go.astype(np.float64))[1]
+                    ok &= bool(np.abs(p_t.grad.cpu().numpy() - d64).max() <= max(1e-2 * np.abs(d64).max(), 1.5 * np.abs(dpos - d64).max()))
+                    stats["f64_referee"] = stats.get("f64_referee", 0) + 1
                 attr = rng.normal(size=(B, nv, 3)).astype(np.float32)
                 a_t, r_t = T(attr, requires_grad=True), rd.clone().requires_grad_(True)
                 io, _ = dd.interpolate(a_t, r_t, tri_t)
@@ -549,7 +556,12 @@ def sweep_api(n_cases=60, seed0=0, verbose=True):
         B = int(rng.randint(1, 7))
         losses = [k for k in ("rgb", "depth", "mask", "edge") if rng.rand() < 0.6] or ["mask"]
         sc = make_scene(rows, cols, H, W, B=1, dist=float(rng.uniform(1.3, 5.0)), seed=seed0 + case, rot_deg=float(rng.uniform(1, 12)), trans=float(rng.uniform(0, 0.05)))
-        tag = f"api case {case} seed {seed0 + case}: mesh {rows}x{cols} frame {H}x{W} B {B} {losses}"
+        # even cases: the engine draws both faces like the op-by-op path (same visibility rule: the kernels are what is compared,
+        # tight); odd cases: the engine's default, back faces of the closed mesh culled (deviation D5) -- equal in exact arithmetic,
+        # but a sliver at a pole of the blob can win a pixel through its extrapolated depth (seed 940228: 600 triangles on 149
+        # pixels, one pixel changes owner, the Sobel term moves by 0.4 %): loose
+        cull = bool(case % 2)
+        tag = f"api case {case} seed {seed0 + case}: mesh {rows}x{cols} frame {H}x{W} B {B} {losses} cull {cull}"
         try:
             def make():
                 mesh = dd.Mesh.from_arrays(sc["pos"], sc["tri"], uv=sc["uv"], tex=sc["tex"])
@@ -561,7 +573,8 @@ def sweep_api(n_cases=60, seed0=0, verbose=True):
                 cam.cam_proj = torch.tensor(sc["proj"], dtype=torch.float64)
                 cfg = dict(losses=dict(l1_rgb_with_mask="rgb" in losses, weight_rgb=0.7, l1_depth_with_mask="depth" in losses, weight_depth=1.0,
                                        l1_mask="mask" in losses, weight_mask=1.0, l1_edge="edge" in losses, weight_edge=0.6),
-                           hyperparameters=dict(nb_iterations=3, batchsize=B, base_lr=0.05, learning_rates_bound=[0.5, 2.0], learning_rate_base=1, lr_decay=0.1, seed=3))
+                           hyperparameters=dict(nb_iterations=3, batchsize=B, base_lr=0.05, learning_rates_bound=[0.5, 2.0], learning_rate_base=1, lr_decay=0.1, seed=3,
+                                                cull_backfaces=cull))
                 return dd.DiffDope(cfg=cfg, camera=cam, object3d=obj, scene=scene)
             a, b = make(), make()
             a.run_optimization(fused=True)
@@ -571,7 +584,7 @@ def sweep_api(n_cases=60, seed0=0, verbose=True):
                 la, lb = a.losses_values[k].numpy(), b.losses_values[k].numpy()
                 d0 = float(np.abs(la[0] - lb[0]).max() / max(np.abs(lb[0]).max(), 1e-6))
                 stats["max_first_loss_diff"] = max(stats["max_first_loss_diff"], d0)
-                ok &= d0 < 2e-3
+                ok &= d0 < (1e-2 if cull else 2e-3)
             pa, pb = a.object3d.params_tensor().cpu().numpy(), b.object3d.params_tensor().cpu().numpy()
             dp = float(np.abs(pa - pb).max())
             stats["max_param_diff"] = max(stats["max_param_diff"], dp)
