@@ -566,6 +566,19 @@ struct AAUnit {
     float C[12];    // d(final rows x,y,w) per unit d alpha (zero if clamped)
 };
 
+// silhouette flags (bit k = edge k) of a triangle cut by the eye plane; out of line and with its own loads (L2 hits): the rare path
+// must not cost the mask role registers
+__device__ __attribute__((noinline)) static int aa_sil_straddler(const float* __restrict__ P, int v0, int v1, int v2, int o0, int o1, int o2)
+{
+    const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
+    const float D = aa_det3_xyw(p0, p1, p2);
+    int m = 7;
+    if (o0 >= 0) { const float4 q = ld4(P + (size_t)o0 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p1, p2)) != sign_bit(D)) m &= ~1; }
+    if (o1 >= 0) { const float4 q = ld4(P + (size_t)o1 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p2, p0)) != sign_bit(D)) m &= ~2; }
+    if (o2 >= 0) { const float4 q = ld4(P + (size_t)o2 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p0, p1)) != sign_bit(D)) m &= ~4; }
+    return m;
+}
+
 __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const int4* __restrict__ rec, const float* __restrict__ pos,
                                              int H, int W, int px, int py, int d, int t0, int t1, AAUnit& o)
 {
@@ -594,30 +607,40 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
         ps[i][0] = pos[(size_t)vi[i] * 3 + 0]; ps[i][1] = pos[(size_t)vi[i] * 3 + 1]; ps[i][2] = pos[(size_t)vi[i] * 3 + 2];
     }
     float x[3], y[3], ox[3], oy[3], iw[3];
+    bool behind[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (!(p[i].w > 0.f)) return;
-        iw[i] = __fdiv_rn(1.0f, p[i].w);
-        x[i] = __fmaf_rn(p[i].x * iw[i], hw, -fx);
+        behind[i] = !(p[i].w > 0.f);
+        iw[i] = behind[i] ? 0.f : __fdiv_rn(1.0f, p[i].w);
+        x[i] = __fmaf_rn(p[i].x * iw[i], hw, -fx);  // (unused for a vertex behind the eye plane)
         y[i] = __fmaf_rn(p[i].y * iw[i], hh, -fy);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        ox[k] = x[k]; oy[k] = y[k];
-        if (ov[k] >= 0 && q[k].w > 0.f) {
-            const float iwq = __fdiv_rn(1.0f, q[k].w);
-            ox[k] = __fmaf_rn(q[k].x * iwq, hw, -fx);
-            oy[k] = __fmaf_rn(q[k].y * iwq, hh, -fy);
-        }
-    }
-    const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
-    float aw[3];
-    aw[0] = (x[1] - ox[0]) * (y[2] - oy[0]) - (x[2] - ox[0]) * (y[1] - oy[0]);
-    aw[1] = (x[2] - ox[1]) * (y[0] - oy[1]) - (x[0] - ox[1]) * (y[2] - oy[1]);
-    aw[2] = (x[0] - ox[2]) * (y[1] - oy[2]) - (x[1] - ox[2]) * (y[0] - oy[2]);
+    const bool straddler = behind[0] || behind[1] || behind[2];
+    if (behind[0] && behind[1] && behind[2]) return;
     bool sil[3];
+    if (!straddler) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) sil[k] = sign_bit(aw[k]) == sign_bit(bb);
+        for (int k = 0; k < 3; ++k) {
+            ox[k] = x[k]; oy[k] = y[k];
+            if (ov[k] >= 0 && q[k].w > 0.f) {
+                const float iwq = __fdiv_rn(1.0f, q[k].w);
+                ox[k] = __fmaf_rn(q[k].x * iwq, hw, -fx);
+                oy[k] = __fmaf_rn(q[k].y * iwq, hh, -fy);
+            }
+        }
+        const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+        float aw[3];
+        aw[0] = (x[1] - ox[0]) * (y[2] - oy[0]) - (x[2] - ox[0]) * (y[1] - oy[0]);
+        aw[1] = (x[2] - ox[1]) * (y[0] - oy[1]) - (x[0] - ox[1]) * (y[2] - oy[1]);
+        aw[2] = (x[0] - ox[2]) * (y[1] - oy[2]) - (x[1] - ox[2]) * (y[0] - oy[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sil[k] = sign_bit(aw[k]) == sign_bit(bb);
+    } else {
+        // a triangle cut by the eye plane (oracle aa_eval_pair, raster_math.h aa_eval_pair): homogeneous orientation tests; only
+        // the edges with both endpoints in front can be the crossed edge
+        const int m = aa_sil_straddler(P, vi[0], vi[1], vi[2], ov[0], ov[1], ov[2]);
+        sil[0] = (m & 1) != 0; sil[1] = (m & 2) != 0; sil[2] = (m & 4) != 0;
+    }
     if (!(sil[0] || sil[1] || sil[2])) return;
     if (d) {
 #pragma unroll
@@ -628,6 +651,7 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int ia = (k + 1) % 3, ib = (k + 2) % 3;
+        if (behind[ia] || behind[ib]) continue;
         if (sign_bit(y[ia]) == sign_bit(y[ib])) continue;
         const float dx = x[ib] - x[ia], dy = y[ib] - y[ia];
         const float r = ds * __fdiv_rn(x[ia] * dy - y[ia] * dx, dy);

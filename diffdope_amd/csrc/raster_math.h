@@ -273,6 +273,16 @@ struct AAPair {
 
 __device__ __forceinline__ bool sign_bit(float x) { return (__float_as_uint(x) >> 31) != 0; }
 
+// det of the (x, y, w) rows of three clip-space points, in the oracle's operation order (aa_det3_xyw there): its sign is the
+// orientation of the projections wherever those exist
+__device__ __forceinline__ float aa_det3_xyw(const float4& a, const float4& b, const float4& c)
+{
+    const float m0 = b.y * c.w - c.y * b.w;
+    const float m1 = b.x * c.w - c.x * b.w;
+    const float m2 = b.x * c.y - c.x * b.y;
+    return (a.x * m0 - a.y * m1) + a.w * m2;
+}
+
 // Analyse the pixel pair (px,py)-(px+1,py) [d=0] or (px,py)-(px,py+1) [d=1] given the triangle ids
 // (0-based, -1 = background) and z/w of both pixels.  P = clip positions [V,4] of this hypothesis.
 __device__ __forceinline__ void aa_eval_pair(const float* __restrict__ P, const int* __restrict__ tri,
@@ -291,35 +301,58 @@ __device__ __forceinline__ void aa_eval_pair(const float* __restrict__ P, const 
     const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
     const float fx = (float)cx + 0.5f - hw, fy = (float)cy + 0.5f - hh;
     float x[3], y[3], ox[3], oy[3];
+    float4 pv[3];
+    bool behind[3];
+    int nbehind = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float4 p = ld4(P + (size_t)vi[i] * 4);
-        if (!(p.w > 0.f)) return;
-        const float iw = __fdiv_rn(1.0f, p.w);
-        x[i] = __fmaf_rn(p.x * iw, hw, -fx);
-        y[i] = __fmaf_rn(p.y * iw, hh, -fy);
+        pv[i] = ld4(P + (size_t)vi[i] * 4);
+        behind[i] = !(pv[i].w > 0.f);
+        nbehind += behind[i] ? 1 : 0;
+        x[i] = 0.f; y[i] = 0.f;
+        if (!behind[i]) {
+            const float iw = __fdiv_rn(1.0f, pv[i].w);
+            x[i] = __fmaf_rn(pv[i].x * iw, hw, -fx);
+            y[i] = __fmaf_rn(pv[i].y * iw, hh, -fy);
+        }
     }
+    if (nbehind == 3) return;
+    bool sil[3];
+    if (nbehind == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int ov = opp[t * 3 + k];
-        ox[k] = x[k]; oy[k] = y[k];
-        if (ov >= 0) {
-            const float4 p = ld4(P + (size_t)ov * 4);
-            if (p.w > 0.f) {
-                const float iw = __fdiv_rn(1.0f, p.w);
-                ox[k] = __fmaf_rn(p.x * iw, hw, -fx);
-                oy[k] = __fmaf_rn(p.y * iw, hh, -fy);
+        for (int k = 0; k < 3; ++k) {
+            const int ov = opp[t * 3 + k];
+            ox[k] = x[k]; oy[k] = y[k];
+            if (ov >= 0) {
+                const float4 p = ld4(P + (size_t)ov * 4);
+                if (p.w > 0.f) {
+                    const float iw = __fdiv_rn(1.0f, p.w);
+                    ox[k] = __fmaf_rn(p.x * iw, hw, -fx);
+                    oy[k] = __fmaf_rn(p.y * iw, hh, -fy);
+                }
+            }
+        }
+        const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+        float aw[3];
+        aw[0] = (x[1] - ox[0]) * (y[2] - oy[0]) - (x[2] - ox[0]) * (y[1] - oy[0]);
+        aw[1] = (x[2] - ox[1]) * (y[0] - oy[1]) - (x[0] - ox[1]) * (y[2] - oy[1]);
+        aw[2] = (x[0] - ox[2]) * (y[1] - oy[2]) - (x[1] - ox[2]) * (y[0] - oy[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sil[k] = sign_bit(aw[k]) == sign_bit(bb);
+    } else {
+        // a triangle cut by the eye plane (oracle aa_eval_pair): orientation tests in homogeneous form, and only the edges with both
+        // endpoints in front of the eye plane can be the crossed edge (below)
+        const float D = aa_det3_xyw(pv[0], pv[1], pv[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int ov = opp[t * 3 + k];
+            sil[k] = true;
+            if (ov >= 0) {
+                const float4 q = ld4(P + (size_t)ov * 4);
+                if (q.w > 0.f) sil[k] = sign_bit(aa_det3_xyw(q, pv[(k + 1) % 3], pv[(k + 2) % 3])) == sign_bit(D);
             }
         }
     }
-    const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
-    float aw[3];
-    aw[0] = (x[1] - ox[0]) * (y[2] - oy[0]) - (x[2] - ox[0]) * (y[1] - oy[0]);
-    aw[1] = (x[2] - ox[1]) * (y[0] - oy[1]) - (x[0] - ox[1]) * (y[2] - oy[1]);
-    aw[2] = (x[0] - ox[2]) * (y[1] - oy[2]) - (x[1] - ox[2]) * (y[0] - oy[2]);
-    bool sil[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sil[k] = sign_bit(aw[k]) == sign_bit(bb);
     if (!(sil[0] || sil[1] || sil[2])) return;
     if (d) {
 #pragma unroll
@@ -330,6 +363,7 @@ __device__ __forceinline__ void aa_eval_pair(const float* __restrict__ P, const 
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int ia = (k + 1) % 3, ib = (k + 2) % 3;
+        if (behind[ia] || behind[ib]) continue;
         if (sign_bit(y[ia]) == sign_bit(y[ib])) continue;
         const float dx = x[ib] - x[ia], dy = y[ib] - y[ia];
         const float r = ds * __fdiv_rn(x[ia] * dy - y[ia] * dx, dy);

@@ -3,7 +3,8 @@ un-vendored and un-pinned).  Each test states, for a hand-built case,
 yields and what this build yields, so the size and the trigger of every deviation is on record.  CPU only (the HIP
 kernels are held to this oracle bit-for-bit / to tolerance by the -m gpu tests).
 
-  D1  (closed in round 2) a triangle with a vertex at clip w <= 0 was dropped; it is now clipped at the near plane as GL does
+  D1  (closed in round 2) a triangle with a vertex at clip w <= 0 was dropped; it is now clipped at the near plane as GL does;
+      (round 3) its fully visible silhouette edges are antialiased, the edges that run through the eye plane are not
   D2  rasterize backward: a barycentric saturated by the [0,1] clamp passes no gradient, nvdiffrast differentiates
       the unclamped expression
   D3  antialias: of two triangle edges that cross the pixel-pair segment the one with the LARGER crossing parameter is
@@ -97,6 +98,62 @@ def test_d1_pose_gradient_when_part_of_a_mesh_crosses_the_camera_plane():
         pm[i, 0] -= eps
         fd = (R.loss_and_grad(pp, np.ones(1), want_grad=False)[0] - R.loss_and_grad(pm, np.ones(1), want_grad=False)[0]) / (2 * eps)
         assert abs(fd - g[i, 0]) < 1e-4 * max(1.0, abs(fd)), (i, fd, g[i, 0])
+
+
+def _straddling_quad():
+    """Two triangles sharing the edge (0, 2); vertex 2 lies BEHIND the eye plane (w < 0).  Generic coordinates: no edge passes
+    through a pixel centre."""
+    pos = np.array([[[-0.6137, -0.5219, 0.2, 1.013], [0.5531, -0.4473, 0.1, 0.917], [0.2071, 0.9113, -0.3, -0.4219], [-0.9043, 0.6171, 0.3, 1.2331]]])
+    tri = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    return pos, tri
+
+
+def test_d1_antialias_on_the_visible_edges_of_a_triangle_cut_by_the_camera_plane():
+    """Round 3 (what was left of D1): the pair analysis used to return early for a triangle with a vertex at w <= 0, so a
+    hypothesis cut by the camera plane got no silhouette blend / gradient on those triangles.  Now the orientation tests are done in
+    homogeneous form (sign of det[x y w]) and every edge with BOTH endpoints in front of the eye plane is analysed as usual; an
+    edge that itself crosses the eye plane, and the cut, are not antialiased.  Known answers: blended pixels exist along the two
+    fully visible silhouette edges (0,1) and (3,0), none along the cut edges; the vertex behind the plane gets no gradient; the
+    gradient is the derivative (float64 finite differences, rast held fixed)."""
+    H, W = 48, 64
+    pos, tri = _straddling_quad()
+    rast = orc.rasterize_fwd(pos, tri, H, W)
+    ids = rast[0, ..., 3]
+    assert (ids == 1).sum() > 500 and (ids == 2).sum() > 20  # both clipped triangles are drawn
+    col = (ids > 0).astype(np.float64)[None, ..., None].repeat(3, -1)
+    out = orc.antialias_fwd(col, rast, pos, tri)
+    changed = np.abs(out - col)[0, ..., 0] > 1e-9
+    assert changed.sum() >= 20
+    # every blended pixel lies within a pixel of the projected edge (0,1) or (3,0)
+    px = lambda v: ((pos[0, v, 0] / pos[0, v, 3] * 0.5 + 0.5) * W, (pos[0, v, 1] / pos[0, v, 3] * 0.5 + 0.5) * H)
+    def dist_to_segment(x, y, a, b):
+        a, b, q = np.array(px(a)), np.array(px(b)), np.array([x + 0.5, y + 0.5])
+        t = np.clip(np.dot(q - a, b - a) / np.dot(b - a, b - a), 0, 1)
+        return np.linalg.norm(q - (a + t * (b - a)))
+    for y, x in np.argwhere(changed):
+        assert min(dist_to_segment(x, y, 0, 1), dist_to_segment(x, y, 3, 0)) < 1.5
+    rng = np.random.RandomState(0)
+    G = rng.normal(size=out.shape)
+    _, dpos = orc.antialias_bwd(col, rast, pos, tri, G)
+    assert np.all(dpos[0, 2] == 0) and np.abs(dpos[0, [0, 1, 3]]).max() > 1
+    f = lambda q: float((orc.antialias_fwd(col, rast, q, tri) * G).sum())
+    checked = 0
+    for v in (0, 1, 3):
+        for c in (0, 1, 3):
+            def fd(eps):
+                a, b = pos.copy(), pos.copy()
+                a[0, v, c] += eps
+                b[0, v, c] -= eps
+                return (f(a) - f(b)) / (2 * eps)
+            n1, n2 = fd(1e-7), fd(1e-8)
+            if abs(n1 - n2) > 1e-4 * max(1, abs(n1)):
+                continue
+            assert abs(dpos[0, v, c] - n1) < 1e-5 * max(1, abs(n1))
+            checked += 1
+    assert checked >= 8
+    # float32 and float64 take the same discrete decisions on this case
+    o32 = orc.antialias_fwd(col.astype(np.float32), rast.astype(np.float32), pos.astype(np.float32), tri)
+    assert np.abs(o32 - out).max() < 1e-5
 
 
 def test_d2_saturated_barycentric_passes_no_gradient():
