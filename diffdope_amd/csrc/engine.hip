@@ -129,6 +129,15 @@ struct EngineDev {
     int2* mtri;       // [M, mesh_ntri] (l0 | l1 << 10 | l2 << 20 local vertex slots, original triangle id or -1 for an unused slot)
     int n_meshlets, mesh_ntri, mesh_nvc;
     unsigned long long* trace;  // DDX_TRACE=1: [3 kernels][TRACE_WG workgroups][8] s_memrealtime stamps of thread 0 (tools/trace_kernels.py), else null
+    // Which meshlets a slot (workgroup of a hypothesis) draws.  slot_table = 0: equal contiguous shares of the interleaved order.
+    // 1: slot s draws slot_items[slot_off[s] .. + slot_cnt[s]) -- shares balanced on the host from MEASURED per-meshlet times (mcost,
+    // recorded by the first step launch after a set-up) and from the speed of the slot's place in the dispatch order (launch_step).
+    int slot_table;
+    unsigned char slot_cnt[64];
+    unsigned short slot_off[64];
+    unsigned short slot_items[192];
+    unsigned short* mcost;      // [B, M] ticks (10 ns) a workgroup spent on meshlet m of hypothesis b
+    int mcost_rec;              // this launch records mcost
     int step_xcd;     // step_kernel grid: 0 = (slots, B); 1 = (B, slots): all workgroups of hypothesis b on XCD b % 8 (observed placement)
     int scatter_mode; // scatter_resolve MODE of the dense variant: 0 plain, 2 hybrid, 3 compacting (the small-mesh variant is MODE 1)
     // Back-face culling for CLOSED meshes (deviation D5).  A closed, consistently oriented surface that lies
@@ -177,6 +186,9 @@ struct ddx_engine {
     bool setup_done = false;
     bool mesh_done = false;  // the mesh half of the setup (sorted copies, meshlets, triangle / texel records, closedness) survives ddx_engine_new_observation
     int step_resident = 0;     // step_kernel workgroups the chip holds at once (step_capacity, asked once); DDX_STEP_RESIDENT overrides
+    int balance = 1;           // balanced shares of the meshlets (balance_slots); DDX_STEP_BALANCE=0: equal shares
+    bool balanced = false;     // the table of this set-up exists
+    int balance_min_per_slot = 4;  // DDX_STEP_BALANCE_MIN
     bool small_mesh = false; // step_kernel variant: one triangle per lane in 64-thread workgroups (few triangles x hypotheses)
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
@@ -257,6 +269,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_vold = carve((size_t)d.V * sizeof(int));
     const size_t o_part = carve((size_t)d.B * 64 * MAX_ROLES * NPART * sizeof(float));  // per (slice <= 64, role)
     const size_t o_edge = carve(d.use_edge ? (size_t)d.H * d.W * sizeof(float2) : 0);
+    const size_t o_mcost = carve((size_t)d.B * Mmax * sizeof(unsigned short));
     const size_t o_lum = carve(d.use_edge ? (size_t)d.B * d.H * d.W * sizeof(float) : 0);
     const size_t o_ubuf = carve(d.use_edge ? (size_t)d.B * d.H * d.W * 12 * sizeof(float) : 0);
     const size_t o_rast = carve(0);
@@ -289,6 +302,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.vold = (int*)(p + o_vold);
     E.partials = (float*)(p + o_part);
     E.gtedge = d.use_edge ? (float2*)(p + o_edge) : nullptr;
+    E.mcost = (unsigned short*)(p + o_mcost);
     E.lumbuf = d.use_edge ? (float*)(p + o_lum) : nullptr;
     E.ubuf = d.use_edge ? (float*)(p + o_ubuf) : nullptr;
     return off;
@@ -1563,7 +1577,7 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
 // The chain of one iteration used to be four launches (transform+update, scatter, compaction, shade) with the clip-space
 // vertices and their window snap travelling through HBM in between; here the optimiser step, the transform and the scatter
 // rasteriser are one workgroup-local pipeline and the compaction is gone (shade_kernel scans the flags itself).
-template <int TPL, int NTH, int MODE>
+template <int TPL, int NTH, int MODE, bool TAB = false /* balanced shares: the slot's meshlets come from the table, and the launch may record their times */>
 __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int SL, int mode, int it_arg)
 {
     constexpr int NTRI = TPL * NTH, NVC = 2 * NTH;
@@ -1591,7 +1605,14 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     // per-hypothesis ticket counter instead was built and measured: 64 hot words of returning device-scope atomics made every
     // workgroup slower -- head 5.1 -> 9.4 us, cfg2 44.4 -> 54 us per iteration.)
     const int npw = (M + SL - 1) / SL, m_begin = slot * npw, m_end = min(M, m_begin + npw);
-    const int m0 = min(m_begin, M - 1);  // (a slot beyond the meshlets only shares the head's re-arm work; the loop below is empty for it)
+    const bool tabled = TAB && E.slot_table != 0;
+    const int n_my = tabled ? (int)E.slot_cnt[slot] : max(0, m_end - m_begin), t_off = tabled ? (int)E.slot_off[slot] : 0;
+    // (the slot's list goes to LDS once: indexing the kernel arguments inside the meshlet loop would put a scalar load and its wait,
+    // which also waits for the LDS traffic, into every trip)
+    __shared__ unsigned short s_items[TAB ? 64 : 1];
+    if (tabled && tid < min(n_my, 64)) s_items[tid] = E.slot_items[t_off + tid];  // (visible after the barrier of the head / first-iteration branch)
+    auto meshlet_of = [&](int k) { return tabled ? (int)s_items[k] : m_begin + k; };
+    const int m0 = n_my > 0 ? (tabled ? (int)E.slot_items[t_off] : m_begin) : M - 1;  // (a slot without meshlets only shares the head's re-arm work)
 #pragma unroll
     for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)m0 * NVC + u * NTH + tid];
 #pragma unroll
@@ -1669,7 +1690,10 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     tg.ntx = E.L.ntx; tg.nty = E.L.nty; tg.NT = E.L.NT; tg.zwb = E.L.zwb;
     tg.ndc = E.L.ndc;
     STAMP(E, 0, wg_id, 2);
-    for (int m = m_begin; m < m_end; ++m) {  // (workgroup-uniform)
+    const bool rec = TAB && E.mcost_rec != 0;
+    unsigned long long t_m = rec ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    for (int mk = 0; mk < n_my; ++mk) {  // (workgroup-uniform)
+        const int m = meshlet_of(mk);
         // ---- the meshlet's vertices on the matrix core -> LDS (clip + 1/256-pixel window snap); the owner of a vertex also
         // stores it for the antialias pass and the tile pass
 #pragma unroll
@@ -1699,16 +1723,22 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
             va[k] = s_snap[i0[k]]; vb[k] = s_snap[i1[k]]; vc[k] = s_snap[i2[k]];
         }
         // the next meshlet of this workgroup is requested now and lands while this one is rasterised
-        if (m + 1 < m_end) {
+        if (mk + 1 < n_my) {
+            const int mn = meshlet_of(mk + 1);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)(m + 1) * NVC + u * NTH + tid];
+            for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)mn * NVC + u * NTH + tid];
 #pragma unroll
-            for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)(m + 1) * NTRI + k * NTH + tid];
+            for (int q = 0; q < TPL; ++q) tr[q] = E.mtri[(size_t)mn * NTRI + q * NTH + tid];
         }
-        STAMP(E, 0, wg_id, m == m_begin ? 3 : 5);
+        STAMP(E, 0, wg_id, mk == 0 ? 3 : 5);
         scatter_resolve<TPL, NTH, MODE>(tg, d.H, d.W, d.T, t, i0, i1, i2, ok, va, vb, vc, cull);
-        STAMP(E, 0, wg_id, m == m_begin ? 4 : 6);
+        STAMP(E, 0, wg_id, mk == 0 ? 4 : 6);
         __syncthreads();  // (s_clip / s_snap are rewritten by the next meshlet)
+        if (rec) {  // (set-up's calibration launch only)
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) E.mcost[(size_t)b * M + m] = (unsigned short)min(65535ull, now - t_m);
+            t_m = now;
+        }
     }
     STAMP(E, 0, wg_id, 7);
 }
@@ -1717,10 +1747,12 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
 #define STEP_MIN_WAVES 6  // waves per SIMD step_kernel is compiled for (<= 80 registers): 1536 resident 256-thread workgroups
 #endif
 // grid (slots, B), or (B, slots) with E.step_xcd
-template <int TPL, int NTH, int MODE>
+template <int TPL, int NTH, int MODE, bool TAB = false>
 __global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, int mode, int it_arg)
 {
-    step_wg<TPL, NTH, MODE>(E, E.step_xcd ? blockIdx.x : blockIdx.y, E.step_xcd ? blockIdx.y : blockIdx.x, E.step_xcd ? gridDim.y : gridDim.x, mode, it_arg);
+    // (TAB: always the slot-major grid (B, slots))
+    if (TAB) step_wg<TPL, NTH, MODE, true>(E, blockIdx.x, blockIdx.y, gridDim.y, mode, it_arg);
+    else step_wg<TPL, NTH, MODE, false>(E, E.step_xcd ? blockIdx.x : blockIdx.y, E.step_xcd ? blockIdx.y : blockIdx.x, E.step_xcd ? gridDim.y : gridDim.x, mode, it_arg);
 }
 
 // group form: grid (largest slot count, sum of the members' hypotheses)
@@ -1848,6 +1880,75 @@ static int step_capacity(ddx_engine* e)
     return per_cu * cus;
 }
 
+// BALANCED SHARES.  The launch ends with its slowest workgroup, and per-workgroup stamps show two things a static equal split
+// cannot know: a meshlet costs 0.5 us when the pose culls it and up to 6 us when it faces the camera, and the 4th / 5th workgroup
+// dispatched to a CU run at about 0.8x / 0.5x the speed of the first three, from their first instruction on (it follows the
+// dispatch order: with the slot-major grid, slot s holds the block ids [s B, (s + 1) B), i.e. the (s B / CUs)-th workgroup of
+// each CU).  So the first step launch after a set-up records what each meshlet cost each hypothesis (mcost: s_memrealtime
+// ticks of the workgroup that drew it), the host reads them back once -- the set-up has synchronised the stream anyway --,
+// averages over the hypotheses, removes the speed of the slot that measured, and hands the meshlets to the slots longest first,
+// each to the slot that would finish it earliest given its speed and its later start (LPT).  The table travels in the kernel
+// arguments.  Which workgroup draws a meshlet does not change a bit of the result (atomicMin, owner stores, idempotent flags).
+static double slot_speed(int slot, int B, int cus, double* head_ticks)
+{
+    const int rank = (int)(((long long)slot * B) / cus);
+    static const double v3 = getenv("DDX_BAL_V3") ? atof(getenv("DDX_BAL_V3")) : 0.8, v4 = getenv("DDX_BAL_V4") ? atof(getenv("DDX_BAL_V4")) : 0.5,
+                        v5 = getenv("DDX_BAL_V5") ? atof(getenv("DDX_BAL_V5")) : 0.4;  // (tuning)
+    *head_ticks = rank <= 2 ? 0.0 : (rank == 3 ? 110.0 : 300.0);
+    return rank <= 2 ? 1.0 : (rank == 3 ? v3 : (rank == 4 ? v4 : v5));
+}
+
+static int balance_slots(ddx_engine* e, int SL, hipStream_t s)
+{
+    EngineDev& E = e->dev;
+    const int M = E.n_meshlets, B = E.d.B;
+    std::vector<unsigned short> h((size_t)B * M);
+    DDX_HIP(hipMemcpyAsync(h.data(), E.mcost, h.size() * sizeof(unsigned short), hipMemcpyDeviceToHost, s));
+    DDX_HIP(hipStreamSynchronize(s));
+    int cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const int npw = (M + SL - 1) / SL;
+    std::vector<double> cost((size_t)M, 0.0);
+    for (int m = 0; m < M; ++m) {
+        double sum = 0.0;
+        for (int b = 0; b < B; ++b) sum += (double)h[(size_t)b * M + m];
+        double ht;
+        cost[(size_t)m] = std::max(1.0, sum / B * slot_speed(m / npw, B, cus, &ht));  // (measured by slot m / npw of the equal split)
+    }
+    std::vector<int> order((size_t)M);
+    for (int m = 0; m < M; ++m) order[(size_t)m] = m;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return cost[(size_t)a] > cost[(size_t)b2]; });
+    std::vector<double> load((size_t)SL), speed((size_t)SL);
+    std::vector<std::vector<int>> items((size_t)SL);
+    for (int sl = 0; sl < SL; ++sl) { double ht; speed[(size_t)sl] = slot_speed(sl, B, cus, &ht); load[(size_t)sl] = ht; }
+    for (int m : order) {
+        int best = 0;
+        double fbest = 1e300;
+        for (int sl = 0; sl < SL; ++sl) {
+            const double f = load[(size_t)sl] + cost[(size_t)m] / speed[(size_t)sl];
+            if (f < fbest) { fbest = f; best = sl; }
+        }
+        load[(size_t)best] = fbest;
+        items[(size_t)best].push_back(m);
+    }
+    int off = 0;
+    for (int sl = 0; sl < SL; ++sl) {
+        if (items[(size_t)sl].size() > 64) return 0;  // (the kernel keeps a slot's list in 64 LDS entries: keep the equal split)
+        E.slot_off[sl] = (unsigned short)off;
+        E.slot_cnt[sl] = (unsigned char)items[(size_t)sl].size();
+        for (int m : items[(size_t)sl]) E.slot_items[off++] = (unsigned short)m;
+    }
+    E.slot_table = 1;
+    e->balanced = true;
+    if (getenv("DDX_DEBUG_BALANCE")) {
+        fprintf(stderr, "ddx balance: M %d SL %d |", M, SL);
+        for (int sl = 0; sl < SL; ++sl) fprintf(stderr, " %d:%d(%.0f)", sl, (int)E.slot_cnt[sl], load[(size_t)sl]);
+        fprintf(stderr, "\n");
+    }
+    return 0;
+}
+
 static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
 {
     RoctxRange rr("ddx.step_kernel");
@@ -1859,14 +1960,29 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
     int SL = std::max(1, std::min(E.n_meshlets, e->step_resident / E.d.B));
     SL = ddx_cdiv(E.n_meshlets, ddx_cdiv(E.n_meshlets, SL));  // (npw = ceil(M / SL) meshlets each; step_kernel computes the same npw)
     SL = std::max(SL, std::min(UPD_SLICES, std::max(1, e->step_resident / E.d.B)));
-    const dim3 g = E.step_xcd ? dim3(E.d.B, SL) : dim3(SL, E.d.B);
+    // balanced shares (slot table): the first step launch after a set-up runs with equal shares and records what every meshlet cost
+    // (worth it from a few meshlets per slot on -- the 51 200-triangle meshes: cfg3 +5 %, cfg50k64 +7 %; with two meshlets per slot
+    // the longest-first hand-out has nothing to even out and the measured times are not additive enough: cfg2 -2 %, midpoly -7 %)
+    const bool can_balance = e->balance && SL > 1 && SL <= 64 && E.n_meshlets <= 192 && E.n_meshlets >= e->balance_min_per_slot * SL;
+    // (the table variant of the kernel is a separate instantiation with the slot-major grid -- a slot's place in the dispatch order
+    // is then the same for every hypothesis --; the equal-share variant stays the code it was: with the table logic compiled into it
+    // it ran 1.3-3 us slower on every workload that does not use it)
+    const bool calibrate = can_balance && !e->balanced && mode == STEP_FIRST && !E.eval_grad;
+    if (calibrate) { E.slot_table = 0; E.mcost_rec = 1; }
+    const bool tab = can_balance && (calibrate || E.slot_table);
+    const dim3 g = (tab || E.step_xcd) ? dim3(E.d.B, SL) : dim3(SL, E.d.B);
 #define STEP_LAUNCH(TPL, NTH, MODE)                                                          \
     do {                                                                                     \
-        step_kernel<TPL, NTH, MODE><<<g, NTH, 0, s>>>(E, mode, it);                          \
+        if (tab) step_kernel<TPL, NTH, MODE, true><<<g, NTH, 0, s>>>(E, mode, it);           \
+        else step_kernel<TPL, NTH, MODE, false><<<g, NTH, 0, s>>>(E, mode, it);              \
     } while (0)
     STEP_DISPATCH(STEP_LAUNCH);
 #undef STEP_LAUNCH
     DDX_LAUNCH_CHECK();
+    if (calibrate) {
+        E.mcost_rec = 0;
+        if (int err = balance_slots(e, SL, s)) return err;
+    }
     return 0;
 }
 
@@ -1984,14 +2100,17 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
                 DDX_HIP(hipMalloc(&E.trace, (size_t)3 * TRACE_WG * 8 * 8));
                 DDX_HIP(hipMemset(E.trace, 0, (size_t)3 * TRACE_WG * 8 * 8));
             }
-        E.step_xcd = 0;
+        E.step_xcd = 0;  // (launch_step switches to the slot-major grid when it balances the shares)
         if (const char* ov = getenv("DDX_STEP_XCD")) E.step_xcd = atoi(ov) != 0;
+        E.slot_table = 0; E.mcost_rec = 0;
         E.scatter_mode = 0;
         E.n_meshlets = 0;
         for (int c = 0; c < 6; ++c) E.bbox[c] = 0.f;
     }
     e->small_mesh = mesh_is_small(*desc);
     if (const char* ov = getenv("DDX_STEP_RESIDENT")) e->step_resident = std::max(1, atoi(ov));
+    if (const char* ov = getenv("DDX_STEP_BALANCE")) e->balance = atoi(ov);
+    if (const char* ov = getenv("DDX_STEP_BALANCE_MIN")) e->balance_min_per_slot = std::max(1, atoi(ov));
     const size_t need = engine_layout(e->dev, *desc, b.scratch);
     if (b.scratch_bytes < need) {
         delete e;
@@ -2534,6 +2653,8 @@ extern "C" int ddx_engine_new_observation(ddx_engine* e)
 {
     DDX_REQUIRE(e, DDX_E_NULL, "engine_new_observation: NULL engine");
     e->setup_done = false;  // the next run / eval redoes the observation half of the setup (frame constants, seg list, optimiser state)
+    e->balanced = false;    // ... and the next run measures the meshlets under the new poses
+    e->dev.slot_table = 0;
     // a captured graph holds the kernels' by-value arguments of the OLD observation (size of the segmentation list, scatter
     // variant): it is captured again by the next run that asks for one
     if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
@@ -2718,6 +2839,8 @@ extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* s
             g->h_tab[i] = g->members[i]->dev;
             g->h_tab[i].eval_grad = nullptr;
             g->h_tab[i].eval_loss = nullptr;
+            g->h_tab[i].slot_table = 0;  // (a group's grid has its own dispatch order: equal shares)
+            g->h_tab[i].mcost_rec = 0;
         }
         DDX_HIP(hipMemcpyAsync(g->d_tab, g->h_tab.data(), g->h_tab.size() * sizeof(EngineDev), hipMemcpyHostToDevice, s));
         DDX_HIP(hipStreamSynchronize(s));  // (pageable source)

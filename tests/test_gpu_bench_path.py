@@ -215,3 +215,31 @@ def test_engine_shard_invariance(optimizer):
             np.testing.assert_allclose(l_sh[0].cpu().numpy(), eng.losses()[0].cpu().numpy(), rtol=1e-6, atol=1e-9)
             np.testing.assert_allclose(m_sh[1].cpu().numpy(), eng.mtx_log[1].cpu().numpy(), rtol=1e-5, atol=1e-6)
             np.testing.assert_allclose(l_sh.cpu().numpy(), eng.losses().cpu().numpy(), rtol=2e-3, atol=1e-7)
+
+
+def test_balanced_meshlet_shares_do_not_change_a_bit(monkeypatch):
+    """Round 3: on meshes with several meshlets per workgroup (the 51 200-triangle workloads: 100 meshlets) the first step launch
+    after a set-up measures what every meshlet costs, and the host hands the meshlets to the workgroups of a hypothesis longest
+    first, by the speed of each workgroup's place in the dispatch order (engine.hip: balance_slots).  Which workgroup draws a
+    meshlet must not change a bit: parameters, loss log and pose log of 8 Adam iterations with the balanced shares == with the
+    equal shares (DDX_STEP_BALANCE=0), also after a new observation (which measures again) and across a graph replay."""
+    from diffdope_amd import workloads as wl
+
+    res = {}
+    for bal in ("1", "0"):
+        monkeypatch.setenv("DDX_STEP_BALANCE", bal)
+        w = wl.build("cfg50k64", torch.device("cuda"))
+        lrs = wl.bench_lr_schedule(8, "adam")
+        eng, params = wl.engine_for(w, lrs, optimizer="adam")
+        eng.run(3); eng.run(5)
+        torch.cuda.synchronize()
+        a = (params.clone(), eng.loss_log.clone(), eng.mtx_log.clone())
+        assert eng.check()["overflow"] == 0
+        eng.new_observation(gt=w["gt"], params=w["params0"].clone(), lr_mult=w["lr_mult"], lr_sched=lrs)
+        eng.run(8, use_graph=4)
+        torch.cuda.synchronize()
+        res[bal] = a + (eng.params.clone(), eng.loss_log.clone())
+    for x, y in zip(res["1"], res["0"]):
+        assert torch.equal(x, y)
+    # the second run of each engine (same observation, same initial poses) reproduces its first
+    assert torch.equal(res["1"][0], res["1"][3]) and torch.equal(res["1"][1], res["1"][4])
