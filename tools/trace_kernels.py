@@ -1,7 +1,7 @@
 """Measurement tool: per-workgroup phase stamps (s_memrealtime, 100 MHz) of step_kernel / shade_kernel.
     DDX_TRACE=1 python tools/trace_kernels.py [config] [distance]
 step stamps: 0 start, 1 head done, 2 pose/matrices done, 3 first meshlet transformed (barrier passed), 4 its scatter issued,
-5/6 the same for the second meshlet, 7 end.  shade: 0 start, 1 scan done, 2 tiles done, 3 end; [4] = role << 32 | tiles."""
+5/6 the same for the second meshlet, 7 end.  shade: 0 start, 1 scan done, 2 tiles done, 3 end; [4] = grid z << 32 | tiles (z = 0 is the MASK role by default: engine_create)."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,4 +42,4 @@ for k, name, cols in ((0, "step", 8), (1, "shade", 4)):
             m = role == r
             if m.any():
                 d = us(a[m][:, 3] - a[m][:, 0]); sc = us(a[m][:, 1] - a[m][:, 0])
-                print(f"  role {r}: {m.sum()} wgs, tiles/wg mean {nt[m].mean():.2f}, in-kernel duration median {np.median(d):.2f} p90 {np.percentile(d,90):.2f}; scan median {np.median(sc):.2f}; start median {np.median(us(a[m][:,0]-t0)):.2f}")
+                print(f"  grid z = {r} ({'mask role unless the set-up put the colour role first' if r == 0 else 'colour role unless ...'}): {m.sum()} wgs, tiles/wg mean {nt[m].mean():.2f}, in-kernel duration median {np.median(d):.2f} p90 {np.percentile(d,90):.2f}; scan median {np.median(sc):.2f}; start median {np.median(us(a[m][:,0]-t0)):.2f}")
