@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 # MI355X_MICROARCH.md: 8 TB/s HBM3E spec (6.3 TB/s achievable copy rate); 256 CUs x 4 SIMD-32 at 2.4 GHz, one wave64 VALU
 # instruction issues over 2 cycles => 256 * 4 * 2.4e9 / 2 wave-instructions per second
 HBM_PEAK_GBS = 8000.0
+LINE_RATE_PEAK_G = 52.7   # random 64-byte lines per second, whole chip, in units of 1e9 (tools/ubench/gather_rate.hip)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # 1228.8 G wave-instructions / s
 
 
@@ -362,6 +363,16 @@ def main():
                     "traffic_fetch_doubled_over_compulsory": (traffic_x2 / comp[dom]) if traffic_x2 else None,
                     "iteration_compulsory_bytes": comp["iteration"],
                     "iteration_frac": comp["iteration"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            # The request view: both kernels move their bytes as single 64-byte lines that no lane shares (texel / triangle records,
+            # zbuf atomics, per-vertex stores), and a CU serves such lines at a fixed rate -- tools/ubench/gather_rate.hip: 52.7 G
+            # lines/s for the whole chip (64 lines in flight per CU and ~750 cycles each), whether 16 or 64 bytes of the line are read.
+            "line_rate": {"ceiling_Glines_s": LINE_RATE_PEAK_G, "source": "tools/ubench/gather_rate.hip (profiles/r3c_ubench_gather_rate.jsonl)",
+                          "memory_side_lines_per_launch": (traffic / 64.0) if traffic else None,
+                          "achieved_Glines_s": (traffic / 64.0 / dom_s / 1e9) if traffic else None,
+                          "frac": (traffic / 64.0 / dom_s / 1e9 / LINE_RATE_PEAK_G) if (traffic and not stale) else None,
+                          "what": "FETCH_SIZE + WRITE_SIZE bytes per launch of the dominant kernel / 64 / its live duration, against the "
+                                  "measured rate of random 64-byte lines from a 268 MB table (L2-resident lines are cheaper: a lower bound "
+                                  "on the kernel's line traffic, an honest ceiling for its memory-side part)"},
             "model_8d": {"algorithmic_bytes_per_launch": model_bytes, "achieved_GBps": model_bytes / dom_s / 1e9,
                          "ratio_to_hbm_peak": model_bytes / dom_s / 1e9 / HBM_PEAK_GBS,
                          "iteration_ratio_to_hbm_peak": alg["iteration"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
