@@ -182,12 +182,12 @@ class Camera:
         self.cam_proj = self.cam_proj.cuda().float()
 
     def resize(self, percentage):
-        self.fx *= percentage
-        self.fy *= percentage
-        self.cx = (int)(percentage * self.cx)
-        self.cy = (int)(percentage * self.cy)
-        self.im_width = (int)(percentage * self.im_width)
-        self.im_height = (int)(percentage * self.im_height)
+        """Scale the intrinsics with the image (diffdope.py:665-677): focal lengths exactly, principal point and image size
+        truncated to whole pixels."""
+        k = float(percentage)
+        self.fx, self.fy = self.fx * k, self.fy * k
+        for name in ("cx", "cy", "im_width", "im_height"):
+            setattr(self, name, int(k * getattr(self, name)))
 
     def get_projection_matrix(self):
         """'y_down' window convention of diffdope.py:726-740."""
@@ -254,7 +254,7 @@ class Mesh(torch.nn.Module):
                 col = np.full((vtx_pos.shape[0], 3), 0.5)
             self.vtx_color = torch.from_numpy(np.ascontiguousarray(col).astype(np.float32))
             self.has_textured_map = False
-        log.info(f"loaded mesh @{self.path_model}. Does it have texture map? {self.has_textured_map} ")
+        log.info("mesh %s: %d vertices, %d faces, %s", self.path_model, int(vtx_pos.shape[0]), int(pos_idx.shape[0]), "texture map" if self.has_textured_map else "vertex colours")
         self._batchsize_set = False
 
     @classmethod
@@ -317,8 +317,7 @@ class Object3D(torch.nn.Module):
         rotation = rotation.reshape(-1) if rotation.size == 4 else quat_from_matrix(rotation)
         if opencv2opengl:
             position, rotation = opencv_2_opengl(position, rotation)
-        log.info(f"translation loaded: {position}")
-        log.info(f"rotation loaded as quaternion: {rotation}")
+        log.info("Object3D pose set: t = %s, q (xyzw) = %s", np.round(np.asarray(position, np.float64), 6).tolist(), np.round(np.asarray(rotation, np.float64), 6).tolist())
         self._position, self._rotation = position, rotation
         device = "cpu" if self.qx is None else self.qx.device
         self._make_params(batchsize, rotation, position)
@@ -358,12 +357,13 @@ class Object3D(torch.nn.Module):
                 getattr(self, name).copy_(p[i])
 
     def forward(self):
-        q = torch.stack([self.qx, self.qy, self.qz, self.qw], dim=0).T
-        q = q / torch.norm(q, dim=1).reshape(-1, 1)
-        to_return = self.mesh()
-        to_return["quat"] = q
-        to_return["trans"] = torch.stack([self.x, self.y, self.z], dim=0).T
-        return to_return
+        """The mesh dictionary plus the pose of every hypothesis: `quat` [B,4] (x, y, z, w, normalised here -- the seven parameters
+        are free, so the optimiser may leave the unit sphere) and `trans` [B,3] (semantics of diffdope.py:1085-1098)."""
+        raw_q = torch.stack((self.qx, self.qy, self.qz, self.qw), dim=1)
+        out = dict(self.mesh())
+        out["quat"] = raw_q / raw_q.norm(dim=1, keepdim=True)
+        out["trans"] = torch.stack((self.x, self.y, self.z), dim=1)
+        return out
 
 
 @dataclass
@@ -389,7 +389,7 @@ class Image:
                 ow, oh = int(im.shape[1] * self.img_resize), int(im.shape[0] * self.img_resize)
                 im = io_img.resize_nearest(im, ow, oh) if self.depth else io_img.resize_linear(im, ow, oh)
             self.img_tensor = torch.tensor(np.ascontiguousarray(im)).float()
-            log.info(f"Loaded image {self.img_path}, shape: {self.img_tensor.shape}")
+            log.info("image %s read as %s", self.img_path, tuple(self.img_tensor.shape))
         self._batchsize_set = False
 
     def __repr__(self):
@@ -549,7 +549,7 @@ class DiffDope:
         if self.cfg.losses.get("l1_edge", False):  # extension, absent from the reference's yaml
             self.loss_functions.append(l1_edge)
         self.last_engine = None
-        log.info(f"batchsize is {self.batchsize}")
+        log.info("DiffDope ready: %d hypotheses, losses %s", self.batchsize, [f.__name__ for f in self.loss_functions])
 
     def _refresh_gt(self):
         if self.scene.tensor_rgb is not None:

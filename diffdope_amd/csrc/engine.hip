@@ -45,21 +45,40 @@
 #include <vector>
 #include <cstdio>
 
-#include <roctracer/roctx.h>
+#include <dlfcn.h>
 
 #include "raster_dev.h"
 
 // roctx ranges around the runs, iterations and launches of the engine (rocprofv3 --marker-trace): on with
-// DDX_ROCTX=1 in the environment (read once), otherwise a test of a static flag
-static bool ddx_roctx_on()
+// DDX_ROCTX=1 in the environment (read once).  libroctx64 is looked up at run time, and only then: the library neither links
+// against roctracer nor needs it installed while the switch is off.
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+static const RoctxApi& ddx_roctx()
 {
-    static const int on = [] { const char* v = getenv("DDX_ROCTX"); return (v && atoi(v)) ? 1 : 0; }();
-    return on != 0;
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        const char* v = getenv("DDX_ROCTX");
+        if (!(v && atoi(v))) return a;
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) {
+            fprintf(stderr, "ddx: DDX_ROCTX=1 but libroctx64.so cannot be loaded (%s): no ranges\n", dlerror());
+            return a;
+        }
+        a.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+        return a;
+    }();
+    return api;
 }
 struct RoctxRange {
     bool on;
-    explicit RoctxRange(const char* name) : on(ddx_roctx_on()) { if (on) roctxRangePushA(name); }
-    ~RoctxRange() { if (on) roctxRangePop(); }
+    explicit RoctxRange(const char* name) : on(ddx_roctx().push != nullptr) { if (on) ddx_roctx().push(name); }
+    ~RoctxRange() { if (on) ddx_roctx().pop(); }
 };
 
 #define NPART 24  // floats per tile partial: 12 dFinal(x,y,w rows) | 4 dMtx row 2 | 4 losses (rgb, depth, mask, edge) | pad
@@ -184,6 +203,7 @@ struct ddx_engine {
     hipGraphExec_t exec = nullptr;
     int graph_chunk = 1;  // iterations per captured graph
     bool setup_done = false;
+    unsigned setup_gen = 0;  // bumped by every engine_setup: a group re-uploads the table row of a member whose set-up ran outside it
     bool mesh_done = false;  // the mesh half of the setup (sorted copies, meshlets, triangle / texel records, closedness) survives ddx_engine_new_observation
     int step_resident = 0;     // step_kernel workgroups the chip holds at once (step_capacity, asked once); DDX_STEP_RESIDENT overrides
     int balance = 1;           // balanced shares of the meshlets (balance_slots); DDX_STEP_BALANCE=0: equal shares
@@ -1816,6 +1836,10 @@ static dim3 shade_grid(const ddx_engine_desc& d)
 {
     int grid = SHADE_GRID;
     if (const char* ov = getenv("DDX_SHADE_GRID")) grid = atoi(ov);  // (tuning)
+    // SHADE_GRID workgroups per role when both roles run (2 x 512 = the 1024 the chip holds at 4 waves per SIMD); a launch with ONE
+    // role -- no mask term, or the mask term alone -- gets all of them (round 4: cfg3's shading launch ran at 2 waves per SIMD)
+    const int n_roles = ((d.use_rgb || d.use_depth || d.use_edge) ? 1 : 0) + (d.use_mask ? 1 : 0);
+    if (n_roles <= 1) grid *= 2;
     int S = d.shade_slices > 0 ? d.shade_slices : grid / d.B;
     if (S < 1) S = 1;
     if (S > 64) S = 64;
@@ -1934,7 +1958,11 @@ static int balance_slots(ddx_engine* e, int SL, hipStream_t s)
     }
     int off = 0;
     for (int sl = 0; sl < SL; ++sl) {
-        if (items[(size_t)sl].size() > 64) return 0;  // (the kernel keeps a slot's list in 64 LDS entries: keep the equal split)
+        if (items[(size_t)sl].size() > 64) {  // (the kernel keeps a slot's list in 64 LDS entries: keep the equal split, and do not try again)
+            E.slot_table = 0;
+            e->balanced = true;
+            return 0;
+        }
         E.slot_off[sl] = (unsigned short)off;
         E.slot_cnt[sl] = (unsigned char)items[(size_t)sl].size();
         for (int m : items[(size_t)sl]) E.slot_items[off++] = (unsigned short)m;
@@ -1967,7 +1995,13 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
     // (the table variant of the kernel is a separate instantiation with the slot-major grid -- a slot's place in the dispatch order
     // is then the same for every hypothesis --; the equal-share variant stays the code it was: with the table logic compiled into it
     // it ran 1.3-3 us slower on every workload that does not use it)
-    const bool calibrate = can_balance && !e->balanced && mode == STEP_FIRST && !E.eval_grad;
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        capturing = hipStreamIsCapturing(s, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
+    }
+    // (the calibration reads its measurements back and synchronises the stream once per set-up -- ddx.h; never inside a capture)
+    const bool calibrate = can_balance && !e->balanced && mode == STEP_FIRST && !E.eval_grad && !capturing;
     if (calibrate) { E.slot_table = 0; E.mcost_rec = 1; }
     const bool tab = can_balance && (calibrate || E.slot_table);
     const dim3 g = (tab || E.step_xcd) ? dim3(E.d.B, SL) : dim3(SL, E.d.B);
@@ -2481,6 +2515,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         }
     }
     e->setup_done = true;
+    ++e->setup_gen;
     return 0;
 }
 
@@ -2725,6 +2760,7 @@ struct ddx_engine_group {
     std::vector<ddx_engine*> members;
     EngineDev* d_tab = nullptr;        // device table of the members' EngineDev
     std::vector<EngineDev> h_tab;
+    std::vector<unsigned> gen_up;      // set-up generation of each member when its row was uploaded (0 = never)
     bool uploaded = false;
 };
 
@@ -2737,10 +2773,16 @@ extern "C" int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_g
         DDX_REQUIRE(engines[i]->dev.d.max_iters == engines[0]->dev.d.max_iters, DDX_E_SHAPE, "engine_group_create: members differ in max_iters");
         for (int j = 0; j < i; ++j) DDX_REQUIRE(engines[j] != engines[i], DDX_E_SHAPE, "engine_group_create: member %d listed twice", i);
     }
+    {   // the hypotheses of all members share one grid dimension (y of the step / finish launches: at most 65535)
+        long long btot = 0;
+        for (int i = 0; i < n; ++i) btot += engines[i]->dev.d.B;
+        DDX_REQUIRE(btot <= 65535, DDX_E_SHAPE, "engine_group_create: %lld hypotheses in all (at most 65535 per group)", btot);
+    }
     ddx_engine_group* g = new (std::nothrow) ddx_engine_group();
     DDX_REQUIRE(g, DDX_E_NULL, "engine_group_create: out of host memory");
     g->members.assign(engines, engines + n);
     g->h_tab.resize((size_t)n);
+    g->gen_up.assign((size_t)n, 0u);
     if (hipMalloc(&g->d_tab, (size_t)n * sizeof(EngineDev)) != hipSuccess) {
         delete g;
         DDX_REQUIRE(false, DDX_E_NULL, "engine_group_create: hipMalloc of the member table failed");
@@ -2834,12 +2876,14 @@ extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* s
     const int max_iters = g->members[0]->dev.d.max_iters;
     DDX_REQUIRE(it0 >= 0 && n >= 0 && it0 + n <= max_iters, DDX_E_SHAPE, "engine_group_run: iterations [%d,%d) exceed max_iters=%d", it0, it0 + n, max_iters);
     bool fresh = !g->uploaded;
-    for (auto* e : g->members) {
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        ddx_engine* e = g->members[i];
         e->fwd_cached_it = -1;
-        if (!e->setup_done) {
+        if (!e->setup_done)
             if (int err = engine_setup(e, s)) return err;
-            fresh = true;
-        }
+        // a member whose set-up ran since its row was uploaded -- here, or in a run / evaluation / profile of its own after a
+        // new observation -- has a stale row (size of the seg list, scatter variant, order of the roles, culling sign, box)
+        fresh = fresh || e->setup_gen != g->gen_up[i];
     }
     if (n == 0) return 0;
     RoctxRange rr("ddx_engine_group_run");
@@ -2852,6 +2896,7 @@ extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* s
             g->h_tab[i].eval_loss = nullptr;
             g->h_tab[i].slot_table = 0;  // (a group's grid has its own dispatch order: equal shares)
             g->h_tab[i].mcost_rec = 0;
+            g->gen_up[i] = g->members[i]->setup_gen;
         }
         DDX_HIP(hipMemcpyAsync(g->d_tab, g->h_tab.data(), g->h_tab.size() * sizeof(EngineDev), hipMemcpyHostToDevice, s));
         DDX_HIP(hipStreamSynchronize(s));  // (pageable source)

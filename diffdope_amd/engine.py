@@ -173,7 +173,9 @@ class RefineEngine:
     def slices(self):
         """(shade_slices, edge_slices) this engine runs with: what a shard of this batch passes to reproduce it bitwise."""
         auto = lambda grid: max(1, min(64, grid // self.B))
-        return (self.desc.shade_slices or auto(512), self.desc.edge_slices or auto(1792))
+        d = self.desc
+        n_roles = int(bool(d.use_rgb or d.use_depth or d.use_edge)) + int(bool(d.use_mask))
+        return (d.shade_slices or auto(512 if n_roles == 2 else 1024), d.edge_slices or auto(1792))
 
     @property
     def cull_sign(self):
@@ -246,10 +248,17 @@ class RefineEngineGroup:
     def run(self, n=None):
         """n iterations (default: all remaining) of every member, asynchronously on the current stream."""
         e0 = self.engines[0]
+        if len({e.it for e in self.engines}) != 1:  # (a member was run, rewound or given a new observation on its own)
+            raise ValueError("the members of a group must sit at the same iteration: " + str([e.it for e in self.engines]))
         n = e0.max_iters - e0.it if n is None else n
         _lib.check(self.lib.ddx_engine_group_run(self.handle, e0.it, n, _lib.stream_ptr()), "ddx_engine_group_run")
         for e in self.engines:
             e.it += n
+
+    def invalidate(self):
+        """A member was re-created in place (same handle, other buffers): its table row is uploaded again by the next run.  Not
+        needed after new_observation(): the native side notices a member's new set-up by itself."""
+        _lib.check(self.lib.ddx_engine_group_invalidate(self.handle), "ddx_engine_group_invalidate")
 
     def finish(self):
         torch.cuda.current_stream().synchronize()

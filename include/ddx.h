@@ -237,7 +237,11 @@ size_t ddx_engine_scratch_bytes(const ddx_engine_desc* desc);
 int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* bufs, ddx_engine** out);
 /* Run iterations [it0, it0+n) (rows of lr_sched / loss_log / mtx_log).  use_graph = k > 0 replays a captured hipGraph of
  * k iterations (k <= 64, fixed at the first graph run of the engine; a remainder of fewer than k iterations is launched
- * kernel by kernel).  Measured on MI355X: k = 1 is 9 % slower than plain stream launches, k = 20 equal (+-1 %). */
+ * kernel by kernel).  Measured on MI355X: k = 1 is 9 % slower than plain stream launches, k = 20 equal (+-1 %).
+ * Asynchronous, with ONE exception: the first run / eval / profile after ddx_engine_create or ddx_engine_new_observation does the
+ * set-up, which reads small tables back (frame constants, segmentation list; on meshes with four or more meshlets per workgroup
+ * also the per-meshlet times of its first launch, once) and therefore synchronises `stream`; that call must not be made while
+ * `stream` is being captured (the meshlet calibration is skipped inside a capture rather than breaking it). */
 int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
 /* Evaluation pass without an optimiser step (for callers that bring their own optimiser): renders the hypotheses
  * at the CURRENT contents of `params`, writes d loss / d params to grad_out [7,B] and the weighted, un-LR'd
@@ -292,13 +296,14 @@ void ddx_engine_destroy(ddx_engine* e);
  * 64 hypotheses on a GPU).  A 64-hypothesis launch is latency-bound and fills a fraction of the chip; the members of a group
  * share every grid.  Each member keeps its own buffers, scratch, schedule rows and launch geometry, and ends with bit for bit the
  * result ddx_engine_run would give it alone.  Members may differ in mesh, texture, frame size, loss set and batch size; they
- * must agree on max_iters.  The group borrows the engines (destroy the group first).  At most 32 members.
+ * must agree on max_iters.  The group borrows the engines (destroy the group first).  At most 32 members and 65535 hypotheses in all.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ddx_engine_group ddx_engine_group;
 int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_group** out);
 /* iterations [it0, it0 + n) of every member; asynchronous on `stream` (plain stream launches) */
 int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* stream);
-/* after ddx_engine_new_observation on a member nothing is needed; call this if a member was re-created in place */
+/* after ddx_engine_new_observation on a member nothing is needed, also when that member was then run, evaluated or profiled on
+ * its own (every set-up bumps a generation counter the group compares); call this if a member was re-created in place */
 int ddx_engine_group_invalidate(ddx_engine_group* g);
 void ddx_engine_group_destroy(ddx_engine_group* g);
 /* measurement hook (DDX_TRACE=1 in the environment when the engine is created): per-workgroup phase stamps, see

@@ -83,6 +83,28 @@ def test_bench_with_two_ranks_sharing_the_gpu():
     assert line["final_pose"]["argmin_global_index"] in range(128)
 
 
+def test_config4_fixed_job_two_ranks_sharing_the_gpu_matches_one_process():
+    """BASELINE configs[3] in the form the 8-GPU node runs it (--config cfg4 --global-batch G: a FIXED job sharded by
+    dist.shard_range), at world size 2 on the one GPU (gloo, DDX_BENCH_SHARE_GPU) against the same 128-hypothesis job in one
+    process: strong scaling reported, 64 hypotheses per rank, the same arg-min hypothesis and loss."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DDX_BENCH_SHARE_GPU", None)
+    common = ["--config", "cfg4", "--steps", "8", "--warmup", "3", "--global-batch", "128", "--no-cpu-baseline", "--no-extras", "--no-convergence"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common
+    two = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, DDX_BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["scaling"] == b["scaling"] == "strong" and b["n_gpus"] == 2 and b["dist"]["world_size"] == 2
+    assert a["config"]["global_hypotheses"] == b["config"]["global_hypotheses"] == 128
+    assert a["config"]["hypotheses_per_gpu"] == 128 and b["config"]["hypotheses_per_gpu"] == 64
+    assert a["final_pose"]["argmin_global_index"] == b["final_pose"]["argmin_global_index"]
+    assert abs(a["final_pose"]["argmin_loss"] - b["final_pose"]["argmin_loss"]) <= 1e-3 * abs(a["final_pose"]["argmin_loss"])
+
+
 def test_multi_object_frame_with_two_ranks_sharing_the_gpu():
     """examples/run_bop_scene.py (bop.refine_frame: objects sharded over ranks, one all_reduce of the object table) with two ranks on
     the one GPU over gloo: the same poses as the single-process run, every object's owner reported."""
