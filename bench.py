@@ -268,13 +268,11 @@ def main():
         row_mask = sum(1 << i for i in used)
         # the one collective of the job: global arg-min hypothesis + its pose (diffdope.py:1488-1513,1618-1632);
         # local selection by one device kernel, one all_reduce of the [world,18] table, one host synchronisation
-        select_best = lambda it: ddist.global_argmin_fused(eng.loss_log[it], row_mask, eng.mtx_log[it], lo=lo_w)
-
+        # (round 4: the local selection rides on the run's last kernel -- ddx_engine_run_select -- instead of its own launch)
         def window():
             barrier()
             t0 = time.perf_counter()
-            eng.run(args.steps, use_graph=args.graph)
-            best = select_best(n_it - 1)
+            best = ddist.run_and_select(eng, args.steps, lo=lo_w, use_graph=args.graph)
             barrier()
             el = time.perf_counter() - t0
             if use_dist:
@@ -283,17 +281,20 @@ def main():
                 el = float(tmax.item())
             return el, best
 
-        eng.run(args.warmup, use_graph=args.graph)
         if args.warmup > 0:
-            select_best(args.warmup - 1)  # warm the selection path too (first-use kernel loads, RCCL channel setup)
+            ddist.run_and_select(eng, args.warmup, lo=lo_w, use_graph=args.graph)  # (warms the selection path too: pinned row, RCCL channels)
         elapsed, best = window()
+        if os.environ.get("DDX_BENCH_CHECK_SELECT"):  # (tests: the fused selection against the stand-alone kernel on the same rows)
+            ref = ddist.global_argmin_fused(eng.loss_log[n_it - 1], row_mask, eng.mtx_log[n_it - 1], lo=lo_w)
+            assert ref[0] == best[0] and ref[1] == best[1] and torch.equal(ref[2], best[2]), (ref, best)
         st = eng.check()
         final = params.clone()
         per_hyp = eng.loss_log[n_it - 1][used].mean(0).clone()
         extra = []
         for _ in range(repeats):
             eng.new_observation(params=w["params0"])  # initial poses, zero moments, iteration 0
-            eng.run(args.warmup, use_graph=args.graph)
+            if args.warmup > 0:
+                eng.run(args.warmup, use_graph=args.graph)
             extra.append(window()[0])
         return dict(elapsed=elapsed, best=best, status=st, params=final, per_hyp=per_hyp, lrs=lrs, repeats=extra, eng=eng)
 

@@ -8,7 +8,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddx.so")
+# DDX_LIB: a VARIANT build of the same sources (tools/build_variant.py: timing / leave-out experiments).  Never a fallback: a path that
+# does not exist is an error like a missing libddx.so
+LIB_PATH = os.environ.get("DDX_LIB") or os.path.join(_HERE, "libddx.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ddx.h")
 
 _lib = None
@@ -28,7 +30,7 @@ class EngineDesc(ctypes.Structure):
         ("adam_beta1", ctypes.c_float), ("adam_beta2", ctypes.c_float), ("adam_eps", ctypes.c_float),
         ("max_iters", ctypes.c_int32), ("use_edge", ctypes.c_int32), ("w_edge", ctypes.c_float),
         ("shade_slices", ctypes.c_int32), ("edge_slices", ctypes.c_int32), ("no_backface_cull", ctypes.c_int32),
-        ("compat", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
+        ("compat", ctypes.c_int32), ("separate_big_pass", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
     ]
 
 
@@ -69,6 +71,7 @@ _SIGNATURES = {
     "ddx_engine_scratch_bytes": (_SZ, [ctypes.POINTER(EngineDesc)]),
     "ddx_engine_create": (_I, [ctypes.POINTER(EngineDesc), ctypes.POINTER(EngineBuffers), ctypes.POINTER(_P)]),
     "ddx_engine_run": (_I, [_P, _I, _I, _I, _P]),
+    "ddx_engine_run_select": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "ddx_engine_eval": (_I, [_P, _I, _P, _P, _P]),
     "ddx_select_best": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "ddx_render_loss_fwd": (_I, [_P, _I, _P, _P]),

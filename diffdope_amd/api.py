@@ -659,7 +659,7 @@ class DiffDope:
         hp = self.cfg.hyperparameters
         return [hp.base_lr * hp.lr_decay ** (it / hp.nb_iterations + 1) for it in range(hp.nb_iterations + 1)]
 
-    def prepare_optimization(self, optimizer="sgd", global_batch=None, shade_slices=0, edge_slices=0):
+    def prepare_optimization(self, optimizer="sgd", global_batch=None, shade_slices=0, edge_slices=0, separate_big_pass=False):
         """First half of run_optimization(wait=False) for callers that run several objects as ONE engine group
         (bop.refine_frame): resets the logs, builds / refreshes the fused engine and returns it WITHOUT launching anything; after
         the group has run, finish_optimization() collects the results as usual.  Only for the built-in losses."""
@@ -668,7 +668,7 @@ class DiffDope:
         self._refresh_gt()
         if not (all(f in _BUILTIN_LOSSES for f in self.loss_functions) and len(self.loss_functions) > 0):
             raise RuntimeError("the fused engine only knows l1_rgb_with_mask / l1_depth_with_mask / l1_mask / l1_edge")
-        eng, params, weights = self._fused_prepare(optimizer, global_batch, shade_slices, edge_slices)
+        eng, params, weights = self._fused_prepare(optimizer, global_batch, shade_slices, edge_slices, separate_big_pass)
         self._pending = (eng, params, weights, torch.cuda.current_stream())
         return eng
 
@@ -697,7 +697,7 @@ class DiffDope:
         if getattr(self, "_pending", None) is not None:
             self._fused_collect()
 
-    def _fused_prepare(self, optimizer, global_batch, shade_slices=0, edge_slices=0):
+    def _fused_prepare(self, optimizer, global_batch, shade_slices=0, edge_slices=0, separate_big_pass=False):
         """The fused engine for this object, observation and schedule, ready at iteration 0 (built, or the previous run's engine
         with the new observation copied in); nothing is launched.  Returns (engine, params tensor, weights)."""
         r = self.object3d.mesh()
@@ -718,7 +718,7 @@ class DiffDope:
         mesh_t = [r["pos"], r["pos_idx"], self.camera.cam_proj] + list(tex.values())
         sig = (tuple(_buffer_key(t) for t in mesh_t), tuple(self.resolution), self.batchsize, tuple(sorted(weights.items())), optimizer,
                global_batch, len(self.lr_schedule()), tuple(sorted((k, tuple(v.shape)) for k, v in gt.items())), shade_slices, edge_slices,
-               bool(self.cfg.hyperparameters.get("cull_backfaces", True)), self.cfg.hyperparameters.get("compat"))
+               bool(self.cfg.hyperparameters.get("cull_backfaces", True)), self.cfg.hyperparameters.get("compat"), bool(separate_big_pass))
         cached = getattr(self, "_engine_cache", None)
         if cached is not None and cached[0] == sig and getattr(self, "_pending", None) is None:
             eng = cached[1]
@@ -730,7 +730,8 @@ class DiffDope:
             hp = self.cfg.hyperparameters
             eng = RefineEngine(r["pos"][0], r["pos_idx"][0], self.camera.cam_proj[0], self.resolution, gt, params, self.learning_rates,
                                self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, shade_slices=shade_slices,
-                               edge_slices=edge_slices, cull_backfaces=bool(hp.get("cull_backfaces", True)), compat=hp.get("compat"), **tex)
+                               edge_slices=edge_slices, cull_backfaces=bool(hp.get("cull_backfaces", True)), compat=hp.get("compat"),
+                               separate_big_pass=separate_big_pass, **tex)
             self._engine_cache = (sig, eng, mesh_t)  # (mesh_t: keeps the keyed buffers alive, see render._buffer_key)
         return eng, params, weights
 

@@ -104,6 +104,12 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
     double c_edge;   // sum over the frame of |Gx| + |Gy| of the observed, masked image (edge extension)
+    // selection of the best hypothesis inside finish_kernel (ddx_engine_run_select): the hypotheses' writer workgroups fold
+    // (order-preserving bits of the mean loss << 32 | index) into sel_key with atomicMin and count themselves in sel_arrive; the
+    // last one writes the [18] row.  Both words are all-ones / zero between runs (re-armed by that last workgroup).
+    unsigned long long sel_key;
+    int sel_arrive;
+    int sel_pad;
 };
 
 // step_kernel(mode): STEP_FIRST draws the first iteration of a run from the caller's parameters (no optimiser step);
@@ -183,10 +189,15 @@ struct EngineDev {
     int roles[MAX_ROLES];    // grid z -> role
     int role_mask;           // bit r set = role r runs
     int s_shade, s_edge;     // slices per hypothesis of shade_kernel / edge_kernel (grid y)
+    int big_inline;          // 1: the shading launch carries the tile pass for large triangles itself (worker workgroups in its first
+                             // slab, big_worker_wg) and big_pass_kernel is not launched; 0: the launch between step_kernel and shade_kernel
+    int big_workers;         // ... worker workgroups per hypothesis that look at its count (<= slices; the others leave on their block id)
     int pslices;             // rows of the partial table per hypothesis: max(s_shade, s_edge) slices
     float* eval_grad;        // [7,B] or null.  Non-null = evaluation pass (ddx_engine_eval): d loss / d params and the
     float* eval_loss;        // [4,B] losses are written here, no optimiser step
     float* eval_tmp;         // [7,B] gradient sink of ddx_render_loss_fwd
+    float* sel_out;          // [18] or null.  Non-null (finish_kernel of ddx_engine_run_select): (mean loss of the best hypothesis, its
+    int sel_lo;              // global index = sel_lo + local index, its 4x4 pose) is written here by the last writer workgroup
 };
 
 #define TRACE_WG 4096
@@ -203,6 +214,9 @@ struct ddx_engine {
     hipGraphExec_t exec = nullptr;
     int graph_chunk = 1;  // iterations per captured graph
     bool setup_done = false;
+    bool inline_ok = false;    // the tile pass MAY run inside shade_kernel (batch shape, residency, desc): decided at creation
+    int inline_env = -1;       // DDX_BIG_INLINE: 0 = never, 1 = whenever inline_ok, -1 = the set-up's estimate decides
+    double mesh_area = 0.0, mesh_max_edge = 0.0;  // object space: sum of the triangle areas, longest edge (mesh half of the set-up)
     unsigned setup_gen = 0;  // bumped by every engine_setup: a group re-uploads the table row of a member whose set-up ran outside it
     bool mesh_done = false;  // the mesh half of the setup (sorted copies, meshlets, triangle / texel records, closedness) survives ddx_engine_new_observation
     int step_resident = 0;     // step_kernel workgroups the chip holds at once (step_capacity, asked once); DDX_STEP_RESIDENT overrides
@@ -1137,6 +1151,55 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 
 // Two builds of the same kernel: without and with the edge role, so that the register allocation (and scratch
 // footprint) of the reference-loss configurations does not depend on the extension.
+// THE TILE PASS INSIDE THE SHADING LAUNCH (EngineDev::big_inline, round 4).  big_pass_kernel between step_kernel and shade_kernel
+// costs a kernel boundary in every iteration -- 2.4 of cfg2's 43 us, measured by leaving it out -- and exits at once in nearly all
+// of them: the dense meshes of the benchmark never have a LARGE triangle.  With big_inline the launch is dropped and the shading
+// grid gets one more slab of workgroups IN FRONT (grid z = 0: the "workers", S per hypothesis): a worker reads its hypothesis'
+// count of large triangles and leaves if it is zero; otherwise the S workers of the hypothesis split its large tiles (a wave per
+// tile, big_tile_wave with a 16-triangle stage), and each adds one to the hypothesis' arrival counter when its atomics have been
+// performed.  A shading workgroup looks at the same count (one scalar load, requested before its flag scan) and, only if it is not
+// zero, waits until all S workers have arrived.  Why that cannot hang: workgroups are dispatched in the order of their linear id,
+// per XCD, and the workers of hypothesis b (block ids b + B (...), B % 8 == 0) sit on the same XCD b % 8 as its shading workgroups
+// with smaller ids -- a shading workgroup that runs implies that every worker of its hypothesis has been dispatched, and a worker
+// waits for nothing.  What crosses the wait is zbuf, written by atomics only and not read by the shading workgroups before; no
+// fence (agent-scope fences cost 23-34 us per round here, tools/ubench/group_barrier.hip), no heavy code in the shading path (the
+// round-3 form -- the shading workgroups running the tile pass themselves through a call -- cost the kernel 13 spilled registers
+// and 2.5 us whether or not a large triangle existed).  Same triangles, same keys, same zbuf as the separate launch.
+__device__ __forceinline__ void big_worker_wg(const EngineDev& E, int b, int sl, int S, int it_arg)
+{
+    S = min(S, E.big_workers);
+    if (sl >= S) return;
+    const RasterScratch& L = E.L;
+    const int par = (it_arg >= 0 ? it_arg : E.st->it_next - 1) & 1;
+    const size_t hb = (size_t)par * E.d.B + b;
+    const int n_big = __builtin_amdgcn_readfirstlane(L.bigcount[hb]);
+    if (n_big <= 0) return;  // (always, on the meshes this mode is chosen for)
+    __shared__ BigStage<16> s_stage[WAVES_PER_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned char* tb = L.tile_big + hb * L.NTp;
+    const int w = sl * WAVES_PER_TILE + wave, NW = S * WAVES_PER_TILE;  // this wave among the hypothesis' worker waves: tiles w, w + NW, ...
+    for (int base = 0; base * NW < L.NT; base += 64) {
+        const int tile = (base + lane) * NW + w;
+        const unsigned long long m = __ballot(tile < L.NT && tb[tile] != 0);
+        for (unsigned long long r = m; r; r &= r - 1) {  // (wave-uniform)
+            const int k = __ffsll((long long)r) - 1;
+            big_tile_wave<16>(s_stage[wave], E.clip + (size_t)b * E.d.V * 4, E.stri, L.snap + (size_t)b * E.d.V, L.biglist + (size_t)b * E.d.T,
+                              min(n_big, E.d.T), L.zbuf + hb * L.zper, L.zwb, L.ntx, (base + k) * NW + w, E.d.H, E.d.W);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's atomics have been performed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(L.bigarrive + hb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a shading workgroup of a hypothesis that HAS large triangles: until its S workers have arrived
+__device__ __forceinline__ void big_wait(int* arrive, int S)
+{
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+}
+
 template <bool EDGE>
 __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int S, int z, int it_arg)
 {
@@ -1169,10 +1232,13 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
     const bool lister = z == 0 && wave == 0;
     const int wg_id = (z * S + sl) * E.d.B + b;
     STAMP(E, 1, wg_id, 0);
+    // (inline tile pass: the hypothesis' count of large triangles, requested before the scan and looked at after it)
+    const int n_big_list = E.big_inline ? __builtin_amdgcn_readfirstlane(L.bigcount[(size_t)tw.par * E.d.B + b]) : 0;
     tw.n_flags = tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, 0, tw.list, lister ? L.active + (size_t)tw.b * L.NT : nullptr);
     tw.n_mine = tw.n_flags > tw.sl ? (tw.n_flags - tw.sl + tw.S - 1) / tw.S : 0;
     wave_lds_sync();
     if (lister && tw.sl == 0 && lane == 0) L.b_count[tw.b] = tw.n_flags;
+    if (n_big_list > 0) big_wait(L.bigarrive + (size_t)tw.par * E.d.B + b, min(S, E.big_workers));  // (workgroup-uniform; rare)
     STAMP(E, 1, wg_id, 1);
     const int role = z == 0 ? E.roles[0] : E.roles[1];
     if (role == 0) shade_body<0, EDGE>(E, pool, tw);
@@ -1185,7 +1251,16 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
 template <bool EDGE>
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E, int it_arg)
 {
-    shade_wg<EDGE>(E, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, it_arg);
+    // grid (B, S, roles), or (B, S, 1 + roles) with the tile pass inside the launch: slab z = 0 = its workers
+    int z = blockIdx.z;
+    if (E.big_inline) {
+        if (z == 0) {
+            big_worker_wg(E, blockIdx.x, blockIdx.y, gridDim.y, it_arg);
+            return;
+        }
+        --z;
+    }
+    shade_wg<EDGE>(E, blockIdx.x, blockIdx.y, gridDim.y, z, it_arg);
 }
 
 // group form: grid (sum of the members' hypotheses, largest slice count, 2)
@@ -1194,8 +1269,17 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_group_kernel(const
 {
     const int o = group_find(G, blockIdx.x);
     const EngineDev& E = tab[G.idx[o]];
-    if ((int)blockIdx.y >= E.s_shade || (int)blockIdx.z >= E.n_roles) return;
-    shade_wg<EDGE>(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_shade, blockIdx.z, it_arg);
+    if ((int)blockIdx.y >= E.s_shade) return;
+    int z = blockIdx.z;
+    if (E.big_inline) {  // (the same for every member of a launch: grid z = 3)
+        if (z == 0) {
+            big_worker_wg(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_shade, it_arg);
+            return;
+        }
+        --z;
+    }
+    if (z >= E.n_roles) return;
+    shade_wg<EDGE>(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_shade, z, it_arg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1368,7 +1452,7 @@ __global__ __launch_bounds__(256) void edge_group_kernel(const EngineDev* __rest
 // 64- and 256-thread variants of step_kernel produce the same bits.
 #define UPD_SLICES 8  // workgroups per hypothesis of finish_kernel; fewer for large batches (upd_slices())
 
-template <int NTH>
+template <int NTH, bool SEL = false /* finish_kernel: the selection of ddx_engine_run_select is compiled in */>
 __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, int slice, int n_slices, float* snew, float* sc)
 {
     constexpr int NG = NTH / 32, NW = NTH / 64, NBK = 8 / NG;  // groups of 32 threads, waves, row buckets per thread
@@ -1470,7 +1554,13 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
             for (int i = 0; i < NBK; ++i) red[i % 4][lane] = acc[i];  // (NTH = 64: thread group g in {0,1} holds buckets g, g+2, g+4, g+6 = pairs 0..3)
         }
     }
+#ifdef DDX_TRACE_HEAD
+    if (E.trace && tid == 0 && blockDim.x == 256 && gridDim.z == 1) E.trace[((size_t)(b * n_slices + slice) % TRACE_WG) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
+#ifdef DDX_TRACE_HEAD
+    if (E.trace && tid == 0 && blockDim.x == 256) E.trace[((size_t)(b * n_slices + slice) % TRACE_WG) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     // ---- whole-frame background depth term: sum_i w_i |dbg - g_i| and sum_i w_i sgn(dbg - g_i) (w = |seg0|, g = observed depth)
     // from the sorted list: k1 = #(g < dbg), k2 = #(g <= dbg) by a 64-way search per round on the last wave (no barrier), then
@@ -1517,6 +1607,49 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
             if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
             if (E.eval_grad) E.eval_loss[(size_t)lane * B + b] = v;
             else E.b.loss_log[((size_t)j * 4 + lane) * B + b] = v;
+        }
+        // ---- arg-min over the hypotheses inside this launch (ddx_engine_run_select; get_argmin / get_pose, diffdope.py:1488-1513,
+        // 1618-1632): the mean of the used loss rows exactly as select_best_kernel forms it, ties to the lowest index
+        if (SEL && writer && E.sel_out) {
+            float v = 0.f;
+            if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
+            if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
+            if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
+            if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
+            const float v0 = __shfl(v, 0, 64), v1 = __shfl(v, 1, 64), v2 = __shfl(v, 2, 64), v3 = __shfl(v, 3, 64);
+            if (lane == 0) {
+                float a = 0.f;
+                int n_used = 0;
+                if (d.use_rgb) { a += v0; ++n_used; }
+                if (d.use_depth) { a += v1; ++n_used; }
+                if (d.use_mask) { a += v2; ++n_used; }
+                if (d.use_edge) { a += v3; ++n_used; }
+                a = __fdiv_rn(a, (float)max(n_used, 1));
+                if (a == a) {  // (a NaN loss never wins: select_best_kernel's comparisons)
+                    unsigned u = __float_as_uint(a);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    atomicMin(&E.st->sel_key, ((unsigned long long)u << 32) | (unsigned)b);
+                }
+                __builtin_amdgcn_s_waitcnt(0);  // the key has been folded in before this workgroup counts itself
+                const int arrived = __hip_atomic_fetch_add(&E.st->sel_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived == B - 1) {  // the last hypothesis: every key is in
+                    const unsigned long long key = __hip_atomic_load(&E.st->sel_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int w = 0;
+                    float best = INFINITY;
+                    if (key != ~0ull) {
+                        unsigned ub = (unsigned)(key >> 32);
+                        ub = (ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub;
+                        best = __uint_as_float(ub);
+                        w = (int)(unsigned)(key & 0xffffffffull);
+                    }
+                    E.sel_out[0] = best;
+                    E.sel_out[1] = (float)(w + E.sel_lo);
+                    const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the step_kernel that drew it)
+                    for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
+                    __hip_atomic_store(&E.st->sel_key, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&E.st->sel_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         // d loss / d mtx = proj^T . dFinal (+ direct depth row): lane = k*4 + j
         if (lane < 16) {
@@ -1692,6 +1825,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
         if (tid == 0) {
             E.inside[b] = inside_all ? 1 : 0;
             E.L.bigcount[(size_t)(1 - par) * B + b] = 0;  // the other parity's list of large triangles: consumed, nobody reads it now
+            E.L.bigarrive[(size_t)(1 - par) * B + b] = 0;
             if (b == 0) {
                 E.L.counters[3 + (1 - par)] = 0;  // ... and its "a large triangle exists" word
                 E.st->it_next = it + 1;           // (read by big_pass / shade / edge of this iteration)
@@ -1750,9 +1884,17 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
 #pragma unroll
             for (int q = 0; q < TPL; ++q) tr[q] = E.mtri[(size_t)mn * NTRI + q * NTH + tid];
         }
+#ifdef DDX_TRACE_HEAD
+        if (mk == 0) STAMP(E, 0, wg_id, 3);
+#else
         STAMP(E, 0, wg_id, mk == 0 ? 3 : 5);
+#endif
         scatter_resolve<TPL, NTH, MODE>(tg, d.H, d.W, d.T, t, i0, i1, i2, ok, va, vb, vc, cull);
+#ifdef DDX_TRACE_HEAD
+        if (mk == 0) STAMP(E, 0, wg_id, 4);
+#else
         STAMP(E, 0, wg_id, mk == 0 ? 4 : 6);
+#endif
         __syncthreads();  // (s_clip / s_snap are rewritten by the next meshlet)
         if (rec) {  // (set-up's calibration launch only)
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -1790,9 +1932,10 @@ __device__ __forceinline__ void finish_wg(const EngineDev& E, int b, int slice, 
     __shared__ float snew[8];
     __shared__ float sc[64];
     const int it = it_arg >= 0 ? it_arg : E.st->it, par = it & 1;
-    update_head<256>(E, b, it - 1, slice, n_slices, snew, sc);
+    update_head<256, true>(E, b, it - 1, slice, n_slices, snew, sc);
     if (slice == 0 && threadIdx.x == 0) {
         E.L.bigcount[(size_t)(1 - par) * E.d.B + b] = 0;
+        E.L.bigarrive[(size_t)(1 - par) * E.d.B + b] = 0;
         if (b == 0) E.L.counters[3 + (1 - par)] = 0;
     }
 }
@@ -2026,22 +2169,21 @@ static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
     if (ev) DDX_HIP(hipEventRecord(ev[K_BIG], s));
-    {
+    if (!E.big_inline) {
         RoctxRange rr("ddx.big_pass_kernel");
         big_pass_kernel<<<BIG_GRID, BIG_WAVES * 64, 0, s>>>(E, it);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
     {
         RoctxRange rr("ddx.shade_kernel");
-        dim3 g = shade_grid(d);
-        g.z = E.n_roles;
+        const dim3 g(d.B, E.s_shade, E.n_roles + (E.big_inline ? 1 : 0));  // (the slices fixed at creation: the partial rows are laid out for them)
         if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E, it);
         else shade_kernel<false><<<g, 256, 0, s>>>(E, it);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
     if (d.use_edge) {
         RoctxRange rr("ddx.edge_kernel");
-        edge_kernel<<<edge_grid(d), 256, 0, s>>>(E, it);
+        edge_kernel<<<dim3(d.B, E.s_edge), 256, 0, s>>>(E, it);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_FINISH], s));
     DDX_LAUNCH_CHECK();
@@ -2101,6 +2243,8 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
     e->dev.b = *bufs;
     e->dev.eval_grad = nullptr;
     e->dev.eval_loss = nullptr;
+    e->dev.sel_out = nullptr;
+    e->dev.sel_lo = 0;
     {
         EngineDev& E = e->dev;
         // shade roles: 0 colour/depth (also runs for the edge term: it produces the luminance + unit gradients that
@@ -2137,6 +2281,13 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         E.step_xcd = 0;  // (launch_step switches to the slot-major grid when it balances the shares)
         if (const char* ov = getenv("DDX_STEP_XCD")) E.step_xcd = atoi(ov) != 0;
         E.slot_table = 0; E.mcost_rec = 0;
+        // the tile pass inside the shading launch (big_worker_wg): hypothesis b's workgroups all on XCD b % 8.
+        // Whether this engine uses it is decided by the set-up (engine_setup: are large triangles to be expected at all?)
+        e->inline_ok = !desc->separate_big_pass && desc->B % 8 == 0;
+        if (const char* ov = getenv("DDX_BIG_INLINE")) e->inline_env = atoi(ov) != 0;
+        E.big_inline = 0;
+        E.big_workers = 64;
+        if (const char* ov = getenv("DDX_BIG_WORKERS")) E.big_workers = std::max(1, atoi(ov));
         E.scatter_mode = 0;
         E.n_meshlets = 0;
         for (int c = 0; c < 6; ++c) E.bbox[c] = 0.f;
@@ -2230,6 +2381,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
 {
     EngineDev& E = e->dev;
     DDX_HIP(hipMemsetAsync(E.st, 0, sizeof(EngineState), s));
+    DDX_HIP(hipMemsetAsync(&E.st->sel_key, 0xFF, sizeof(unsigned long long), s));
     DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)2 * 14 * E.d.B * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // (both parities) kept zero by update_head afterwards
     DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));   // (both parities) re-armed per active tile by update_head
@@ -2370,6 +2522,29 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             DDX_LAUNCH_CHECK();
             DDX_HIP(hipStreamSynchronize(s));  // (the host vectors above are the copy sources)
         }
+        // size of the mesh's triangles in object space (engine_setup's estimate of whether a hypothesis will have LARGE triangles)
+        {
+            double area = 0.0, emax = 0.0;
+            for (int t = 0; t < T; ++t) {
+                const int i0 = htri[(size_t)t * 3], i1 = htri[(size_t)t * 3 + 1], i2 = htri[(size_t)t * 3 + 2];
+                if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= V || i1 >= V || i2 >= V) continue;
+                double p[3][3];
+                const int iv[3] = {i0, i1, i2};
+                for (int k = 0; k < 3; ++k)
+                    for (int c = 0; c < 3; ++c) p[k][c] = hpos[(size_t)iv[k] * 3 + c];
+                double e1[3], e2[3], e3[3];
+                for (int c = 0; c < 3; ++c) { e1[c] = p[1][c] - p[0][c]; e2[c] = p[2][c] - p[0][c]; e3[c] = p[2][c] - p[1][c]; }
+                const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                const double a2 = std::sqrt(cx * cx + cy * cy + cz * cz);
+                if (std::isfinite(a2)) area += 0.5 * a2;
+                for (const double* ed : {e1, e2, e3}) {
+                    const double l = std::sqrt(ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2]);
+                    if (std::isfinite(l) && l > emax) emax = l;
+                }
+            }
+            e->mesh_area = area;
+            e->mesh_max_edge = emax;
+        }
         // object-space bounding box of ALL vertices (the view-volume test of the culling rule, EngineDev::cull_sign)
         bool finite = true;
         for (int v = 0; v < V; ++v)
@@ -2502,6 +2677,22 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
         if (!E.scatter_mode && (long long)E.n_meshlets * E.d.B >= 6000) E.scatter_mode = 3;
         if (const char* ov = getenv("DDX_SCATTER_EXCHANGE")) { const int v = atoi(ov); E.scatter_mode = v <= 0 ? 0 : (v >= 2 ? 3 : 2); }  // 0 plain, 1 hybrid, 2 compacting
         if (const char* ov = getenv("DDX_SCATTER_MODE")) { const int v = atoi(ov); E.scatter_mode = (v == 2 || v == 3) ? v : 0; }
+        // ---- where the tile pass for LARGE triangles runs.  As its own launch between step_kernel and shade_kernel it costs a kernel
+        // boundary in every iteration (2.4 of cfg2's 43 us) and exits at once when the batch has no such triangle -- the dense meshes of
+        // the benchmark never have one.  So: when no large triangle is to be EXPECTED, the launch is dropped and shade_kernel runs the
+        // pass itself for a hypothesis that turns out to have some (big_inline_pass: correct, slower than the launch).  Expected size:
+        // the observed object covers n_px pixels and shows about a quarter of the mesh's area (a convex body projects to area / 4 on
+        // average), so one unit of object-space length is about sqrt(4 n_px / area) pixels and the longest edge of the mesh spans
+        // that many pixels times its length; a triangle goes to the tile pass when its bounding box holds more than 64 pixel centres.
+        {
+            const double n_px = hst.c_mask / 3.0;
+            const double px_per_unit = (e->mesh_area > 0.0 && n_px > 0.0) ? std::sqrt(4.0 * n_px / e->mesh_area) : 1e30;
+            const double edge_px = e->mesh_max_edge * px_per_unit;
+            bool expect_none = edge_px < 4.0;  // (a bounding box of 16 centres where 64 are allowed: hypotheses start nearer than the object is)
+            if (e->inline_env >= 0) expect_none = e->inline_env != 0;
+            E.big_inline = (e->inline_ok && expect_none) ? 1 : 0;
+            if (getenv("DDX_DEBUG_INLINE")) fprintf(stderr, "ddx: longest edge ~%.2f px, inline tile pass %d (allowed %d)\n", edge_px, E.big_inline, (int)e->inline_ok);
+        }
         // grid z order of the shading launch (engine_create: mask role first).  On CLOSE-UPS of a textured object the other order is
         // 5 % faster (object at 7-21 % of the frame: 9.76 -> 10.25, 7.78 -> 8.15, 5.97 -> 6.28, 4.53 -> 4.75 k it/s) and 3-5 % slower
         // below (1.2 %, 4.7 %: the crossover lies at 12-14 tiles per shading workgroup) and on untextured large-triangle meshes.
@@ -2519,7 +2710,21 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
     return 0;
 }
 
+static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* stream, float* sel_out, int sel_lo);
+
 extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream)
+{
+    return engine_run_impl(e, it0, n, use_graph, stream, nullptr, 0);
+}
+
+extern "C" int ddx_engine_run_select(ddx_engine* e, int it0, int n, int use_graph, int lo, float* out18, void* stream)
+{
+    DDX_REQUIRE(out18, DDX_E_NULL, "engine_run_select: NULL out18");
+    DDX_REQUIRE(n >= 1, DDX_E_SHAPE, "engine_run_select: n = %d (the selection rides on the run's last kernel)", n);
+    return engine_run_impl(e, it0, n, use_graph, stream, out18, lo);
+}
+
+static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* stream, float* sel_out, int sel_lo)
 {
     DDX_REQUIRE(e, DDX_E_NULL, "engine_run: NULL engine");
     e->fwd_cached_it = -1;
@@ -2560,7 +2765,11 @@ extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void
             ++i;
         }
     }
-    if (int err = launch_finish(e, it0 + n, s)) return err;
+    e->dev.sel_out = sel_out;  // (finish_kernel's by-value copy of the arguments carries it)
+    e->dev.sel_lo = sel_lo;
+    const int ferr = launch_finish(e, it0 + n, s);
+    e->dev.sel_out = nullptr;
+    if (ferr) return ferr;
     e->adam_parity = (it0 + n) & 1;
     return 0;
 }
@@ -2762,6 +2971,7 @@ struct ddx_engine_group {
     std::vector<EngineDev> h_tab;
     std::vector<unsigned> gen_up;      // set-up generation of each member when its row was uploaded (0 = never)
     bool uploaded = false;
+    bool big_inline = false;  // decided with the table upload
 };
 
 extern "C" int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_group** out)
@@ -2858,8 +3068,8 @@ static int group_rest(ddx_engine_group* g, int it, hipStream_t s)
         smax = std::max(smax, e->dev.s_shade);
         if (e->dev.d.use_edge) { edge = true; semax = std::max(semax, e->dev.s_edge); }
     }
-    big_pass_group_kernel<<<dim3(BIG_GRID, H.n), BIG_WAVES * 64, 0, s>>>(g->d_tab, H, it);
-    const dim3 gs(H.bpre[H.n], smax, 2);
+    if (!g->big_inline) big_pass_group_kernel<<<dim3(BIG_GRID, H.n), BIG_WAVES * 64, 0, s>>>(g->d_tab, H, it);
+    const dim3 gs(H.bpre[H.n], smax, g->big_inline ? 3 : 2);
     if (edge) shade_group_kernel<true><<<gs, 256, 0, s>>>(g->d_tab, H, it);
     else shade_group_kernel<false><<<gs, 256, 0, s>>>(g->d_tab, H, it);
     if (edge) edge_group_kernel<<<dim3(H.bpre[H.n], semax), 256, 0, s>>>(g->d_tab, H, it);
@@ -2890,10 +3100,23 @@ extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* s
     for (auto* e : g->members)
         if (int err = run_prologue(e, it0, s)) return err;
     if (fresh) {  // (set-up fills fields of EngineDev: meshlet count, culling sign, scatter variant, bounding box, seg list size)
+        int smax = 1, btot = 0;
+        bool edge = false, all_inline = true;
+        for (auto* e : g->members) {
+            smax = std::max(smax, e->dev.s_shade);
+            btot += e->dev.d.B;
+            edge = edge || e->dev.d.use_edge;
+            all_inline = all_inline && e->dev.big_inline;
+        }
+        g->big_inline = all_inline;  // (every member a multiple of 8 hypotheses: so is every prefix, and hypothesis x of the launch sits on XCD x % 8)
+        (void)smax; (void)btot; (void)edge;
+        if (getenv("DDX_DEBUG_INLINE")) fprintf(stderr, "ddx group: inline tile pass %d\n", (int)g->big_inline);
         for (size_t i = 0; i < g->members.size(); ++i) {
             g->h_tab[i] = g->members[i]->dev;
             g->h_tab[i].eval_grad = nullptr;
             g->h_tab[i].eval_loss = nullptr;
+            g->h_tab[i].sel_out = nullptr;
+            g->h_tab[i].big_inline = g->big_inline ? 1 : 0;
             g->h_tab[i].slot_table = 0;  // (a group's grid has its own dispatch order: equal shares)
             g->h_tab[i].mcost_rec = 0;
             g->gen_up[i] = g->members[i]->setup_gen;
@@ -2944,3 +3167,7 @@ extern "C" void ddx_engine_destroy(ddx_engine* e)
     if (e->graph) (void)hipGraphDestroy(e->graph);
     delete e;
 }
+
+#ifdef DDX_EXPERIMENTS  // variant builds only (tools/build_variant.py): measurement code that is not part of the product
+#include "tools/experiments/stagger_exp.inc"
+#endif

@@ -15,6 +15,7 @@ struct RasterScratch {
     int2* snap;               // [B,V] window coordinates in 1/256 px (x = INT_MIN if w <= 0)
     uint2* biglist;           // [B,T] the LARGE triangles of each hypothesis: (triangle id, packed tile range tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24)
     int* bigcount;            // [npar][B] entries of biglist (appended by the scatter pass, one atomic per wave; re-armed by the consumer)
+    int* bigarrive;           // [npar][B] workgroups of shade_kernel that finished their share of the hypothesis' tile pass (engine, inline tile pass)
     unsigned long long* zbuf; // [npar][B, zper] (depth key << 32 | triangle id), all ones = background; per hypothesis the frame is
                               // stored in 4x4-pixel blocks (16 entries = one 128-byte line), see zaddr()
     size_t zbuf_bytes;        // all parities
@@ -24,7 +25,7 @@ struct RasterScratch {
     // bigcount, the "large triangle" word -- so that the kernel that rasterises iteration i + 1 can re-arm what iteration i
     // dirtied while it draws (engine.hip: step_kernel).  The op-level entry has one copy (npar = 1) and memsets it.
     int npar;
-    size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount)
+    size_t zero_bytes;        // bytes from `counters` that must be zero before a pass (counters + tile_flag + tile_big + bigcount + bigarrive)
     int ntx, nty, NT;
     int NTp;                  // bytes per hypothesis row of tile_flag / tile_big: NT rounded up to 256 (dword loads of a row stay inside it)
     PixNdc ndc;               // pixel index -> NDC centre constants for (H, W)

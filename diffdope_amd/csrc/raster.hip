@@ -42,7 +42,8 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     const size_t o_flag = carve((size_t)npar * B * NTp);
     const size_t o_big = carve((size_t)npar * B * NTp);
     const size_t o_bigcount = carve((size_t)npar * B * sizeof(int));
-    L.zero_bytes = off;  // [counters | tile_flag | tile_big | bigcount] must be zero when a pass starts
+    const size_t o_bigarrive = carve((size_t)npar * B * sizeof(int));
+    L.zero_bytes = off;  // [counters | tile_flag | tile_big | bigcount | bigarrive] must be zero when a pass starts
     const size_t o_active = carve((size_t)B * NT * sizeof(int));
     const size_t o_bcount = carve((size_t)B * sizeof(int));
     const size_t o_snap = carve((size_t)B * V * sizeof(int2));
@@ -58,6 +59,7 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.snap = (int2*)(p + o_snap);
     L.biglist = (uint2*)(p + o_range);
     L.bigcount = (int*)(p + o_bigcount);
+    L.bigarrive = (int*)(p + o_bigarrive);
     L.zbuf = (unsigned long long*)(p + o_zbuf);
     L.zbuf_bytes = (size_t)npar * B * zper * sizeof(unsigned long long);
     L.zper = zper;

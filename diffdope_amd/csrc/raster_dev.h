@@ -398,45 +398,26 @@ __device__ __attribute__((noinline)) static int clip_near_call(const float4& p0,
 // tile_big [B, NTp] bytes; snap [B,V]; pos [B,V,4]; biglist [B,T]; bigcount [B]; zbuf [B, zper].
 #define BIG_SCAN 1024  // (hypothesis, tile) flags scanned per step of the large-triangle pass
 
-template <int NWB /* waves per workgroup: 4 (op-level, 1024 workgroups) or 16 (engine: 256 workgroups of 1024 threads -- the same number
-                     of tiles in flight, and a launch that exits at once when the batch has no large triangle costs 256 dispatches) */>
-__device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, const int* __restrict__ tri, const int2* __restrict__ snap,
-                                              const unsigned char* __restrict__ tile_big, const uint2* __restrict__ biglist,
-                                              const int* __restrict__ bigcount, unsigned long long* __restrict__ zbuf, size_t zper, int zwb, int ntx,
-                                              int NT, int NTp, int B, int V, int T, int H, int W, int g, int G, unsigned long long& n_done)
+// The staging arrays of one wave of the tile pass (LDS): NS staged triangles per round.
+template <int NS>
+struct BigStage {
+    int4 e0[NS], e1[NS], e2[NS];  // per edge (e.lo, e.hi, step x, step y) at the tile origin
+    float4 p0[NS], p1[NS], p2[NS];  // ... the triangles' clip-space vertices
+    int t[NS];                      // ... their ids
+    int cand[256];                  // range-test survivors of 256 list entries
+};
+
+// ONE large tile by one wave: P / S / BL / zb are the hypothesis' own rows (clip vertices, snapped vertices, list, zbuf).
+// NS = 64: every round of 64 candidates is staged at once (the tile-pass kernels); NS = 16: in chunks of 16 hits (the pass run
+// from inside shade_kernel on 3 KB of LDS per wave).  Same triangles, same keys, min() does not care about the order.
+template <int NS>
+__device__ __forceinline__ void big_tile_wave(BigStage<NS>& st_, const float* __restrict__ P, const int* __restrict__ tri, const int2* __restrict__ S,
+                                              const uint2* __restrict__ BL, int n_big, unsigned long long* __restrict__ zb, int zwb, int ntx,
+                                              int tile, int H, int W)
 {
-    __shared__ int4 s_e0[NWB][64], s_e1[NWB][64], s_e2[NWB][64];  // staged LARGE triangles of each wave's tile: per edge (e.lo, e.hi, step x, step y) at the tile origin
-    __shared__ int s_t[NWB][64];                              // ... their ids
-    __shared__ int s_cand[NWB][256];                          // range-test survivors of 256 list entries (per wave)
-    __shared__ float4 s_p0[NWB][64], s_p1[NWB][64], s_p2[NWB][64];  // ... and their clip-space vertices
-    __shared__ int s_big[BIG_SCAN];
-    __shared__ int s_nbig;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per_b = (NT + G - 1) / G;          // candidate tiles per hypothesis for this workgroup
-    const int n_cand = B * per_b;
-    for (int base = 0; base < n_cand; base += BIG_SCAN) {
-    __syncthreads();
-    if (tid == 0) s_nbig = 0;
-    __syncthreads();
-    for (int j = base + tid; j < min(n_cand, base + BIG_SCAN); j += NWB * 64) {
-        const int bb = j / per_b, kk = j - bb * per_b;
-        int t0 = (g - 13 * bb) % G;
-        if (t0 < 0) t0 += G;
-        const int tile = t0 + kk * G;
-        if (tile < NT) {
-            if (tile_big[(size_t)bb * NTp + tile] != 0) s_big[atomicAdd(&s_nbig, 1)] = bb * NT + tile;  // LDS atomic; the order does not matter (atomicMin below)
-        }
-    }
-    __syncthreads();
-    const int nbig = s_nbig;
-    for (int e = wave; e < nbig; e += NWB) {  // (wave-uniform)
-        const int flat = s_big[e];
-        const int b = flat / NT, tile = flat - b * NT;
-        const int tcx = tile % ntx, tcy = tile / ntx;
-        const float* P = pos + (size_t)b * V * 4;
-        const int2* S = snap + (size_t)b * V;
-        const uint2* BL = biglist + (size_t)b * T;
-        const int n_big = min(bigcount[b], T);
+    const int lane = threadIdx.x & 63;
+    const int tcx = tile % ntx, tcy = tile / ntx;
+    {
         const int lx = lane % DDX_TILE, ly0 = lane / DDX_TILE;  // pixels (lx, ly0 + 4 q), q = 0..3
         const int px = tcx * DDX_TILE + lx;
         unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
@@ -458,7 +439,7 @@ __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, con
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const unsigned long long mu = __ballot(in[u]);
-                    if (in[u]) s_cand[wave][ncand + __popcll(mu & ((1ull << lane) - 1ull))] = (int)en[u].x;
+                    if (in[u]) st_.cand[ncand + __popcll(mu & ((1ull << lane) - 1ull))] = (int)en[u].x;
                     ncand += __popcll(mu);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -470,7 +451,7 @@ __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, con
             // dependent gather chain per triangle and pixel loop step
             const int idx = r0 + lane;
             const bool cand = idx < ncand;
-            const unsigned ent_id = cand ? (unsigned)s_cand[wave][idx] : 0u;  // bit 31: a near-plane straddler (see scatter_one)
+            const unsigned ent_id = cand ? (unsigned)st_.cand[idx] : 0u;  // bit 31: a near-plane straddler (see scatter_one)
             const int t_id = (int)(ent_id & 0x7fffffffu);
             // the snapped triangle(s) of the candidate: its own three vertices, or -- for a triangle with a vertex at w <= 0 --
             // the one or two triangles of its near-clipped polygon (clip_near; fragments still come from the original triangle)
@@ -531,21 +512,25 @@ __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, con
             const unsigned long long m = __ballot(hit);
             const int nh = __popcll(m);
             if (nh == 0) continue;  // (wave-uniform)
-            if (hit) {
-                const int slot = __popcll(m & ((1ull << lane) - 1ull));
-                s_e0[wave][slot] = es[0]; s_e1[wave][slot] = es[1]; s_e2[wave][slot] = es[2];
-                s_t[wave][slot] = t_id;
-                const bool have = (ent_id >> 31) != 0u;  // (a straddler's clip-space vertices are already here)
-                s_p0[wave][slot] = have ? cp0 : ld4(P + (size_t)i0 * 4);
-                s_p1[wave][slot] = have ? cp1 : ld4(P + (size_t)i1 * 4);
-                s_p2[wave][slot] = have ? cp2 : ld4(P + (size_t)i2 * 4);
+            const int slot = __popcll(m & ((1ull << lane) - 1ull));
+            float4 q0v = cp0, q1v = cp1, q2v = cp2;
+            if (hit && !(ent_id >> 31)) {  // (a straddler's clip-space vertices are already here)
+                q0v = ld4(P + (size_t)i0 * 4); q1v = ld4(P + (size_t)i1 * 4); q2v = ld4(P + (size_t)i2 * 4);
+            }
+          for (int h0 = 0; h0 < nh; h0 += NS) {  // (one trip when NS = 64)
+            if (hit && slot >= h0 && slot < h0 + NS) {
+                const int sl_ = slot - h0;
+                st_.e0[sl_] = es[0]; st_.e1[sl_] = es[1]; st_.e2[sl_] = es[2];
+                st_.t[sl_] = t_id;
+                st_.p0[sl_] = q0v; st_.p1[sl_] = q1v; st_.p2[sl_] = q2v;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- lane = 4 pixels of the tile over the staged triangles (wave-uniform walk, LDS broadcast reads)
             if (px < W) {
-                for (int j = 0; j < nh; ++j) {
-                    const int4 q0 = s_e0[wave][j], q1 = s_e1[wave][j], q2 = s_e2[wave][j];
+                const int nj = min(NS, nh - h0);
+                for (int j = 0; j < nj; ++j) {
+                    const int4 q0 = st_.e0[j], q1 = st_.e1[j], q2 = st_.e2[j];
                     const long long c0 = (((long long)q0.y << 32) | (unsigned)q0.x) + (long long)(lx * DDX_SUBPIX) * q0.z;
                     const long long c1 = (((long long)q1.y << 32) | (unsigned)q1.x) + (long long)(lx * DDX_SUBPIX) * q1.z;
                     const long long c2 = (((long long)q2.y << 32) | (unsigned)q2.x) + (long long)(lx * DDX_SUBPIX) * q2.z;
@@ -555,7 +540,7 @@ __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, con
                         const long long v0 = c0 + (long long)(ly * DDX_SUBPIX) * q0.w, v1 = c1 + (long long)(ly * DDX_SUBPIX) * q1.w,
                                         v2 = c2 + (long long)(ly * DDX_SUBPIX) * q2.w;
                         if ((v0 | v1 | v2) < 0 || py >= H) continue;
-                        const unsigned long long key = frag_key(s_p0[wave][j], s_p1[wave][j], s_p2[wave][j], px, py, H, W, s_t[wave][j]);
+                        const unsigned long long key = frag_key(st_.p0[j], st_.p1[j], st_.p2[j], px, py, H, W, st_.t[j]);
                         best[q] = key < best[q] ? key : best[q];
                     }
                 }
@@ -563,13 +548,51 @@ __device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, con
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();  // (the staging arrays are rewritten by the next round)
           }
+          }
         }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int py = tcy * DDX_TILE + ly0 + 4 * q;
-            if (best[q] != ~0ull) atomicMin(zbuf + (size_t)b * zper + zaddr(px, py, zwb), best[q]);
+            if (best[q] != ~0ull) atomicMin(zb + zaddr(px, py, zwb), best[q]);
         }
+    }
+}
+
+template <int NWB /* waves per workgroup: 4 (op-level, 1024 workgroups) or 16 (engine: 256 workgroups of 1024 threads -- the same number
+                     of tiles in flight, and a launch that exits at once when the batch has no large triangle costs 256 dispatches) */>
+__device__ __forceinline__ void big_pass_body(const float* __restrict__ pos, const int* __restrict__ tri, const int2* __restrict__ snap,
+                                              const unsigned char* __restrict__ tile_big, const uint2* __restrict__ biglist,
+                                              const int* __restrict__ bigcount, unsigned long long* __restrict__ zbuf, size_t zper, int zwb, int ntx,
+                                              int NT, int NTp, int B, int V, int T, int H, int W, int g, int G, unsigned long long& n_done)
+{
+    __shared__ BigStage<64> s_stage[NWB];  // staged LARGE triangles of each wave's tile
+    __shared__ int s_big[BIG_SCAN];
+    __shared__ int s_nbig;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int per_b = (NT + G - 1) / G;          // candidate tiles per hypothesis for this workgroup
+    const int n_cand = B * per_b;
+    for (int base = 0; base < n_cand; base += BIG_SCAN) {
+    __syncthreads();
+    if (tid == 0) s_nbig = 0;
+    __syncthreads();
+    for (int j = base + tid; j < min(n_cand, base + BIG_SCAN); j += NWB * 64) {
+        const int bb = j / per_b, kk = j - bb * per_b;
+        int t0 = (g - 13 * bb) % G;
+        if (t0 < 0) t0 += G;
+        const int tile = t0 + kk * G;
+        if (tile < NT) {
+            if (tile_big[(size_t)bb * NTp + tile] != 0) s_big[atomicAdd(&s_nbig, 1)] = bb * NT + tile;  // LDS atomic; the order does not matter (atomicMin below)
+        }
+    }
+    __syncthreads();
+    const int nbig = s_nbig;
+    for (int e = wave; e < nbig; e += NWB) {  // (wave-uniform)
+        const int flat = s_big[e];
+        const int b = flat / NT, tile = flat - b * NT;
+        const int n_big = min(bigcount[b], T);
+        big_tile_wave<64>(s_stage[wave], pos + (size_t)b * V * 4, tri, snap + (size_t)b * V, biglist + (size_t)b * T, n_big,
+                          zbuf + (size_t)b * zper, zwb, ntx, tile, H, W);
         if (wave == 0) n_done += 1 + ((unsigned long long)n_big << 32);
     }
     }

@@ -85,6 +85,30 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
     return int(t[row, 1]), float(t[row, 0]), torch.from_numpy(t[row, 2:].copy()).reshape(4, 4)  # (the pose on the HOST, as in the one-process path)
 
 
+def run_and_select(eng, n, lo=0, group=None, use_graph=False):
+    """eng.run(n) + global_argmin_fused of its last iteration with the local selection folded into the run's LAST kernel
+    (ddx_engine_run_select): no selection launch, and in one process the 18 floats land in pinned host memory, so the end of a
+    run is one kernel and one synchronisation.  Returns (global index, loss, pose [4,4] on the host), identical on every rank."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        with _PINNED_LOCK:
+            table = _pinned_row()
+            eng.run_select(table, n, lo=lo, use_graph=use_graph)
+            torch.cuda.current_stream().synchronize()
+            t = table.numpy()
+            return int(t[0, 1]), float(t[0, 0]), table[0, 2:].clone().reshape(4, 4)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    table = torch.zeros((world, 18), dtype=torch.float32, device=eng.params.device)
+    eng.run_select(table[rank], n, lo=lo, use_graph=use_graph)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    t = table.cpu().numpy()
+    losses, gidx = t[:, 0], t[:, 1]
+    cand = [(gidx[r], r) for r in range(world) if losses[r] == losses.min()]
+    row = min(cand)[1]
+    return int(t[row, 1]), float(t[row, 0]), torch.from_numpy(t[row, 2:].copy()).reshape(4, 4)
+
+
 import threading
 
 _PINNED = None

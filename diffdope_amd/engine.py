@@ -47,11 +47,13 @@ class RefineEngine:
             switchable, nvdiffrast's (D2: the rasterize backward differentiates the unclamped barycentrics; ddx.h DDX_COMPAT_*)
         cull_backfaces: skip the back faces of a closed mesh while a hypothesis lies inside the view volume (ddx.h
             no_backface_cull; identical visibility in exact arithmetic).  False = always draw both faces.
+        separate_big_pass: True = the tile pass for large / near-clipped triangles as its own launch instead of inside the shading
+            kernel (ddx.h separate_big_pass): for engines that run next to several others on one device (one stream each).
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
                  vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True, shade_slices=0,
-                 edge_slices=0, cull_backfaces=True, compat=None):
+                 edge_slices=0, cull_backfaces=True, compat=None, separate_big_pass=False):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":
@@ -94,6 +96,7 @@ class RefineEngine:
         d.max_iters = n_it
         d.shade_slices, d.edge_slices = int(shade_slices), int(edge_slices)
         d.no_backface_cull = int(not cull_backfaces)
+        d.separate_big_pass = int(bool(separate_big_pass))
         d.compat = {None: 0, "nvdiffrast": _lib.COMPAT_UNCLAMPED_BARY_GRAD}[compat]
         self.desc = d
         nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))
@@ -121,6 +124,16 @@ class RefineEngine:
         stream launches measured 9 % faster than k = 1 and equal to k = 20 on MI355X, so streams are the default."""
         n = self.max_iters - self.it if n is None else n
         _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
+        self.it += n
+
+    def run_select(self, out18, n=None, lo=0, use_graph=False):
+        """run(n) with the arg-min selection of its last iteration folded into the run's last kernel (ddx_engine_run_select):
+        `out18` -- an 18-float tensor in device memory or PINNED host memory -- receives (mean loss of the best local
+        hypothesis over the enabled terms, lo + its index, its 4x4 pose), as ddx_select_best would write it."""
+        n = self.max_iters - self.it if n is None else n
+        assert out18.dtype == torch.float32 and out18.numel() >= 18 and out18.is_contiguous() and (out18.is_cuda or out18.is_pinned())
+        _lib.check(self.lib.ddx_engine_run_select(self.handle, self.it, n, int(use_graph), int(lo), out18.data_ptr(), _lib.stream_ptr()),
+                   "ddx_engine_run_select")
         self.it += n
 
     def new_observation(self, gt=None, params=None, lr_mult=None, lr_sched=None):
@@ -186,7 +199,7 @@ class RefineEngine:
         self.it = it
 
     def status(self):
-        """dict(overflow (always 0), big_triangles (0/1: the tile pass ran), active_tiles, it (the last iteration drawn), n_seg,
+        """dict(overflow (0; 2 = a wait of the inline tile pass timed out, see check()), big_triangles (0/1: the tile pass ran), active_tiles, it (the last iteration drawn), n_seg,
         outside_view_volume (hypotheses of the last iteration whose bounding box had a corner at w <= 0 or |z| > w: near-plane
         clipping and two-sided drawing for those)) -- synchronises."""
         p = self.lib.ddx_engine_status_ptr(self.handle)
@@ -197,7 +210,8 @@ class RefineEngine:
     def check(self):
         st = self.status()
         if st["overflow"]:
-            raise RuntimeError("engine reported an internal overflow")
+            raise RuntimeError("engine status word 0 = %d: a wait of the inline tile pass did not end (too many engines with large triangles "
+                               "running at once on this device: create them with separate_big_pass=True); results are invalid" % st["overflow"])
         return st
 
     def profile(self, it0=0, iters=5):

@@ -201,7 +201,14 @@ typedef struct ddx_engine_desc {
      * arithmetic (deviation D5) and halves the fragment work.  Environment DDX_NO_CULL=1 also disables. */
     int32_t no_backface_cull;
     int32_t compat;   /* DDX_COMPAT_* bits for this engine (0 = this build's documented behaviour) */
-    int32_t reserved[2];
+    /* 0 (default): when the batch allows it (B a multiple of 8, the shading launch resident as a whole) the tile pass for large /
+     * near-clipped triangles runs inside the shading kernel, only for hypotheses that have such triangles, and the launch between
+     * the rasterising and the shading kernel is dropped.  Its workgroups meet at a counter: engines that
+     * share the device with MORE THAN ONE other engine running at the same time (one stream per object) set this to 1 -- the
+     * separate launch, no waiting inside a kernel.  A wait that does not end sets status word 0 to 2 instead of hanging.
+     * Environment DDX_BIG_INLINE=0 also selects the separate launch.  Same results either way. */
+    int32_t separate_big_pass;
+    int32_t reserved[1];
 } ddx_engine_desc;
 
 typedef struct ddx_engine_buffers {
@@ -243,6 +250,12 @@ int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_buffers* buf
  * also the per-meshlet times of its first launch, once) and therefore synchronises `stream`; that call must not be made while
  * `stream` is being captured (the meshlet calibration is skipped inside a capture rather than breaking it). */
 int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
+/* ddx_engine_run (n >= 1) with the selection of the best local hypothesis folded into the run's LAST kernel -- get_argmin / get_pose
+ * (diffdope/diffdope.py:1488-1513, 1618-1632) for iteration it0 + n - 1 without a further launch: out18 (18 floats; device memory
+ * or mapped pinned host memory) receives what ddx_select_best writes for that iteration's rows -- (mean over the engine's enabled
+ * loss terms of the winner's weighted losses, lo + its local index, its 4x4 pose row-major), ties to the lowest index, a NaN
+ * loss never wins.  With out18 in mapped host memory the end of a run costs one kernel and one synchronisation. */
+int ddx_engine_run_select(ddx_engine* e, int it0, int n, int use_graph, int lo, float* out18, void* stream);
 /* Evaluation pass without an optimiser step (for callers that bring their own optimiser): renders the hypotheses
  * at the CURRENT contents of `params`, writes d loss / d params to grad_out [7,B] and the weighted, un-LR'd
  * per-hypothesis losses (rgb, depth, mask, edge) to loss_out [4,B] (may be NULL); parameters, optimiser state and logs
@@ -269,7 +282,7 @@ int ddx_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
  * lo = global index of the first local hypothesis; out18 = (mean loss of the winner, its global index, its 4x4
  * pose row-major): this rank's row of the [world,18] table that ONE all_reduce(SUM) exchanges. */
 int ddx_select_best(const float* loss_rows, int row_mask, int B, const float* mtx, int lo, float* out18, void* stream);
-/* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
+/* device int32[8] inside scratch: [0] 0, or 2 = a wait of the inline tile pass did not end (results invalid: see separate_big_pass), [1] large triangles (tile-pass) of the last
  * iteration, [2] active tiles of the last iteration, [3] internal, [4] pixels with seg != 0, [5] last iteration drawn + 1,
  * [6] hypotheses of the last iteration whose object-space bounding box had a corner outside the view volume (w <= 0 or
  * |z| > w): their triangles with a vertex at w <= 0 took the near-plane clipping path and their back faces were drawn -- 0 in any

@@ -1,0 +1,135 @@
+"""Run-to-run determinism of the engine GROUP launches (`-m gpu`).  Round 3 saw a build of shade_group_kernel give different losses
+from run to run (the inline tile pass); nothing in the suite would have caught a latent race in the shipped
+kernels, so this repeats ddx_engine_group_run of four unlike members 50 times per shading-grid size and compares every bit --
+parameters, loss log, pose log -- with the first repetition and with each member's own run."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shade_grid", [256, 512, 1024])
+def test_fifty_group_runs_give_the_same_bits(shade_grid):
+    import diffdope_amd as dd
+    from diffdope_amd import workloads as wl
+    from tests.test_gpu_group import _members
+
+    dev = torch.device("cuda")
+    n_it, reps = 5, 50
+    old = os.environ.get("DDX_SHADE_GRID")
+    os.environ["DDX_SHADE_GRID"] = str(shade_grid)  # (read by the native side when an engine is created and when it launches)
+    try:
+        specs = _members(dev, n_it, "adam")
+        engs = [wl.engine_for(w, lrs, optimizer="adam") for w, lrs in specs]
+        assert engs[0][0].lib.ddx_engine_scratch_bytes is not None
+        grp = dd.RefineEngineGroup([e for e, _ in engs])
+        first = None
+        for rep in range(reps):
+            if rep:
+                for (e, _), (w, _) in zip(engs, specs):
+                    e.new_observation(params=w["params0"])
+            grp.run()
+            grp.finish()
+            snap = [(p.clone(), e.losses().clone(), e.mtx_log.clone()) for e, p in engs]
+            for e, _ in engs:
+                e.check()
+            if first is None:
+                first = snap
+                continue
+            for k, (a, b) in enumerate(zip(first, snap)):
+                assert all(torch.equal(x, y) for x, y in zip(a, b)), f"repetition {rep}: member {k} differs from the first run (shade grid {shade_grid})"
+        # ... and the bits are those of each member's own run with the same grid
+        for k, (w, lrs) in enumerate(specs):
+            e, p = wl.engine_for(w, lrs, optimizer="adam")
+            e.run()
+            e.finish()
+            assert torch.equal(p, first[k][0]) and torch.equal(e.losses(), first[k][1]) and torch.equal(e.mtx_log, first[k][2]), f"member {k} alone"
+    finally:
+        if old is None:
+            os.environ.pop("DDX_SHADE_GRID", None)
+        else:
+            os.environ["DDX_SHADE_GRID"] = old
+
+
+@pytest.mark.parametrize("name,B,dist,must", [("lowpoly", 16, None, True), ("hugetri", 8, None, True), ("midpoly", 24, 2.5, False), ("cfg2", 16, 0.9, False)])
+def test_tile_pass_inside_the_shading_launch_equals_the_separate_launch(name, B, dist, must):
+    """Round 4: where no large triangle is expected the tile-pass launch is dropped and worker workgroups in the first slab of the
+    shading launch run the pass for a hypothesis that has some after all (engine.hip big_worker_wg).  Forced on for meshes that
+    are ALL large triangles, a mix, and a dense mesh with the camera almost inside it (near-clipped triangles): parameters, loss
+    log, pose log and status equal the separate launch bit for bit, alone and as an engine group."""
+    import diffdope_amd as dd
+    from diffdope_amd import workloads as wl
+
+    dev = torch.device("cuda")
+    n_it = 6
+    w = wl.build(name, dev, B=B, distance=dist)
+    lrs = wl.bench_lr_schedule(n_it, "adam")
+    old = os.environ.get("DDX_BIG_INLINE")
+    out = {}
+    try:
+        for mode in ("0", "1"):
+            os.environ["DDX_BIG_INLINE"] = mode  # (read when an engine is created)
+            e, p = wl.engine_for(w, lrs, optimizer="adam")
+            e.run(2)
+            e.run()
+            e.finish()
+            st = e.check()
+            e2, p2 = wl.engine_for(w, lrs, optimizer="adam")
+            e3, p3 = wl.engine_for(w, lrs, optimizer="adam")
+            g = dd.RefineEngineGroup([e2, e3])
+            g.run()
+            g.finish()
+            out[mode] = (p.clone(), e.losses().clone(), e.mtx_log.clone(), st, p2.clone(), e2.losses().clone(), p3.clone())
+    finally:
+        if old is None:
+            os.environ.pop("DDX_BIG_INLINE", None)
+        else:
+            os.environ["DDX_BIG_INLINE"] = old
+    a, b = out["0"], out["1"]
+    print(name, "large triangles in the last iteration:", a[3]["big_triangles"], "outside the view volume:", a[3]["outside_view_volume"])
+    assert a[3]["big_triangles"] == 1 or not must, "the case must take the tile pass"
+    assert a[3] == b[3]
+    for x, y in zip(a[:3] + a[4:], b[:3] + b[4:]):
+        assert torch.equal(x, y)
+    assert torch.equal(b[0], b[4]) and torch.equal(b[0], b[6]) and torch.equal(b[1], b[5])  # group members == the engine alone
+
+
+def test_selection_inside_the_last_kernel_equals_the_selection_kernel():
+    """ddx_engine_run_select (round 4): the arg-min over the local hypotheses folded into finish_kernel -- atomicMin of (loss bits,
+    index) + an arrival count -- against ddx_select_best on the same iteration's rows: same index (ties to the LOWEST index: two
+    hypotheses are exact duplicates), same loss bits, same pose; into pinned host memory and into a device row; twice in a row
+    (the words are re-armed by the launch that used them); through dist.run_and_select."""
+    from diffdope_amd import dist as ddist, workloads as wl
+
+    dev = torch.device("cuda")
+    for name, B in (("cfg2", 24), ("cfg4", 40)):
+        w = wl.build(name, dev, B=B)
+        p0 = w["params0"].clone()
+        p0[:, 7] = p0[:, 3]      # exact duplicates: they tie
+        p0[:, B - 1] = p0[:, 3]
+        lrm = w["lr_mult"].clone()
+        lrm[7] = lrm[3]
+        lrm[B - 1] = lrm[3]
+        w = dict(w, params0=p0, lr_mult=lrm)
+        n_it = 9
+        eng, params = wl.engine_for(w, wl.bench_lr_schedule(n_it, "adam"), optimizer="adam")
+        used = [i for i, k in enumerate(("rgb", "depth", "mask", "edge")) if w["weights"].get(k) is not None]
+        mask = sum(1 << i for i in used)
+        pinned = torch.empty((1, 18), dtype=torch.float32, pin_memory=True)
+        row = torch.zeros(18, dtype=torch.float32, device=dev)
+        done = 0
+        for n, out in ((3, pinned[0]), (2, row), (1, pinned[0])):
+            eng.run_select(out, n, lo=100)
+            eng.finish()
+            done += n
+            ref = ddist.global_argmin_fused(eng.loss_log[done - 1], mask, eng.mtx_log[done - 1], lo=100)
+            got = out.cpu().numpy()
+            assert int(got[1]) == ref[0] and float(got[0]) == ref[1], (name, n, got[:2], ref[:2])
+            assert torch.equal(torch.from_numpy(got[2:].copy()).reshape(4, 4), ref[2])
+        assert torch.equal(params[:, 3], params[:, 7])  # (the duplicates stayed duplicates, so the tie is real)
+        gi, gl, gm = ddist.run_and_select(eng, 2, lo=5)
+        ref = ddist.global_argmin_fused(eng.loss_log[eng.it - 1], mask, eng.mtx_log[eng.it - 1], lo=5)
+        assert (gi, gl) == (ref[0], ref[1]) and torch.equal(gm, ref[2])
+        eng.check()

@@ -13,9 +13,13 @@ for n in (1, 2, 5, 10, 20, 40, 80):
     for rep in range(7):
         eng.rewind(20)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        eng.run(n)
-        t1 = time.perf_counter()
-        best = ddist.global_argmin_fused(eng.loss_log[20 + n - 1], 0b0101, eng.mtx_log[20 + n - 1], lo=0)
+        if os.environ.get("OLD_SELECT"):
+            eng.run(n)
+            t1 = time.perf_counter()
+            best = ddist.global_argmin_fused(eng.loss_log[20 + n - 1], 0b0101, eng.mtx_log[20 + n - 1], lo=0)
+        else:
+            best = ddist.run_and_select(eng, n)  # (round 4: the selection inside the run's last kernel)
+            t1 = time.perf_counter()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         ts.append((t2 - t0, t1 - t0))
     ts.sort()
