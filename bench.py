@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 # instruction issues over 2 cycles => 256 * 4 * 2.4e9 / 2 wave-instructions per second
 HBM_PEAK_GBS = 8000.0
 LINE_RATE_PEAK_G = 52.7   # random 64-byte lines per second, whole chip, in units of 1e9 (tools/ubench/gather_rate.hip)
+STORE_LINE_PEAK_G = 50.0  # coalesced 16 B + 8 B per-lane record stores as 64-byte lines per second (tools/ubench/store_rate.hip; set from its measurement)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # 1228.8 G wave-instructions / s
 
 
@@ -344,43 +345,49 @@ def main():
         comp = compulsory_bytes(V, T, HW, Bl, r["status"]["active_tiles"], w["coverage"] * HW * Bl, w["tex"] is not None,
                                 max(n_roles, 1), r["eng"].slices[0], uses)
         model_bytes = alg[dom]
-        # The dominant kernels are bound by dependent-latency chains and VALU issue, not by DRAM (traffic_frac below), so the
-        # roofline of record is VALU issue: wave-level VALU instructions per launch (PMC) / live launch duration against
-        # 1228.8 G wave-instructions/s.  `hbm` holds the byte view (work-proportional compulsory bytes, PMC traffic).
+        # ---- the roofline block (round 4: says what the measurements support).  Top level = the HBM byte view of the dominant
+        # kernel: achieved = the work-proportional COMPULSORY bytes of this engine per launch / the live launch duration, against
+        # 8 TB/s; `traffic` = what the PMC passes counted on the memory side for that launch, next to it their ratio.  The
+        # SURVEY 8(d) model (full-frame G-buffer streams this engine never moves) stays as model_8d for continuity.  `valu` is the
+        # issue view (wave-level VALU instructions per launch / duration against 1228.8 G/s).  Neither is near its ceiling: these
+        # launches are bound by dependent memory levels and kernel boundaries (what_binds).
         valu_ach = (valu_insts / dom_s / 1e9) if (valu_insts and not stale) else None
+        hbm_ach = comp[dom] / dom_s / 1e9
+        sh_s = kms["shade_kernel"] * 1e-3
+        st_s = kms["step_kernel"] * 1e-3
+        texel_lines = (w["coverage"] * HW * Bl) if (w["tex"] is not None and (uses["rgb"] or uses["edge"])) else 0.0
+        store_lines = 24.0 * V * Bl / 64.0
         roof = {
-            "kernel": dom, "bound": "valu", "achieved": valu_ach, "peak": VALU_PEAK_GINST, "unit": "Ginst/s",
-            "frac": (valu_ach / VALU_PEAK_GINST) if valu_ach else None,
-            "valu_wave_insts_per_launch": valu_insts, "avg_launch_ms": kms[dom], "counters_source": pmc_src,
-            "counters_stale": stale, "csrc_sha16": csrc_sha16(),
-            "traffic": traffic, "traffic_fetch_doubled": traffic_x2, "fetch_size_calibration": fetch_cal,
-            "hbm": {"compulsory_bytes_per_launch": comp[dom], "achieved_GBps": comp[dom] / dom_s / 1e9,
-                    "frac": comp[dom] / dom_s / 1e9 / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS,
-                    "traffic_bytes_per_launch": traffic,
-                    "traffic_frac_of_peak": (traffic / dom_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                    "traffic_over_compulsory": (traffic / comp[dom]) if traffic else None,
-                    "traffic_fetch_doubled_bytes_per_launch": traffic_x2,
-                    "traffic_fetch_doubled_frac_of_peak": (traffic_x2 / dom_s / 1e9 / HBM_PEAK_GBS) if traffic_x2 else None,
-                    "traffic_fetch_doubled_over_compulsory": (traffic_x2 / comp[dom]) if traffic_x2 else None,
-                    "iteration_compulsory_bytes": comp["iteration"],
-                    "iteration_frac": comp["iteration"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            # The request view: both kernels move their bytes as single 64-byte lines that no lane shares (texel / triangle records,
-            # zbuf atomics, per-vertex stores), and a CU serves such lines at a fixed rate -- tools/ubench/gather_rate.hip: 52.7 G
-            # lines/s for the whole chip (64 lines in flight per CU and ~750 cycles each), whether 16 or 64 bytes of the line are read.
-            "line_rate": {"ceiling_Glines_s": LINE_RATE_PEAK_G, "source": "tools/ubench/gather_rate.hip (profiles/r3c_ubench_gather_rate.jsonl)",
-                          "memory_side_lines_per_launch": (traffic / 64.0) if traffic else None,
-                          "achieved_Glines_s": (traffic / 64.0 / dom_s / 1e9) if traffic else None,
-                          "frac": (traffic / 64.0 / dom_s / 1e9 / LINE_RATE_PEAK_G) if (traffic and not stale) else None,
-                          "what": "FETCH_SIZE + WRITE_SIZE bytes per launch of the dominant kernel / 64 / its live duration, against the "
-                                  "measured rate of random 64-byte lines from a 268 MB table (L2-resident lines are cheaper: a lower bound "
-                                  "on the kernel's line traffic, an honest ceiling for its memory-side part)"},
+            "kernel": dom, "bound": "hbm", "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
+            "compulsory_bytes_per_launch": comp[dom],
+            "traffic": None if stale else traffic, "traffic_over_compulsory": (traffic / comp[dom]) if (traffic and not stale) else None,
+            "traffic_frac_of_peak": (traffic / dom_s / 1e9 / HBM_PEAK_GBS) if (traffic and not stale) else None,
+            "traffic_fetch_doubled": None if stale else traffic_x2, "fetch_size_calibration": fetch_cal,
+            "avg_launch_ms": kms[dom], "counters_source": pmc_src, "counters_stale": stale, "csrc_sha16": csrc_sha16(),
+            "valu": {"achieved": valu_ach, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": (valu_ach / VALU_PEAK_GINST) if valu_ach else None,
+                     "valu_wave_insts_per_launch": valu_insts},
+            "iteration": {"compulsory_bytes": comp["iteration"], "achieved_GBps": comp["iteration"] / (ms_per_step * 1e-3) / 1e9,
+                          "frac": comp["iteration"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            # the request view, per kind of line: lines NO lane shares (one 64-byte texel record per covered pixel: the colour role's
+            # gather, the one load of the shading launch whose removal shortens it) against the measured rate of random 64-byte
+            # records (tools/ubench/gather_rate.hip); COALESCED store lines of step_kernel (16 B clip + 8 B snap per vertex, whole
+            # lines since round 4) against the measured rate of such stores (tools/ubench/store_rate.hip).  No line-rate claim is
+            # made for step_kernel as a whole: leaving its stores out does not shorten the launch.
+            "lines": {"shade_texel_record_lines_per_launch": texel_lines, "gather_ceiling_Glines_s": LINE_RATE_PEAK_G,
+                      "shade_texel_gather_frac": (texel_lines / sh_s / 1e9 / LINE_RATE_PEAK_G) if sh_s > 0 else None,
+                      "step_coalesced_store_lines_per_launch": store_lines, "store_ceiling_Glines_s": STORE_LINE_PEAK_G,
+                      "step_store_frac": (store_lines / st_s / 1e9 / STORE_LINE_PEAK_G) if st_s > 0 else None,
+                      "sources": "tools/ubench/gather_rate.hip, tools/ubench/store_rate.hip (profiles/r4_ubench_*.jsonl)"},
+            "what_binds": "neither bytes nor issue: a launch begins with two dependent memory levels on a cold L2 (kernel arguments, then its first "
+                          "data: ~3.5 us before useful work, per-workgroup stamps in profiles/), ends with its slowest workgroup, and a kernel "
+                          "boundary costs ~2.4 us; at 512 hypotheses per GPU the same kernels run at 25 us per 64 hypotheses",
             "model_8d": {"algorithmic_bytes_per_launch": model_bytes, "achieved_GBps": model_bytes / dom_s / 1e9,
                          "ratio_to_hbm_peak": model_bytes / dom_s / 1e9 / HBM_PEAK_GBS,
                          "iteration_ratio_to_hbm_peak": alg["iteration"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
                          "note": "SURVEY 8(d) visibility-buffer model (full-frame G-buffer streams); this engine touches active tiles "
                                  "only, so the ratio exceeds 1 -- continuity with round 1, not a roofline"},
-            "note": "frac = VALU issue utilisation of the dominant kernel (PMC SQ_INSTS_VALU per launch / live HIP-event launch duration "
-                    "/ (1024 SIMD-32 x 2.4 GHz / 2 cycles)); hbm.frac = work-proportional compulsory bytes / duration / 8 TB/s; see DESIGN.md section 6",
+            "note": "frac = compulsory HBM bytes of the dominant kernel / its live HIP-event launch duration / 8 TB/s; traffic = FETCH_SIZE + WRITE_SIZE "
+                    "of the committed PMC passes for this build (null when the kernel sources changed since); see DESIGN.md section 6",
         }
         tex_hw = (int(w["tex"].shape[0]), int(w["tex"].shape[1])) if w["tex"] is not None else (0, 0)
         job_iters = args.steps / elapsed  # iterations of the whole job per second

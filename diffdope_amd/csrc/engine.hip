@@ -2498,6 +2498,54 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
                 ++nt;
             }
             E.n_meshlets = M + 1;
+            // ---- final vertex numbering (round 4): the vertices a meshlet OWNS become one contiguous run of ids, in the order of
+            // its first slots, so that the owner's clip / snap stores of a wave are whole lines (lane t of the meshlet's workgroup
+            // stores vertex base + t): with the Morton ids the owned vertices of a meshlet were interleaved with its neighbours'
+            // and the stores were partial lines (WRITE_SIZE 40.7 MB per step launch on cfg2 against 22 MB of payload).  Slots are
+            // permuted (owned first, first-use order kept), the triangles' local indices follow, and vold / vnew are composed
+            // with the renumbering; vertices no triangle uses keep their Morton order behind all the others.
+            {
+                const int Mn = E.n_meshlets;
+                std::vector<int> fin((size_t)V, -1);  // Morton id -> final id
+                int next = 0;
+                for (int m = 0; m < Mn; ++m) {
+                    int perm[1024];  // old slot -> new slot (NVC <= 512)
+                    int n_own = 0, n_all = 0;
+                    for (int k = 0; k < NVC; ++k) {
+                        const unsigned bits = [&] { unsigned u; memcpy(&u, &hv[(size_t)m * NVC + k].w, 4); return u; }();
+                        if (bits == 0xffffffffu) break;
+                        ++n_all;
+                        if (bits >> 31) ++n_own;
+                    }
+                    int io = 0, ib = n_own;
+                    for (int k = 0; k < n_all; ++k) {
+                        unsigned bits; memcpy(&bits, &hv[(size_t)m * NVC + k].w, 4);
+                        if (bits >> 31) { fin[(size_t)(bits & 0x7fffffffu)] = next + io; perm[k] = io++; }
+                        else perm[k] = ib++;
+                    }
+                    next += n_own;
+                    std::vector<float4> tmp(hv.begin() + (size_t)m * NVC, hv.begin() + (size_t)m * NVC + n_all);
+                    for (int k = 0; k < n_all; ++k) hv[(size_t)m * NVC + perm[k]] = tmp[(size_t)k];
+                    for (int k = 0; k < NTRI; ++k) {
+                        int2& tr = ht[(size_t)m * NTRI + k];
+                        if (tr.y < 0) continue;
+                        const int l0 = tr.x & 1023, l1 = (tr.x >> 10) & 1023, l2 = (tr.x >> 20) & 1023;
+                        tr.x = perm[l0] | (perm[l1] << 10) | (perm[l2] << 20);
+                    }
+                }
+                for (int n = 0; n < V; ++n)
+                    if (fin[(size_t)n] < 0) fin[(size_t)n] = next++;  // (unreferenced vertices)
+                for (size_t i = 0; i < hv.size(); ++i) {
+                    unsigned bits; memcpy(&bits, &hv[i].w, 4);
+                    if (bits == 0xffffffffu) continue;
+                    bits = (bits & 0x80000000u) | (unsigned)fin[(size_t)(bits & 0x7fffffffu)];
+                    memcpy(&hv[i].w, &bits, 4);
+                }
+                std::vector<int> vold2((size_t)V);
+                for (int n = 0; n < V; ++n) vold2[(size_t)fin[(size_t)n]] = vold[(size_t)n];
+                vold.swap(vold2);
+                for (int n = 0; n < V; ++n) vnew[(size_t)vold[(size_t)n]] = n;
+            }
             // interleave the two ends of the Morton curve: 0, M-1, 1, M-2, ...  The bit-complement of a Morton code is the point
             // reflection through the centre of the bounding box, so consecutive meshlets of the new order are (roughly) antipodes
             // of the object: a workgroup's consecutive meshlets are one front-facing and one back-facing patch in any pose
@@ -2688,7 +2736,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
             const double n_px = hst.c_mask / 3.0;
             const double px_per_unit = (e->mesh_area > 0.0 && n_px > 0.0) ? std::sqrt(4.0 * n_px / e->mesh_area) : 1e30;
             const double edge_px = e->mesh_max_edge * px_per_unit;
-            bool expect_none = edge_px < 4.0;  // (a bounding box of 16 centres where 64 are allowed: hypotheses start nearer than the object is)
+            bool expect_none = edge_px < 6.0;  // (a bounding box of 36 centres where 64 are allowed: hypotheses start nearer than the object is)
             if (e->inline_env >= 0) expect_none = e->inline_env != 0;
             E.big_inline = (e->inline_ok && expect_none) ? 1 : 0;
             if (getenv("DDX_DEBUG_INLINE")) fprintf(stderr, "ddx: longest edge ~%.2f px, inline tile pass %d (allowed %d)\n", edge_px, E.big_inline, (int)e->inline_ok);
@@ -3170,4 +3218,5 @@ extern "C" void ddx_engine_destroy(ddx_engine* e)
 
 #ifdef DDX_EXPERIMENTS  // variant builds only (tools/build_variant.py): measurement code that is not part of the product
 #include "tools/experiments/stagger_exp.inc"
+#include "tools/experiments/role_kernels.inc"
 #endif

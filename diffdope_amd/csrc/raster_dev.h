@@ -258,7 +258,7 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
     constexpr bool COMPACT = MODE == 3;
     // compacting variant: 32 bytes per survivor: first corner, the other two relative to it in 16 bits (a small triangle spans
     // < 2^13 sub-pixels), vertex handles, triangle id
-    __shared__ int4 s_q[COMPACT ? NTHREADS / 64 : 1][COMPACT ? 64 * TPL : 1][2];
+    __shared__ int4 s_q[COMPACT ? NTHREADS / 64 : 1][2][COMPACT ? 64 * TPL : 1];  // (two planes of 16-byte records: a 32-byte record per lane made every 128-bit access a two-way bank conflict)
     // fragment exchange of one wave: exclusive prefix of the lanes' fragment counts, their coverage masks and triangle records
     __shared__ int s_pref[EXCHANGE ? NTHREADS / 64 : 1][EXCHANGE ? 64 : 1];
     __shared__ scatter_mask_t s_mask[EXCHANGE ? NTHREADS / 64 : 1][EXCHANGE ? 64 : 1];
@@ -287,8 +287,8 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
                 const int slot = n_q + __popcll(m & ((1ull << lane) - 1ull));
                 const unsigned rb = ((unsigned)(vb[k].x - va[k].x) & 0xffffu) | ((unsigned)(vb[k].y - va[k].y) << 16);
                 const unsigned rc = ((unsigned)(vc[k].x - va[k].x) & 0xffffu) | ((unsigned)(vc[k].y - va[k].y) << 16);
-                s_q[wv][slot][0] = make_int4(va[k].x, va[k].y, (int)rb, (int)rc);
-                s_q[wv][slot][1] = make_int4(i0[k], i1[k], i2[k], t[k]);
+                s_q[wv][0][slot] = make_int4(va[k].x, va[k].y, (int)rb, (int)rc);
+                s_q[wv][1][slot] = make_int4(i0[k], i1[k], i2[k], t[k]);
             }
             n_q += __popcll(m);
         }
@@ -297,7 +297,7 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
         for (int base = 0; base < n_q; base += 64) {  // (wave-uniform)
             const int idx = base + lane;
             if (idx < n_q) {
-                const int4 g = s_q[wv][idx][0], h = s_q[wv][idx][1];
+                const int4 g = s_q[wv][0][idx], h = s_q[wv][1][idx];
                 const int2 qa = make_int2(g.x, g.y);
                 const int2 qb = make_int2(g.x + (int)(short)((unsigned)g.z & 0xffffu), g.y + ((int)g.z >> 16));
                 const int2 qc = make_int2(g.x + (int)(short)((unsigned)g.w & 0xffffu), g.y + ((int)g.w >> 16));
