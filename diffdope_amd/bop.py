@@ -69,8 +69,7 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
             st = torch.cuda.Stream()
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                # (engines running side by side: the tile pass as its own launch, ddx.h separate_big_pass)
-                eng = dd.prepare_optimization(optimizer=optimizer, shade_slices=ss, edge_slices=es, separate_big_pass=True)
+                eng = dd.prepare_optimization(optimizer=optimizer, shade_slices=ss, edge_slices=es)
                 eng.run()
         elif mode == "sequential":
             dd.prepare_optimization(optimizer=optimizer, shade_slices=ss, edge_slices=es).run()

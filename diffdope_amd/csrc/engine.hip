@@ -3004,6 +3004,7 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     e->adam_parity = (it0 + iters) & 1;
     for (int k = K_STEP; k < K_FINISH; ++k) ms_out[k] /= (float)timed;
     if (!e->dev.d.use_edge) ms_out[K_EDGE] = 0.f;  // (not launched)
+    if (e->dev.big_inline) ms_out[K_BIG] = 0.f;    // (not launched: the tile pass rides in the shading launch; the interval is two event records)
     DDX_HIP(hipEventElapsedTime(&ms_out[K_FINISH], ev[K_FINISH], ev[K_COUNT]));  // once per run, not per iteration
     for (int k = 0; k < K_COUNT; ++k)
         if (names_out) names_out[k] = kKernelNames[k];

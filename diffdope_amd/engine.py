@@ -47,8 +47,8 @@ class RefineEngine:
             switchable, nvdiffrast's (D2: the rasterize backward differentiates the unclamped barycentrics; ddx.h DDX_COMPAT_*)
         cull_backfaces: skip the back faces of a closed mesh while a hypothesis lies inside the view volume (ddx.h
             no_backface_cull; identical visibility in exact arithmetic).  False = always draw both faces.
-        separate_big_pass: True = the tile pass for large / near-clipped triangles as its own launch instead of inside the shading
-            kernel (ddx.h separate_big_pass): for engines that run next to several others on one device (one stream each).
+        separate_big_pass: True = the tile pass for large / near-clipped triangles always as its own launch (ddx.h separate_big_pass);
+            default: the set-up decides from the expected triangle size (no launch where no large triangle is expected; same results).
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
@@ -199,7 +199,7 @@ class RefineEngine:
         self.it = it
 
     def status(self):
-        """dict(overflow (0; 2 = a wait of the inline tile pass timed out, see check()), big_triangles (0/1: the tile pass ran), active_tiles, it (the last iteration drawn), n_seg,
+        """dict(overflow (always 0), big_triangles (0/1: the tile pass ran), active_tiles, it (the last iteration drawn), n_seg,
         outside_view_volume (hypotheses of the last iteration whose bounding box had a corner at w <= 0 or |z| > w: near-plane
         clipping and two-sided drawing for those)) -- synchronises."""
         p = self.lib.ddx_engine_status_ptr(self.handle)
@@ -210,8 +210,7 @@ class RefineEngine:
     def check(self):
         st = self.status()
         if st["overflow"]:
-            raise RuntimeError("engine status word 0 = %d: a wait of the inline tile pass did not end (too many engines with large triangles "
-                               "running at once on this device: create them with separate_big_pass=True); results are invalid" % st["overflow"])
+            raise RuntimeError("engine reported an internal overflow")
         return st
 
     def profile(self, it0=0, iters=5):

@@ -201,12 +201,13 @@ typedef struct ddx_engine_desc {
      * arithmetic (deviation D5) and halves the fragment work.  Environment DDX_NO_CULL=1 also disables. */
     int32_t no_backface_cull;
     int32_t compat;   /* DDX_COMPAT_* bits for this engine (0 = this build's documented behaviour) */
-    /* 0 (default): when the batch allows it (B a multiple of 8, the shading launch resident as a whole) the tile pass for large /
-     * near-clipped triangles runs inside the shading kernel, only for hypotheses that have such triangles, and the launch between
-     * the rasterising and the shading kernel is dropped.  Its workgroups meet at a counter: engines that
-     * share the device with MORE THAN ONE other engine running at the same time (one stream per object) set this to 1 -- the
-     * separate launch, no waiting inside a kernel.  A wait that does not end sets status word 0 to 2 instead of hanging.
-     * Environment DDX_BIG_INLINE=0 also selects the separate launch.  Same results either way. */
+    /* Where the tile pass for LARGE / near-clipped triangles runs.  0 (default): the set-up estimates the longest edge of the mesh in
+     * pixels from the observed object's size; where no large triangle is to be expected (dense meshes) and B is a multiple of 8,
+     * the launch between the rasterising and the shading kernel is dropped and worker workgroups in the first slab of the shading
+     * launch run the pass for a hypothesis that has such triangles after all (no waiting that could hang: workgroups are
+     * dispatched in id order per XCD, and a hypothesis' workers have smaller ids than its shading workgroups on the same XCD;
+     * DESIGN.md section 4).  1: always the separate launch.  Environment DDX_BIG_INLINE=0 / 1 overrides the estimate.  Same
+     * results either way, bit for bit. */
     int32_t separate_big_pass;
     int32_t reserved[1];
 } ddx_engine_desc;
@@ -282,7 +283,7 @@ int ddx_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
  * lo = global index of the first local hypothesis; out18 = (mean loss of the winner, its global index, its 4x4
  * pose row-major): this rank's row of the [world,18] table that ONE all_reduce(SUM) exchanges. */
 int ddx_select_best(const float* loss_rows, int row_mask, int B, const float* mtx, int lo, float* out18, void* stream);
-/* device int32[8] inside scratch: [0] 0, or 2 = a wait of the inline tile pass did not end (results invalid: see separate_big_pass), [1] large triangles (tile-pass) of the last
+/* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
  * iteration, [2] active tiles of the last iteration, [3] internal, [4] pixels with seg != 0, [5] last iteration drawn + 1,
  * [6] hypotheses of the last iteration whose object-space bounding box had a corner outside the view volume (w <= 0 or
  * |z| > w): their triangles with a vertex at w <= 0 took the near-plane clipping path and their back faces were drawn -- 0 in any
