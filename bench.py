@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 # instruction issues over 2 cycles => 256 * 4 * 2.4e9 / 2 wave-instructions per second
 HBM_PEAK_GBS = 8000.0
 LINE_RATE_PEAK_G = 52.7   # random 64-byte lines per second, whole chip, in units of 1e9 (tools/ubench/gather_rate.hip)
-STORE_LINE_PEAK_G = 50.0  # coalesced 16 B + 8 B per-lane record stores as 64-byte lines per second (tools/ubench/store_rate.hip; set from its measurement)
+STORE_LINE_PEAK_G = 104.2  # coalesced 16 B + 8 B per-lane record stores as 64-byte lines per second: 6.67 TB/s on a 257 MB footprint (tools/ubench/store_rate.hip,
+                           # profiles/r4b_ubench_store_rate.jsonl; 33.5 G lines/s on cfg2's own 16 MB, where the launch is the limit)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # 1228.8 G wave-instructions / s
 
 
@@ -337,6 +338,7 @@ def main():
         # counters measured on other kernel sources than the ones running now are not this build's: reported as stale, never as frac
         stale = bool(pmc) and pmc.get("csrc_sha16") != csrc_sha16()
         valu_insts = kp.get("SQ_INSTS_VALU") if kp else None
+        valu_active_q = kp.get("SQ_ACTIVE_INST_VALU") if kp else None                # quad-cycles the waves spent executing VALU instructions
         traffic = kp.get("hbm_bytes_per_launch") if kp else None                      # FETCH_SIZE + WRITE_SIZE as reported
         traffic_x2 = kp.get("hbm_bytes_per_launch_fetch_doubled") if kp else None     # with the guide's x2 on FETCH_SIZE
         fetch_cal = (pmc or {}).get("fetch_size_calibration")                         # tools/ubench/gather64.hip under --pmc FETCH_SIZE
@@ -365,7 +367,11 @@ def main():
             "traffic_fetch_doubled": None if stale else traffic_x2, "fetch_size_calibration": fetch_cal,
             "avg_launch_ms": kms[dom], "counters_source": pmc_src, "counters_stale": stale, "csrc_sha16": csrc_sha16(),
             "valu": {"achieved": valu_ach, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": (valu_ach / VALU_PEAK_GINST) if valu_ach else None,
-                     "valu_wave_insts_per_launch": valu_insts},
+                     "valu_wave_insts_per_launch": valu_insts,
+                     # the same pipe seen by SQ_ACTIVE_INST_VALU (quad-cycles waves spent executing VALU instructions, summed over the
+                     # chip) x 4 / (1024 SIMDs x 2.4 GHz x duration): ~4 cycles per instruction on these integer-heavy kernels, so
+                     # about twice `frac`; the larger of the two is the honest "how busy is the VALU" (0.72 at saturation)
+                     "busy_frac": (valu_active_q * 4.0 / (1024 * 2.4e9 * dom_s)) if (valu_active_q and not stale) else None},
             "iteration": {"compulsory_bytes": comp["iteration"], "achieved_GBps": comp["iteration"] / (ms_per_step * 1e-3) / 1e9,
                           "frac": comp["iteration"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             # the request view, per kind of line: lines NO lane shares (one 64-byte texel record per covered pixel: the colour role's

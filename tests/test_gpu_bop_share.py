@@ -70,9 +70,9 @@ def test_config5_share_four_objects_64_hypotheses_1280x720(tmp_path, H, W, rows,
     cfg = dict(losses=dict(l1_rgb_with_mask=True, weight_rgb=0.7, l1_depth_with_mask=True, weight_depth=1.0, l1_mask=True, weight_mask=1.0),
                hyperparameters=dict(nb_iterations=n_it, batchsize=B, base_lr=0.05, learning_rates_bound=[0.5, 3.0], learning_rate_base=1,
                                     lr_decay=0.1, seed=5))
-    # ---- the frame as the driver runs it: the four local objects as ONE engine group (one launch of each kernel per iteration)
-    table, handles = bop.refine_frame(cfg, dd.Camera(**intr), scene, objs, meshes, masks, optimizer="sgd")
-    # ... one stream per object gives the same bits
+    # ---- the four local objects as ONE engine group (one launch of each kernel per iteration)
+    table, handles = bop.refine_frame(cfg, dd.Camera(**intr), scene, objs, meshes, masks, optimizer="sgd", mode="group")
+    # ... one stream per object (the driver's default since round 4) gives the same bits
     table_s, handles_s = bop.refine_frame(cfg, dd.Camera(**intr), scene, objs, meshes, masks, optimizer="sgd", mode="streams")
     assert torch.equal(table, table_s)
     for i in range(4):

@@ -1,4 +1,4 @@
-"""Experiment (round 4): the B = 64 iteration of cfg2 as (a) the product's run, (b) the same without the empty tile-pass launch,
+"""Experiment (round 4): the B = 64 iteration of cfg2 as (a) the product's run, (b) the same without any tile pass (the floor of what removing the launch can give),
 (c) two 32-hypothesis halves in phase-staggered MIXED launches (step blocks of one half + shade blocks of the other in one grid),
 (d) the two halves as independent chains on two streams, each sized for half the chip.  Needs the variant library:
     python tools/build_variant.py exp -DDDX_EXPERIMENTS ;  DDX_LIB=diffdope_amd/libddx_exp.so python tools/experiments/exp_stagger.py [cfg2]
@@ -53,10 +53,10 @@ def timeit(name, make, run, result):
 s_cur = lambda: torch.cuda.current_stream().cuda_stream
 def run_full(st, it0, n):
     st[0].rewind(it0); st[0].run(n)
-ref = timeit(f"{cfg}: product run (step, tile pass, shade)", full_engine, run_full, lambda st: (st[1].clone(), st[0].loss_log.clone()))
+ref = timeit(f"{cfg}: product run (step, shade with the tile-pass worker slab)", full_engine, run_full, lambda st: (st[1].clone(), st[0].loss_log.clone()))
 def run_nobig(st, it0, n):
     _lib.check(raw.ddx_exp_run_no_big(st[0].handle, it0, n, s_cur()), "no_big")
-got = timeit(f"{cfg}: without the tile-pass launch", full_engine, run_nobig, lambda st: (st[1].clone(), st[0].loss_log.clone(), st[0].status()))
+got = timeit(f"{cfg}: without any tile pass (neither launch nor worker slab)", full_engine, run_nobig, lambda st: (st[1].clone(), st[0].loss_log.clone(), st[0].status()))
 check("no_big", got[2])
 print("   bit-identical to the product run:", torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]))
 
