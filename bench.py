@@ -383,7 +383,7 @@ def main():
                       "shade_texel_gather_frac": (texel_lines / sh_s / 1e9 / LINE_RATE_PEAK_G) if sh_s > 0 else None,
                       "step_coalesced_store_lines_per_launch": store_lines, "store_ceiling_Glines_s": STORE_LINE_PEAK_G,
                       "step_store_frac": (store_lines / st_s / 1e9 / STORE_LINE_PEAK_G) if st_s > 0 else None,
-                      "sources": "tools/ubench/gather_rate.hip, tools/ubench/store_rate.hip (profiles/r4_ubench_*.jsonl)"},
+                      "sources": "tools/ubench/gather_rate.hip, tools/ubench/store_rate.hip (profiles/r3c_ubench_gather_rate.jsonl, profiles/r4b_ubench_store_rate.jsonl)"},
             "what_binds": "neither bytes nor issue: a launch begins with two dependent memory levels on a cold L2 (kernel arguments, then its first "
                           "data: ~3.5 us before useful work, per-workgroup stamps in profiles/), ends with its slowest workgroup, and a kernel "
                           "boundary costs ~2.4 us; at 512 hypotheses per GPU the same kernels run at 25 us per 64 hypotheses",

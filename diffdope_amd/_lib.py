@@ -54,6 +54,7 @@ _SIGNATURES = {
     "ddx_pose_matrix_bwd": (_I, [_P, _P, _I, _P, _P, _P]),
     "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "ddx_rasterize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
+    "ddx_rasterize_fwd_rows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _I, _P]),
     "ddx_rasterize_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_interpolate_fwd": (_I, [_P, _LL, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "ddx_interpolate_bwd": (_I, [_P, _LL, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -64,6 +65,10 @@ _SIGNATURES = {
     "ddx_antialias_bwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_gbuffer_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_gbuffer_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "ddx_gbuffer_fwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "ddx_gbuffer_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "ddx_silhouette_fwd_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "ddx_silhouette_bwd_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_silhouette_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "ddx_silhouette_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "ddx_masked_l1_fwd": (_I, [_P, _P, _P, _I, _I, _LL, _P, _P, _P]),

@@ -12,6 +12,7 @@ struct RasterScratch {
     unsigned char* tile_big;  // [npar][B,NTp] != 0: a large triangle overlaps the tile
     int* active;              // [B,NT] per-hypothesis ordered list of active tiles, packed ty << 16 | tx (first b_count[b] entries)
     int* b_count;             // [B] active tiles of each hypothesis
+    int* row_range;           // [B][2] first / last pixel row of the hypothesis' active tiles (lo > hi: none); op-level compaction only
     int2* snap;               // [B,V] window coordinates in 1/256 px (x = INT_MIN if w <= 0)
     uint2* biglist;           // [B,T] the LARGE triangles of each hypothesis: (triangle id, packed tile range tx0 | ty0<<8 | (nx-1)<<16 | (ny-1)<<24)
     int* bigcount;            // [npar][B] entries of biglist (appended by the scatter pass, one atomic per wave; re-armed by the consumer)

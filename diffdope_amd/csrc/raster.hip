@@ -46,6 +46,7 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.zero_bytes = off;  // [counters | tile_flag | tile_big | bigcount | bigarrive] must be zero when a pass starts
     const size_t o_active = carve((size_t)B * NT * sizeof(int));
     const size_t o_bcount = carve((size_t)B * sizeof(int));
+    const size_t o_rows = carve((size_t)B * 2 * sizeof(int));
     const size_t o_snap = carve((size_t)B * V * sizeof(int2));
     const size_t o_range = carve((size_t)B * T * sizeof(uint2));
     const int zwb = (W + 3) / 4, zhb = (H + 3) / 4;
@@ -56,6 +57,7 @@ size_t raster_layout(RasterScratch& L, void* base, int B, int V, int T, int H, i
     L.tile_big = (unsigned char*)(p + o_big);
     L.active = (int*)(p + o_active);
     L.b_count = (int*)(p + o_bcount);
+    L.row_range = (int*)(p + o_rows);
     L.snap = (int2*)(p + o_snap);
     L.biglist = (uint2*)(p + o_range);
     L.bigcount = (int*)(p + o_bigcount);
@@ -149,6 +151,9 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
         // 16 rounds of 256 flags at a time: all loads in flight at once, one ordered prefix over the (round, wave) counts --
         // a load / ballot / barrier loop per 256 flags paid one memory round trip per round (5 on 640x480, 15 on 1280x720)
         __shared__ int s_cnt[CB_ROUNDS * 4], s_off[CB_ROUNDS * 4 + 1];
+        __shared__ int s_lo, s_hi;  // lowest / highest flagged tile index (the rows the hypothesis draws into)
+        if (tid == 0) { s_lo = 0x7fffffff; s_hi = -1; }
+        int my_lo = 0x7fffffff, my_hi = -1;
         int carry = 0;
         for (int start = 0; start < L.NT; start += CB_ROUNDS * 256) {
             int fl[CB_ROUNDS];
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
             for (int c = 0; c < CB_ROUNDS; ++c) {
                 const int i = start + c * 256 + tid;
                 fl[c] = i < L.NT ? (int)flg[i] : 0;
+                if (fl[c] != 0) { my_lo = min(my_lo, i); my_hi = max(my_hi, i); }
             }
             unsigned long long m[CB_ROUNDS];
 #pragma unroll
@@ -187,7 +193,14 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
             }
             carry += s_off[64];
         }
-        if (tid == 0) L.b_count[b] = carry;
+        if (my_hi >= 0) { atomicMin(&s_lo, my_lo); atomicMax(&s_hi, my_hi); }
+        __syncthreads();
+        if (tid == 0) {
+            L.b_count[b] = carry;
+            const bool any = s_hi >= 0;
+            L.row_range[b * 2 + 0] = any ? (s_lo / L.ntx) * DDX_TILE : 1;
+            L.row_range[b * 2 + 1] = any ? min(H - 1, (s_hi / L.ntx) * DDX_TILE + DDX_TILE - 1) : 0;
+        }
         return;
     }
     if (L.counters[3] == 0) return;  // no large triangle in the whole batch
@@ -198,11 +211,17 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------
 // emit nvdiffrast-style rast [B,H,W,4]
+#define EMIT_ROW_MARGIN 8  // rows emitted beyond the hypothesis' active rows in the restricted form (the antialias kernels read AA_ROWS + 1 rows per block)
 __global__ __launch_bounds__(256) void emit_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
-                                                   int B, int H, int W, RasterScratch L, float* __restrict__ rast)
+                                                   int B, int H, int W, RasterScratch L, float* __restrict__ rast, int restrict_rows)
 {
     // blockIdx.y = hypothesis, 1024 consecutive pixels of it per workgroup: 32-bit pixel arithmetic (H, W <= 4096)
     const int b = blockIdx.y, HW = H * W;
+    if (restrict_rows) {  // (the fused materialising path: rows far from the hypothesis' active tiles are never read by its consumers)
+        const int lo = (L.row_range[b * 2] - EMIT_ROW_MARGIN) * W, hi = (L.row_range[b * 2 + 1] + EMIT_ROW_MARGIN + 1) * W;
+        const int p0 = blockIdx.x * 1024;
+        if (p0 + 1024 <= lo || p0 >= hi) return;  // (workgroup-uniform; lo > hi for a hypothesis that draws nothing)
+    }
     unsigned long long keys[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -259,6 +278,12 @@ extern "C" size_t ddx_rasterize_scratch_bytes(int B, int V, int T, int H, int W)
 extern "C" int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W, void* scratch,
                                  size_t scratch_bytes, float* rast, void* stream)
 {
+    return ddx_rasterize_fwd_rows(pos, tri, B, V, T, H, W, scratch, scratch_bytes, rast, nullptr, 1, stream);
+}
+
+extern "C" int ddx_rasterize_fwd_rows(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W, void* scratch,
+                                      size_t scratch_bytes, float* rast, int32_t* row_range, int emit_all, void* stream)
+{
     DDX_REQUIRE(pos && tri && scratch && rast, DDX_E_NULL, "rasterize_fwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && B <= 65535 && V >= 1 && T >= 1 && H >= 1 && W >= 1 && H <= 4096 && W <= 4096, DDX_E_SHAPE,
                 "rasterize_fwd: bad shape B=%d V=%d T=%d H=%d W=%d", B, V, T, H, W);
@@ -270,7 +295,10 @@ extern "C" int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, in
     hipStream_t s = (hipStream_t)stream;
     if (int e = raster_snap(pos, B, V, H, W, L, s)) return e;
     if (int e = raster_run(pos, tri, B, V, T, H, W, L, s, true, nullptr)) return e;
-    emit_kernel<<<dim3((unsigned)((H * W + 1023) / 1024), (unsigned)B), 256, 0, s>>>(pos, tri, V, B, H, W, L, rast);
+    const int restrict_rows = (row_range && !emit_all) ? 1 : 0;
+    emit_kernel<<<dim3((unsigned)((H * W + 1023) / 1024), (unsigned)B), 256, 0, s>>>(pos, tri, V, B, H, W, L, rast, restrict_rows);
     DDX_LAUNCH_CHECK();
+    // the rows a hypothesis draws into, for the consumers of `rast` (the scratch is overwritten by the next call: the caller keeps a copy)
+    if (row_range) DDX_HIP(hipMemcpyAsync(row_range, L.row_range, (size_t)B * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return 0;
 }

@@ -242,8 +242,11 @@ __global__ __launch_bounds__(256) void antialias_kernel(const float* __restrict_
                                                         const int* __restrict__ tri, const int* __restrict__ opp,
                                                         int V, int T, int H, int W, const float* __restrict__ dout,
                                                         float* __restrict__ out /* fwd: out ; bwd: dcolor */,
-                                                        float* __restrict__ dpos)
+                                                        float* __restrict__ dpos, const int* __restrict__ row_range = nullptr)
 {
+    // (row_range: a block of rows that lies outside the rows of the hypothesis' active tiles holds no pair -- and `rast` is not
+    // filled there by the restricted emit; blocks that pass read rows within EMIT_ROW_MARGIN of the active ones)
+    if (row_range && ((int)blockIdx.x * AA_ROWS > row_range[blockIdx.y * 2 + 1] || (int)blockIdx.x * AA_ROWS + AA_ROWS < row_range[blockIdx.y * 2])) return;
     // A workgroup takes AA_ROWS full rows of one hypothesis (blockIdx.y), 256 columns at a time.
     // (1) streaming: each lane reads the triangle ids of its column in those rows plus the row above -- the upper neighbour of
     // a row is the next row's own id, the right neighbour comes from the next lane -- and queues the pairs whose ids differ (a
@@ -373,10 +376,16 @@ extern "C" int ddx_antialias_bwd(const float* color, int C, const float* rast, c
 extern "C" int ddx_silhouette_fwd(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
                                   int H, int W, float* mask, void* stream)
 {
+    return ddx_silhouette_fwd_rows(rast, pos, tri, opp, B, V, T, H, W, nullptr, mask, stream);
+}
+
+extern "C" int ddx_silhouette_fwd_rows(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
+                                       int H, int W, const int32_t* row_range, float* mask, void* stream)
+{
     DDX_REQUIRE(rast && pos && tri && opp && mask, DDX_E_NULL, "silhouette_fwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "silhouette_fwd: bad shape");
     DDX_REQUIRE_FRAME(B, H, W, "silhouette_fwd");
-    antialias_kernel<false, true><<<aa_grid(H, B), 256, 0, (hipStream_t)stream>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, nullptr, mask, nullptr);
+    antialias_kernel<false, true><<<aa_grid(H, B), 256, 0, (hipStream_t)stream>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, nullptr, mask, nullptr, row_range);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -384,12 +393,18 @@ extern "C" int ddx_silhouette_fwd(const float* rast, const float* pos, const int
 extern "C" int ddx_silhouette_bwd(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
                                   int H, int W, const float* dmask, float* dpos, void* stream)
 {
+    return ddx_silhouette_bwd_rows(rast, pos, tri, opp, B, V, T, H, W, nullptr, dmask, dpos, stream);
+}
+
+extern "C" int ddx_silhouette_bwd_rows(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
+                                       int H, int W, const int32_t* row_range, const float* dmask, float* dpos, void* stream)
+{
     DDX_REQUIRE(rast && pos && tri && opp && dmask && dpos, DDX_E_NULL, "silhouette_bwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "silhouette_bwd: bad shape");
     DDX_REQUIRE_FRAME(B, H, W, "silhouette_bwd");
     hipStream_t s = (hipStream_t)stream;
     DDX_HIP(hipMemsetAsync(dpos, 0, (size_t)B * V * 4 * sizeof(float), s));
-    antialias_kernel<true, true><<<aa_grid(H, B), 256, 0, s>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, dmask, nullptr, dpos);
+    antialias_kernel<true, true><<<aa_grid(H, B), 256, 0, s>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, dmask, nullptr, dpos, row_range);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -572,16 +587,20 @@ __global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restric
                                                           const float* __restrict__ pos, const int* __restrict__ tri,
                                                           const float* __restrict__ uv, const float* __restrict__ tex, int Th, int Tw,
                                                           const float* __restrict__ vcol, int V, int T, int HW,
-                                                          float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ cover)
+                                                          float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ cover,
+                                                          const int* __restrict__ row_range, int W)
 {
     const int b = blockIdx.y;
     const float* M = mtx + (size_t)b * 16;
+    // (row_range: pixels outside the rows of the hypothesis' active tiles are background by construction -- written without
+    // reading `rast`, which the restricted emit has not filled there)
+    const int plo = row_range ? row_range[b * 2] * W : 0, phi = row_range ? (row_range[b * 2 + 1] + 1) * W : HW;
 #pragma unroll
     for (int rd = 0; rd < PIX_ROUNDS; ++rd) {
         const int p = blockIdx.x * PIX_PER_WG + rd * 256 + threadIdx.x;
         if (p >= HW) continue;
         const long long i = (long long)b * HW + p;
-        const float4 r = ld4(rast + i * 4);
+        const float4 r = (p >= plo && p < phi) ? ld4(rast + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int t = (int)r.w - 1;
         float col[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f}, cv = 0.f;
         int i0 = 0, i1 = 0, i2 = 0;
@@ -633,9 +652,10 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restric
                                                           const float* __restrict__ tex, int Th, int Tw, const float* __restrict__ vcol,
                                                           int V, int T, int H, int W, const float* __restrict__ drgb,
                                                           const float* __restrict__ ddepth, float* __restrict__ dclip,
-                                                          float* __restrict__ dmtx, int compat)
+                                                          float* __restrict__ dmtx, int compat, const int* __restrict__ row_range)
 {
     const int HW = H * W;
+    const int plo = row_range ? row_range[blockIdx.y * 2] * W : 0, phi = row_range ? (row_range[blockIdx.y * 2 + 1] + 1) * W : HW;
     __shared__ float s_dm[4][4];
     // the pixels of this workgroup belong to ONE hypothesis (blockIdx.y): their contributions to d mtx[b][2][:] are summed over
     // the workgroup and added with four atomics at the end
@@ -646,7 +666,7 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float* __restric
 #pragma unroll
     for (int rd = 0; rd < PIX_ROUNDS; ++rd) {
         const int p = blockIdx.x * PIX_PER_WG + rd * 256 + threadIdx.x;
-        rr[rd] = p < HW ? ld4(rast + ((long long)bb * HW + p) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rr[rd] = (p < HW && p >= plo && p < phi) ? ld4(rast + ((long long)bb * HW + p) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);  // (outside the active rows: background)
     }
 #pragma unroll
     for (int rd = 0; rd < PIX_ROUNDS; ++rd) {
@@ -750,14 +770,21 @@ extern "C" int ddx_gbuffer_fwd(const float* rast, const float* mtx, const float*
                                const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, float* rgb,
                                float* depth, float* cover, void* stream)
 {
+    return ddx_gbuffer_fwd_rows(rast, mtx, pos, tri, uv, tex, Th, Tw, vtx_color, B, V, T, H, W, nullptr, rgb, depth, cover, stream);
+}
+
+extern "C" int ddx_gbuffer_fwd_rows(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv,
+                                    const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
+                                    const int32_t* row_range, float* rgb, float* depth, float* cover, void* stream)
+{
     DDX_REQUIRE(rast && mtx && pos && tri && rgb && depth && cover, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
     DDX_REQUIRE((uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_fwd: needs (uv, tex) or vtx_color");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "gbuffer_fwd: bad shape");
     DDX_REQUIRE(((uintptr_t)rast & 15) == 0, DDX_E_ALIGN, "gbuffer_fwd: rast must be 16-byte aligned");
     DDX_REQUIRE_FRAME(B, H, W, "gbuffer_fwd");
     hipStream_t s = (hipStream_t)stream;
-    if (uv && tex) gbuffer_fwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H * W, rgb, depth, cover);
-    else gbuffer_fwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H * W, rgb, depth, cover);
+    if (uv && tex) gbuffer_fwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H * W, rgb, depth, cover, row_range, W);
+    else gbuffer_fwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H * W, rgb, depth, cover, row_range, W);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -765,6 +792,13 @@ extern "C" int ddx_gbuffer_fwd(const float* rast, const float* mtx, const float*
 extern "C" int ddx_gbuffer_bwd(const float* rast, const float* clip, const float* mtx, const float* pos, const int32_t* tri,
                                const float* uv, const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
                                const float* drgb, const float* ddepth, float* dclip, float* dmtx, void* stream)
+{
+    return ddx_gbuffer_bwd_rows(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, vtx_color, B, V, T, H, W, nullptr, drgb, ddepth, dclip, dmtx, stream);
+}
+
+extern "C" int ddx_gbuffer_bwd_rows(const float* rast, const float* clip, const float* mtx, const float* pos, const int32_t* tri,
+                                    const float* uv, const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
+                                    const int32_t* row_range, const float* drgb, const float* ddepth, float* dclip, float* dmtx, void* stream)
 {
     DDX_REQUIRE(rast && clip && mtx && pos && tri && dclip && dmtx, DDX_E_NULL, "gbuffer_bwd: NULL pointer");
     DDX_REQUIRE((uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_bwd: needs (uv, tex) or vtx_color");
@@ -774,8 +808,8 @@ extern "C" int ddx_gbuffer_bwd(const float* rast, const float* clip, const float
     hipStream_t s = (hipStream_t)stream;
     DDX_HIP(hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(dmtx, 0, (size_t)B * 16 * sizeof(float), s));
-    if (uv && tex) gbuffer_bwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H, W, drgb, ddepth, dclip, dmtx, ddx_compat_flags());
-    else gbuffer_bwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H, W, drgb, ddepth, dclip, dmtx, ddx_compat_flags());
+    if (uv && tex) gbuffer_bwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H, W, drgb, ddepth, dclip, dmtx, ddx_compat_flags(), row_range);
+    else gbuffer_bwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, clip, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H, W, drgb, ddepth, dclip, dmtx, ddx_compat_flags(), row_range);
     DDX_LAUNCH_CHECK();
     return 0;
 }

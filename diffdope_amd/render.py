@@ -141,6 +141,21 @@ class _rasterize_func(torch.autograd.Function):
         return None, dpos, None, None
 
 
+def _rasterize_rows(glctx, pos, tri, resolution, emit_all):
+    """Visibility for the fused materialising path (no autograd: its consumers get `rast` detached): (rast [B,H,W,4], row_range
+    [B,2] int32 = first / last pixel row of each hypothesis' active tiles).  emit_all=False: only those rows (+ margin) of `rast`
+    are defined -- it must not leave this module (ddx_rasterize_fwd_rows)."""
+    pos, tri = _f32c(pos.detach(), "pos"), _i32c(tri, "tri")
+    H, W = int(resolution[0]), int(resolution[1])
+    B, V, T = pos.shape[0], pos.shape[1], tri.shape[0]
+    rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device)
+    rows = torch.empty((B, 2), dtype=torch.int32, device=pos.device)  # (a copy: the scratch is overwritten by the context's next call)
+    scratch, nbytes = glctx.scratch(B, V, T, H, W, pos.device)
+    _lib.check(glctx.lib.ddx_rasterize_fwd_rows(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes, _lib.ptr(rast),
+                                                _lib.ptr(rows), int(bool(emit_all)), _lib.stream_ptr()), "ddx_rasterize_fwd_rows")
+    return rast, rows
+
+
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     """dr.rasterize (diffdope.py:198-200).  Returns (rast [B,H,W,4] = (u,v,z/w,tri_id+1), rast_db placeholder that raises
     when consumed)."""
@@ -343,26 +358,26 @@ class _silhouette_func(torch.autograd.Function):
     operand, no copy of the frame, gradient for the clip-space positions only."""
 
     @staticmethod
-    def forward(ctx, cover, rast, pos, tri, opp):
+    def forward(ctx, cover, rast, pos, tri, opp, rows=None):
         rast, pos, tri = _f32c(rast, "rast"), _f32c(pos, "pos"), _i32c(tri, "tri")
         B, H, W = rast.shape[:3]
         V, T = pos.shape[1], tri.shape[0]
-        _lib.check(_lib.load().ddx_silhouette_fwd(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(cover),
-                                                  _lib.stream_ptr()), "ddx_silhouette_fwd")
+        _lib.check(_lib.load().ddx_silhouette_fwd_rows(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(rows),
+                                                       _lib.ptr(cover), _lib.stream_ptr()), "ddx_silhouette_fwd_rows")
         ctx.mark_dirty(cover)
-        ctx.save_for_backward(rast, pos, tri, opp)
+        ctx.save_for_backward(rast, pos, tri, opp, rows)
         return cover
 
     @staticmethod
     def backward(ctx, dmask):
-        rast, pos, tri, opp = ctx.saved_tensors
+        rast, pos, tri, opp, rows = ctx.saved_tensors
         B, H, W = rast.shape[:3]
         V, T = pos.shape[1], tri.shape[0]
         dmask = _f32c(dmask, "dmask")
         dpos = torch.empty_like(pos)
-        _lib.check(_lib.load().ddx_silhouette_bwd(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(dmask),
-                                                  _lib.ptr(dpos), _lib.stream_ptr()), "ddx_silhouette_bwd")
-        return None, None, dpos, None, None
+        _lib.check(_lib.load().ddx_silhouette_bwd_rows(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(rows),
+                                                       _lib.ptr(dmask), _lib.ptr(dpos), _lib.stream_ptr()), "ddx_silhouette_bwd_rows")
+        return None, None, dpos, None, None, None
 
 
 def antialias_construct_topology_hash(tri):
@@ -422,7 +437,7 @@ class _gbuffer_func(torch.autograd.Function):
     frame each way).  pos / uv / tex / vtx_color are ONE copy each ([V,3], [V,2], [Th,Tw,3], [V,3]); they get no gradient."""
 
     @staticmethod
-    def forward(ctx, clip, mtx, rast, pos, tri, uv, tex, vtx_color):
+    def forward(ctx, clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows=None):
         lib = _lib.load()
         clip, mtx, rast = _f32c(clip, "clip"), _f32c(mtx, "mtx"), _f32c(rast, "rast")
         B, H, W = rast.shape[:3]
@@ -432,19 +447,19 @@ class _gbuffer_func(torch.autograd.Function):
         rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
         depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
         cover = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
-        _lib.check(lib.ddx_gbuffer_fwd(_lib.ptr(rast), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv), _lib.ptr(tex), Th, Tw,
-                                       _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(cover), _lib.stream_ptr()),
-                   "ddx_gbuffer_fwd")
-        ctx.save_for_backward(clip, mtx, rast, pos, tri, uv, tex, vtx_color)
+        _lib.check(lib.ddx_gbuffer_fwd_rows(_lib.ptr(rast), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv), _lib.ptr(tex), Th, Tw,
+                                            _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(cover),
+                                            _lib.stream_ptr()), "ddx_gbuffer_fwd_rows")
+        ctx.save_for_backward(clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows)
         ctx.set_materialize_grads(False)  # (an unused output arrives as None instead of a zero-filled 80-240 MB tensor)
         ctx.mark_non_differentiable(cover)  # (the interpolation of a tensor of ones does not depend on the barycentrics)
         return rgb, depth, cover
 
     @staticmethod
     def backward(ctx, drgb, ddepth, _dcover):
-        clip, mtx, rast, pos, tri, uv, tex, vtx_color = ctx.saved_tensors
+        clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows = ctx.saved_tensors
         if drgb is None and ddepth is None:
-            return (None,) * 8
+            return (None,) * 9
         B, H, W = rast.shape[:3]
         V, T = pos.shape[0], tri.shape[0]
         Th, Tw = (tex.shape[0], tex.shape[1]) if tex is not None else (0, 0)
@@ -452,10 +467,10 @@ class _gbuffer_func(torch.autograd.Function):
         ddepth = None if ddepth is None else _f32c(ddepth, "ddepth")
         dclip = torch.empty_like(clip)
         dmtx = torch.empty_like(mtx)
-        _lib.check(_lib.load().ddx_gbuffer_bwd(_lib.ptr(rast), _lib.ptr(clip), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv),
-                                               _lib.ptr(tex), Th, Tw, _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(drgb), _lib.ptr(ddepth),
-                                               _lib.ptr(dclip), _lib.ptr(dmtx), _lib.stream_ptr()), "ddx_gbuffer_bwd")
-        return dclip, dmtx, None, None, None, None, None, None
+        _lib.check(_lib.load().ddx_gbuffer_bwd_rows(_lib.ptr(rast), _lib.ptr(clip), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv),
+                                                    _lib.ptr(tex), Th, Tw, _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(drgb),
+                                                    _lib.ptr(ddepth), _lib.ptr(dclip), _lib.ptr(dmtx), _lib.stream_ptr()), "ddx_gbuffer_bwd_rows")
+        return dclip, dmtx, None, None, None, None, None, None, None
 
 
 _same_index_cache = {}
@@ -490,7 +505,7 @@ def _one_copy(t):
 
 
 def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None, uv_idx=None, tex=None, vtx_color=None,
-                         return_rast_out=False, fused=None):
+                         return_rast_out=False, fused=None, restrict_rows=True):
     """The materialising render of diffdope.py:156-234 (same signature and outputs), for user loss functions that read
     ddope.renders; the built-in losses take the fused engine (diffdope_amd.engine) instead.
 
@@ -502,12 +517,14 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
     makes) and none of them needs a gradient, everything between rasterize and antialias runs as ONE kernel each way
     (ddx_gbuffer_fwd / _bwd); otherwise -- or with fused=False -- op by op through interpolate / texture / xfm_points, like the
     reference.  Both are held to the same oracle.
+    restrict_rows (fused path; round 4): the passes only visit the pixel rows each hypothesis draws into (the rows of its active
+    tiles, from the rasteriser): outside them a pixel is background by construction, so nothing is read there -- the same
+    images and gradients, bit for bit, at a fraction of the traffic (an object at 1.2 % of the frame spans a fifth of the rows).
     """
     H, W = (resolution if isinstance(resolution, (list, tuple)) else (resolution, resolution))
     faces = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
     # clip-space vertices and visibility (:195-200)
     clip = dd_ops.xfm_points(pos.contiguous(), torch.matmul(proj_cam, mtx))
-    rast, _ = rasterize(glctx, clip, faces, resolution=[H, W])
     textured = vtx_color is None
     attrs = (pos, uv, tex) if textured else (pos, vtx_color)
     uv_faces = None if not textured else (uv_idx[0] if uv_idx.dim() == 3 else uv_idx)
@@ -519,14 +536,21 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
         raise RuntimeError("render_texture_batch(fused=True) needs batch-shared (stride-0 or batch-1) pos / uv / tex / vtx_color without "
                            "gradients and uv_idx == pos_idx")
     if fused:
+        # with restrict_rows: visibility without autograd (the fused passes differentiate through clip themselves) and only the rows
+        # a hypothesis draws into emitted -- unless the caller wants the rast image itself
+        if restrict_rows and not return_rast_out:  # (a returned rast keeps its autograd path through dr.rasterize's backward)
+            rast, rows = _rasterize_rows(glctx, clip, _i32c(faces, "pos_idx"), [H, W], emit_all=False)
+        else:
+            rast, rows = rasterize(glctx, clip, faces, resolution=[H, W])[0], None
         p1 = _f32c(_one_copy(pos), "pos")
         kw = dict(uv=_f32c(_one_copy(uv), "uv"), tex=_f32c(_one_copy(tex), "tex"), vtx_color=None) if textured else \
             dict(uv=None, tex=None, vtx_color=_f32c(_one_copy(vtx_color), "vtx_color"))
-        rgb, depth, cover = _gbuffer_func.apply(clip, mtx, rast.detach(), p1, _i32c(faces, "pos_idx"), kw["uv"], kw["tex"], kw["vtx_color"])
+        rgb, depth, cover = _gbuffer_func.apply(clip, mtx, rast.detach(), p1, _i32c(faces, "pos_idx"), kw["uv"], kw["tex"], kw["vtx_color"], rows)
         # the silhouette: antialias blends added in place onto the coverage image (rast detached: antialias has no gradient for
         # it, and an attached one would still make autograd run rasterize's backward on zeros)
-        mask = _silhouette_func.apply(cover, rast.detach(), clip, _i32c(faces, "pos_idx"), build_topology(faces))
+        mask = _silhouette_func.apply(cover, rast.detach(), clip, _i32c(faces, "pos_idx"), build_topology(faces), rows)
         return {"rgb": rgb, "depth": depth, "rast_out": rast if return_rast_out else None, "mask": mask}
+    rast, _ = rasterize(glctx, clip, faces, resolution=[H, W])
     covered = rast[..., 3:].clamp(0, 1)
     # depth: object-space position under each pixel, through the pose, camera z negated (:203-209); a background pixel
     # interpolates to the origin, so its depth is -mtx[2,3], as in the reference

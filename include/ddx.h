@@ -87,6 +87,12 @@ int ddx_pose_matrix_bwd(const float* q, const float* dmtx, int B, float* dq, flo
 size_t ddx_rasterize_scratch_bytes(int B, int V, int T, int H, int W);
 int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
                       void* scratch, size_t scratch_bytes, float* rast, void* stream);
+/* The same, for callers whose consumers of `rast` are this library's fused passes (the *_rows entry points below): row_range
+ * [B,2] int32 (device) receives the first / last pixel row of each hypothesis' active 16x16 tiles (first > last: it draws nothing);
+ * with emit_all = 0 only those rows (+ a margin of 8) of `rast` are written -- the rest of the buffer is NOT defined and must
+ * not be read by anything but the *_rows passes given the same row_range.  emit_all = 1: the whole frame, as ddx_rasterize_fwd. */
+int ddx_rasterize_fwd_rows(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
+                           void* scratch, size_t scratch_bytes, float* rast, int32_t* row_range, int emit_all, void* stream);
 /* drast [B,H,W,4] (channels 0,1 used) -> dpos [B,V,4], fully written (zeroed then accumulated). */
 int ddx_rasterize_bwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
                       const float* rast, const float* drast, float* dpos, void* stream);
@@ -148,6 +154,16 @@ int ddx_gbuffer_fwd(const float* rast, const float* mtx, const float* pos, const
 int ddx_gbuffer_bwd(const float* rast, const float* clip, const float* mtx, const float* pos, const int32_t* tri, const float* uv,
                     const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, const float* drgb,
                     const float* ddepth, float* dclip, float* dmtx, void* stream);
+/* ... restricted to the rows a hypothesis draws into (row_range [B,2] from ddx_rasterize_fwd_rows; NULL = the whole frame): a pixel
+ * outside them is background by construction -- the forward writes rgb = cover = 0, depth = -mtx[2][3] there without reading
+ * `rast`, the backward only adds its d depth to d mtx[2][3] -- so 64 hypotheses of an object that covers a sixth of the rows
+ * stop reading five sixths of `rast`, d rgb and d mask.  Same outputs, bit for bit, as the unrestricted calls. */
+int ddx_gbuffer_fwd_rows(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv, const float* tex,
+                         int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, const int32_t* row_range, float* rgb,
+                         float* depth, float* cover, void* stream);
+int ddx_gbuffer_bwd_rows(const float* rast, const float* clip, const float* mtx, const float* pos, const int32_t* tri, const float* uv,
+                         const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
+                         const int32_t* row_range, const float* drgb, const float* ddepth, float* dclip, float* dmtx, void* stream);
 
 /* The silhouette of render_texture_batch -- dr.antialias applied to the interpolation of a tensor of ones (diffdope.py:212-214) --
  * without a colour operand: the colour IS the coverage (recomputed from rast), so the forward blends IN PLACE on the `cover` image
@@ -158,6 +174,11 @@ int ddx_silhouette_fwd(const float* rast, const float* pos, const int32_t* tri, 
                        float* mask, void* stream);
 int ddx_silhouette_bwd(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
                        const float* dmask, float* dpos, void* stream);
+/* ... restricted to the blocks of rows that can hold a silhouette pair (row_range as above; NULL = the whole frame) */
+int ddx_silhouette_fwd_rows(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
+                            const int32_t* row_range, float* mask, void* stream);
+int ddx_silhouette_bwd_rows(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
+                            const int32_t* row_range, const float* dmask, float* dpos, void* stream);
 
 /* Image-space part of the built-in losses for the op-by-op path (diffdope.py:547-613: l1_rgb_with_mask :547-562,
  * l1_depth_with_mask :565-580, l1_mask :583-613): out[b] = mean_i |(x[b,i] - y[i]) * m[i * m_stride]|, with the observed image y [N]

@@ -133,3 +133,41 @@ def test_selection_inside_the_last_kernel_equals_the_selection_kernel():
         ref = ddist.global_argmin_fused(eng.loss_log[eng.it - 1], mask, eng.mtx_log[eng.it - 1], lo=5)
         assert (gi, gl) == (ref[0], ref[1]) and torch.equal(gm, ref[2])
         eng.check()
+
+
+def test_row_restricted_materialising_path_equals_the_full_frame_one():
+    """render_texture_batch(fused=True): the passes restricted to the rows each hypothesis draws into (ddx_*_rows, round 4) against
+    the same passes over the whole frame: rgb, depth and mask bit for bit, the gradient with respect to the pose matrices up to the order of its atomic additions --
+    hypotheses in the middle of the frame, at its upper and lower border, one that draws nothing at all, and one covering
+    every row."""
+    import diffdope_amd as dd
+    from diffdope_amd import workloads as wl
+    from diffdope_amd.render import RasterizeContext, render_texture_batch
+
+    dev = torch.device("cuda")
+    for name in ("cfg2", "cfg4"):
+        w = wl.build(name, dev, B=6)
+        p = w["params0"].clone()
+        p[5, 1] += 2.2    # towards the upper border
+        p[5, 2] -= 2.4    # the lower border
+        p[4, 3] += 40.0   # out of the frame: draws nothing
+        p[6, 4] = -1.6    # close: every row
+        B, H, W = 6, w["H"], w["W"]
+        ex = lambda t: t[None].expand(B, *t.shape)
+        kw = dict(uv=ex(w["uv"]), uv_idx=ex(w["tri"]), tex=ex(w["tex"])) if w["uv"] is not None else dict(vtx_color=ex(w["vtx_color"]))
+        outs = []
+        for restrict in (False, True):
+            q = p[:4].T / torch.norm(p[:4].T, dim=1, keepdim=True)
+            mtx = dd.matrix_batch_44_from_position_quat(q=q, p=p[4:].T).detach().requires_grad_(True)
+            r = render_texture_batch(RasterizeContext(), ex(w["proj"]), mtx, ex(w["pos"]), ex(w["tri"]), [H, W], fused=True, restrict_rows=restrict, **kw)
+            g = torch.Generator(device="cpu").manual_seed(7)
+            wr, wd, wm = (torch.rand(r[k].shape, generator=g).to(dev) for k in ("rgb", "depth", "mask"))
+            loss = (r["rgb"] * wr).sum() + (r["depth"] * wd).sum() + (r["mask"] * wm).sum()
+            (grad,) = torch.autograd.grad(loss, mtx)
+            outs.append((r["rgb"].detach().clone(), r["depth"].detach().clone(), r["mask"].detach().clone(), grad.clone()))
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(a, b)
+        # (the backward passes accumulate with floating-point atomics: equal up to the order of the additions)
+        ga, gb = outs[0][3], outs[1][3]
+        assert torch.allclose(ga, gb, rtol=2e-4, atol=2e-4 * float(ga.abs().max()))
+        assert float(outs[0][2][1].sum()) > 0 and float(outs[0][2][3].sum()) == 0  # (the shifted one draws, the far one does not)

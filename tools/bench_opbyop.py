@@ -51,6 +51,23 @@ for _ in range(n): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f'{cfg} ({"fused masked-L1 losses" if FUSED_LOSS else "torch loss expressions"}): op-by-op path {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s  (peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB)')
 
+if '--graph' in sys.argv:
+    # the same iteration captured ONCE into a hipGraph (torch.cuda.graph: the library's launches go to torch's current stream, so
+    # they are captured like torch's own) and replayed: what the ~60 framework launches per iteration cost on the host
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for _ in range(3): g.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): g.replay()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    print(f'{cfg}: the same iteration replayed from one captured graph: {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s')
+
 if '--api' in sys.argv:
     # the same workload through DiffDope.run_optimization(fused=False): Object3D / Mesh modules, the built-in loss functions
     # with their per-iteration logs, torch SGD -- what a user loss function forces (api._run_autograd)
