@@ -1906,11 +1906,16 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
 }
 
 #ifndef STEP_MIN_WAVES
-#define STEP_MIN_WAVES 6  // waves per SIMD step_kernel is compiled for (<= 80 registers): 1536 resident 256-thread workgroups
+#define STEP_MIN_WAVES 5  // waves per SIMD step_kernel is compiled for (<= 96 registers): 1280 resident 256-thread workgroups -- exactly the 20 slots x 64
+                          // hypotheses of the headline launch.  (Rounds 2-3 compiled for 6 = 80 registers, which the plain variant met with 48 bytes of
+                          // scratch per lane and the others not at all; at 5 nothing spills: cfg2 41.3 -> 40.8 us, cfg4 50.7 -> 48.9, cfg5 85.0 -> 82.3,
+                          // everything else within +-1 %, 512-hypothesis batches unchanged)
 #endif
+// (the hybrid scatter variant -- close-ups -- needs 117 registers: 4 waves per SIMD, as it always ran)
+#define STEP_WAVES(MODE) ((MODE) == 2 ? 4 : STEP_MIN_WAVES)
 // grid (slots, B), or (B, slots) with E.step_xcd
 template <int TPL, int NTH, int MODE, bool TAB = false>
-__global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, int mode, int it_arg)
+__global__ __launch_bounds__(NTH, STEP_WAVES(MODE)) void step_kernel(EngineDev E, int mode, int it_arg)
 {
     // (TAB: always the slot-major grid (B, slots))
     if (TAB) step_wg<TPL, NTH, MODE, true>(E, blockIdx.x, blockIdx.y, gridDim.y, mode, it_arg);
@@ -1919,7 +1924,7 @@ __global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_kernel(EngineDev E, 
 
 // group form: grid (largest slot count, sum of the members' hypotheses)
 template <int TPL, int NTH, int MODE>
-__global__ __launch_bounds__(NTH, STEP_MIN_WAVES) void step_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int mode, int it_arg)
+__global__ __launch_bounds__(NTH, STEP_WAVES(MODE)) void step_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int mode, int it_arg)
 {
     const int o = group_find(G, blockIdx.y);
     if ((int)blockIdx.x >= G.sl[o]) return;
