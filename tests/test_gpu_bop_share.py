@@ -72,7 +72,7 @@ def test_config5_share_four_objects_64_hypotheses_1280x720(tmp_path, H, W, rows,
                                     lr_decay=0.1, seed=5))
     # ---- the four local objects as ONE engine group (one launch of each kernel per iteration)
     table, handles = bop.refine_frame(cfg, dd.Camera(**intr), scene, objs, meshes, masks, optimizer="sgd", mode="group")
-    # ... one stream per object (the driver's default since round 4) gives the same bits
+    # ... one stream per object gives the same bits
     table_s, handles_s = bop.refine_frame(cfg, dd.Camera(**intr), scene, objs, meshes, masks, optimizer="sgd", mode="streams")
     assert torch.equal(table, table_s)
     for i in range(4):
