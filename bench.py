@@ -15,6 +15,7 @@ GPU, global batch 64*N in the batch-mean factor) with ONE all_reduce for the glo
 Rank 0 prints one JSON line; see DESIGN.md "Measurement" for every field.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -263,6 +264,11 @@ def main():
         (incl. the one all_reduce) between barrier + synchronize, max over ranks.  Optionally `repeats` more windows of the
         same engine, each restarted from the initial poses with a fresh optimiser state and the same W warm-up iterations
         (the same rows of the schedule, the same work), for a median."""
+        # (the interpreter's cyclic collector stays off from here to the end of the measurement, as in timeit: a generation-2
+        # collection -- 1.3 ms with torch loaded -- landed in the first window of some workloads and not of others, by allocation
+        # count; and collecting right before a window leaves the GPU idle for milliseconds, after which the window itself runs
+        # 8-10 us per iteration slower.  tools/first_window.py)
+        gc.disable()
         lrs = wl.bench_lr_schedule(n_it, optimizer)
         lo_w = lo if lo_w is None else lo_w
         eng, params = wl.engine_for(w, lrs, optimizer=optimizer, global_batch=global_w or w["global_B"])
@@ -298,6 +304,7 @@ def main():
             if args.warmup > 0:
                 eng.run(args.warmup, use_graph=args.graph)
             extra.append(window()[0])
+        gc.enable()
         return dict(elapsed=elapsed, best=best, status=st, params=final, per_hyp=per_hyp, lrs=lrs, repeats=extra, eng=eng)
 
     w = wl.build(args.config, dev, B=Bl, global_lo=lo, global_B=B_job, distance=args.distance)

@@ -30,7 +30,7 @@ class EngineDesc(ctypes.Structure):
         ("adam_beta1", ctypes.c_float), ("adam_beta2", ctypes.c_float), ("adam_eps", ctypes.c_float),
         ("max_iters", ctypes.c_int32), ("use_edge", ctypes.c_int32), ("w_edge", ctypes.c_float),
         ("shade_slices", ctypes.c_int32), ("edge_slices", ctypes.c_int32), ("no_backface_cull", ctypes.c_int32),
-        ("compat", ctypes.c_int32), ("separate_big_pass", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1),
+        ("compat", ctypes.c_int32), ("separate_big_pass", ctypes.c_int32), ("single_stream", ctypes.c_int32),
     ]
 
 

@@ -198,6 +198,7 @@ struct EngineDev {
     float* eval_tmp;         // [7,B] gradient sink of ddx_render_loss_fwd
     float* sel_out;          // [18] or null.  Non-null (finish_kernel of ddx_engine_run_select): (mean loss of the best hypothesis, its
     int sel_lo;              // global index = sel_lo + local index, its 4x4 pose) is written here by the last writer workgroup
+    int b_off;               // first hypothesis of this launch (0 except in the half-batch launches of a two-stream run, engine_run_impl)
 };
 
 #define TRACE_WG 4096
@@ -225,6 +226,10 @@ struct ddx_engine {
     int balance_min_per_slot = 4;  // DDX_STEP_BALANCE_MIN
     bool small_mesh = false; // step_kernel variant: one triangle per lane in 64-thread workgroups (few triangles x hypotheses)
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
+    int two_streams = 1;     // DDX_TWO_STREAMS: 1 = the iterations of a run after its first as two half-batch chains on two streams, 0 = never
+    int two_min_iters = 48;  // ... for runs of at least this many iterations (DDX_TWO_MIN)
+    hipStream_t side = nullptr;  // ... the second stream, and the events that fork it from / join it to the caller's
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
@@ -1248,19 +1253,20 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
     if (tid == 0 && E.trace && wg_id < TRACE_WG) E.trace[((size_t)TRACE_WG + wg_id) * 8 + 4] = ((unsigned long long)z << 32) | (unsigned)tw.n_mine;
 }
 
-template <bool EDGE>
+// (HALF: the same kernel under a second name, for the half-batch launches of a two-stream run -- a profile lists them apart)
+template <bool EDGE, bool HALF = false>
 __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E, int it_arg)
 {
     // grid (B, S, roles), or (B, S, 1 + roles) with the tile pass inside the launch: slab z = 0 = its workers
     int z = blockIdx.z;
     if (E.big_inline) {
         if (z == 0) {
-            big_worker_wg(E, blockIdx.x, blockIdx.y, gridDim.y, it_arg);
+            big_worker_wg(E, E.b_off + blockIdx.x, blockIdx.y, gridDim.y, it_arg);
             return;
         }
         --z;
     }
-    shade_wg<EDGE>(E, blockIdx.x, blockIdx.y, gridDim.y, z, it_arg);
+    shade_wg<EDGE>(E, E.b_off + blockIdx.x, blockIdx.y, gridDim.y, z, it_arg);
 }
 
 // group form: grid (sum of the members' hypotheses, largest slice count, 2)
@@ -1428,7 +1434,8 @@ __device__ __forceinline__ void edge_wg(const EngineDev& E, int b, int sl, int S
     }
 }
 
-__global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg) { edge_wg(E, blockIdx.x, blockIdx.y, gridDim.y, it_arg); }
+template <bool HALF = false>
+__global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg) { edge_wg(E, E.b_off + blockIdx.x, blockIdx.y, gridDim.y, it_arg); }
 
 // group form: grid (sum of the members' hypotheses, largest slice count); members without the edge term leave at once
 __global__ __launch_bounds__(256) void edge_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
@@ -1914,12 +1921,12 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
 // (the hybrid scatter variant -- close-ups -- needs 117 registers: 4 waves per SIMD, as it always ran)
 #define STEP_WAVES(MODE) ((MODE) == 2 ? 4 : STEP_MIN_WAVES)
 // grid (slots, B), or (B, slots) with E.step_xcd
-template <int TPL, int NTH, int MODE, bool TAB = false>
+template <int TPL, int NTH, int MODE, bool TAB = false, bool HALF = false>
 __global__ __launch_bounds__(NTH, STEP_WAVES(MODE)) void step_kernel(EngineDev E, int mode, int it_arg)
 {
     // (TAB: always the slot-major grid (B, slots))
-    if (TAB) step_wg<TPL, NTH, MODE, true>(E, blockIdx.x, blockIdx.y, gridDim.y, mode, it_arg);
-    else step_wg<TPL, NTH, MODE, false>(E, E.step_xcd ? blockIdx.x : blockIdx.y, E.step_xcd ? blockIdx.y : blockIdx.x, E.step_xcd ? gridDim.y : gridDim.x, mode, it_arg);
+    if (TAB) step_wg<TPL, NTH, MODE, true>(E, E.b_off + blockIdx.x, blockIdx.y, gridDim.y, mode, it_arg);
+    else step_wg<TPL, NTH, MODE, false>(E, E.b_off + (E.step_xcd ? blockIdx.x : blockIdx.y), E.step_xcd ? blockIdx.y : blockIdx.x, E.step_xcd ? gridDim.y : gridDim.x, mode, it_arg);
 }
 
 // group form: grid (largest slot count, sum of the members' hypotheses)
@@ -2125,13 +2132,13 @@ static int balance_slots(ddx_engine* e, int SL, hipStream_t s)
     return 0;
 }
 
-static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
+// slots (workgroups) per hypothesis of step_kernel, and whether the slot table (balance_slots) applies to this engine
+static int step_slots(ddx_engine* e, bool* can_balance)
 {
-    RoctxRange rr("ddx.step_kernel");
     EngineDev& E = e->dev;
-    // slots (workgroups) per hypothesis: every workgroup the same number of meshlets, all of them resident -- a second round of
-    // workgroups would pay the head's chain again -- and at least a few, because the slots also share the re-arm of the tiles the
-    // previous iteration dirtied (a slot beyond the meshlet count does just that)
+    // every workgroup the same number of meshlets, all of them resident -- a second round of workgroups would pay the head's chain
+    // again -- and at least a few, because the slots also share the re-arm of the tiles the previous iteration dirtied (a slot
+    // beyond the meshlet count does just that)
     if (e->step_resident <= 0) e->step_resident = step_capacity(e);
     int SL = std::max(1, std::min(E.n_meshlets, e->step_resident / E.d.B));
     SL = ddx_cdiv(E.n_meshlets, ddx_cdiv(E.n_meshlets, SL));  // (npw = ceil(M / SL) meshlets each; step_kernel computes the same npw)
@@ -2139,7 +2146,19 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
     // balanced shares (slot table): the first step launch after a set-up runs with equal shares and records what every meshlet cost
     // (worth it from a few meshlets per slot on -- the 51 200-triangle meshes: cfg3 +5 %, cfg50k64 +7 %; with two meshlets per slot
     // the longest-first hand-out has nothing to even out and the measured times are not additive enough: cfg2 -2 %, midpoly -7 %)
-    const bool can_balance = e->balance && SL > 1 && SL <= 64 && E.n_meshlets <= 192 && E.n_meshlets >= e->balance_min_per_slot * SL;
+    *can_balance = e->balance && SL > 1 && SL <= 64 && E.n_meshlets <= 192 && E.n_meshlets >= e->balance_min_per_slot * SL;
+    return SL;
+}
+
+// half: -1 = all hypotheses; 0 / 1 = the first / second half of them (two-stream runs: same slots, same bits, half the grid)
+static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s, int half = -1)
+{
+    RoctxRange rr("ddx.step_kernel");
+    EngineDev& E = e->dev;
+    const int nb = half < 0 ? E.d.B : E.d.B / 2;
+    E.b_off = half > 0 ? nb : 0;
+    bool can_balance = false;
+    const int SL = step_slots(e, &can_balance);
     // (the table variant of the kernel is a separate instantiation with the slot-major grid -- a slot's place in the dispatch order
     // is then the same for every hypothesis --; the equal-share variant stays the code it was: with the table logic compiled into it
     // it ran 1.3-3 us slower on every workload that does not use it)
@@ -2152,14 +2171,18 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
     const bool calibrate = can_balance && !e->balanced && mode == STEP_FIRST && !E.eval_grad && !capturing;
     if (calibrate) { E.slot_table = 0; E.mcost_rec = 1; }
     const bool tab = can_balance && (calibrate || E.slot_table);
-    const dim3 g = (tab || E.step_xcd) ? dim3(E.d.B, SL) : dim3(SL, E.d.B);
+    const dim3 g = (tab || E.step_xcd) ? dim3(nb, SL) : dim3(SL, nb);
 #define STEP_LAUNCH(TPL, NTH, MODE)                                                          \
     do {                                                                                     \
-        if (tab) step_kernel<TPL, NTH, MODE, true><<<g, NTH, 0, s>>>(E, mode, it);           \
+        if (half >= 0) {                                                                     \
+            if (tab) step_kernel<TPL, NTH, MODE, true, true><<<g, NTH, 0, s>>>(E, mode, it); \
+            else step_kernel<TPL, NTH, MODE, false, true><<<g, NTH, 0, s>>>(E, mode, it);    \
+        } else if (tab) step_kernel<TPL, NTH, MODE, true><<<g, NTH, 0, s>>>(E, mode, it);    \
         else step_kernel<TPL, NTH, MODE, false><<<g, NTH, 0, s>>>(E, mode, it);              \
     } while (0)
     STEP_DISPATCH(STEP_LAUNCH);
 #undef STEP_LAUNCH
+    E.b_off = 0;
     DDX_LAUNCH_CHECK();
     if (calibrate) {
         E.mcost_rec = 0;
@@ -2169,10 +2192,12 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s)
 }
 
 // the rest of an iteration after its step_kernel: tile pass for large triangles, shading (+ edge term)
-static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */)
+static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */, int half = -1)
 {
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
+    const int nb = half < 0 ? d.B : d.B / 2;
+    E.b_off = half > 0 ? nb : 0;
     if (ev) DDX_HIP(hipEventRecord(ev[K_BIG], s));
     if (!E.big_inline) {
         RoctxRange rr("ddx.big_pass_kernel");
@@ -2181,15 +2206,20 @@ static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K
     if (ev) DDX_HIP(hipEventRecord(ev[K_SHADE], s));
     {
         RoctxRange rr("ddx.shade_kernel");
-        const dim3 g(d.B, E.s_shade, E.n_roles + (E.big_inline ? 1 : 0));  // (the slices fixed at creation: the partial rows are laid out for them)
-        if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E, it);
+        const dim3 g(nb, E.s_shade, E.n_roles + (E.big_inline ? 1 : 0));  // (the slices fixed at creation: the partial rows are laid out for them)
+        if (half >= 0) {
+            if (d.use_edge) shade_kernel<true, true><<<g, 256, 0, s>>>(E, it);
+            else shade_kernel<false, true><<<g, 256, 0, s>>>(E, it);
+        } else if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E, it);
         else shade_kernel<false><<<g, 256, 0, s>>>(E, it);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
     if (d.use_edge) {
         RoctxRange rr("ddx.edge_kernel");
-        edge_kernel<<<dim3(d.B, E.s_edge), 256, 0, s>>>(E, it);
+        if (half >= 0) edge_kernel<true><<<dim3(nb, E.s_edge), 256, 0, s>>>(E, it);
+        else edge_kernel<false><<<dim3(nb, E.s_edge), 256, 0, s>>>(E, it);
     }
+    E.b_off = 0;
     if (ev) DDX_HIP(hipEventRecord(ev[K_FINISH], s));
     DDX_LAUNCH_CHECK();
     return 0;
@@ -2290,6 +2320,8 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         // Whether this engine uses it is decided by the set-up (engine_setup: are large triangles to be expected at all?)
         e->inline_ok = !desc->separate_big_pass && desc->B % 8 == 0;
         if (const char* ov = getenv("DDX_BIG_INLINE")) e->inline_env = atoi(ov) != 0;
+        if (const char* ov = getenv("DDX_TWO_STREAMS")) e->two_streams = atoi(ov);
+        if (const char* ov = getenv("DDX_TWO_MIN")) e->two_min_iters = std::max(2, atoi(ov));
         E.big_inline = 0;
         E.big_workers = 64;
         if (const char* ov = getenv("DDX_BIG_WORKERS")) E.big_workers = std::max(1, atoi(ov));
@@ -2765,6 +2797,27 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
 
 static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* stream, float* sel_out, int sel_lo);
 
+// the engine's own stream for the second chain of a two-stream run (engine_run_impl), created -- and its queue woken with an
+// empty launch -- by the set-up of an engine that may use it: a stream's first submission costs milliseconds
+__global__ void side_wake_kernel() {}
+
+static bool two_streams_possible(const ddx_engine* e)
+{
+    const EngineDev& E = e->dev;
+    return e->two_streams > 0 && !E.d.single_stream && E.big_inline && E.d.B >= 32 && E.d.B % 16 == 0;
+}
+
+static int ensure_side_stream(ddx_engine* e)
+{
+    if (e->side) return 0;
+    DDX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    DDX_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    DDX_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    side_wake_kernel<<<1, 64, 0, e->side>>>();
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream)
 {
     return engine_run_impl(e, it0, n, use_graph, stream, nullptr, 0);
@@ -2784,13 +2837,29 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
     DDX_REQUIRE(it0 >= 0 && n >= 0 && it0 + n <= e->dev.d.max_iters, DDX_E_SHAPE, "engine_run: iterations [%d,%d) exceed max_iters=%d", it0,
                 it0 + n, e->dev.d.max_iters);
     hipStream_t s = (hipStream_t)stream;
-    if (!e->setup_done)
+    if (!e->setup_done) {
         if (int err = engine_setup(e, s)) return err;
+        if (two_streams_possible(e))
+            if (int err = ensure_side_stream(e)) return err;
+    }
     if (n == 0) return 0;
     RoctxRange rr("ddx_engine_run");
     if (int err = run_prologue(e, it0, s)) return err;
     // iteration it0 is drawn from the caller's parameters; each later step_kernel first steps the optimiser for the iteration
     // before it; finish_kernel steps it for the last one
+    // Long runs: the iterations after the first as two chains of half-batch launches, one on the caller's stream and one on a
+    // stream of the engine's own, forked from and joined to the caller's by events -- one chain's kernel boundaries and launch
+    // prologues are covered by the other chain's work (cfg2: 40.0 -> 38.0 us per iteration; fork + join cost 31 us per run, even
+    // at 40 iterations: hence two_min_iters).  Every hypothesis runs the slots, slices and sums it runs in the full launches --
+    // the same bits --; the words the halves share are the status counters (rewritten by finish_kernel after the join) and the
+    // tile pass's global "a large triangle exists" word, which only the separate big_pass_kernel reads: hence big_inline only.
+    // (Forking before the first iteration as well measured 7 us worse per run.)
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        capturing = hipStreamIsCapturing(s, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
+    }
+    const bool two = two_streams_possible(e) && !use_graph && !capturing && n >= e->two_min_iters && !e->dev.trace;
     if (int err = launch_step(e, STEP_FIRST, it0, s)) return err;
     if (int err = launch_rest(e, it0, s, nullptr)) return err;
     if (use_graph && !e->exec && n > 1) {
@@ -2809,7 +2878,20 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         DDX_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
         DDX_HIP(hipStreamDestroy(cs));
     }
-    for (int i = 1; i < n;) {
+    if (two) {
+        if (int err = ensure_side_stream(e)) return err;
+        DDX_HIP(hipEventRecord(e->ev_fork, s));
+        DDX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        for (int i = 1; i < n; ++i) {
+            if (int err = launch_step(e, STEP_NORMAL, it0 + i, s, 0)) return err;
+            if (int err = launch_step(e, STEP_NORMAL, it0 + i, e->side, 1)) return err;
+            if (int err = launch_rest(e, it0 + i, s, nullptr, 0)) return err;
+            if (int err = launch_rest(e, it0 + i, e->side, nullptr, 1)) return err;
+        }
+        DDX_HIP(hipEventRecord(e->ev_join, e->side));
+        DDX_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
+    }
+    for (int i = two ? n : 1; i < n;) {
         if (use_graph && e->exec && i + e->graph_chunk <= n) {
             DDX_HIP(hipGraphLaunch(e->exec, s));
             i += e->graph_chunk;
@@ -3219,6 +3301,9 @@ extern "C" void ddx_engine_destroy(ddx_engine* e)
     if (e->dev.trace) (void)hipFree(e->dev.trace);
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     delete e;
 }
 

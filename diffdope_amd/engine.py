@@ -49,11 +49,13 @@ class RefineEngine:
             no_backface_cull; identical visibility in exact arithmetic).  False = always draw both faces.
         separate_big_pass: True = the tile pass for large / near-clipped triangles always as its own launch (ddx.h separate_big_pass);
             default: the set-up decides from the expected triangle size (no launch where no large triangle is expected; same results).
+        single_stream: True = every launch of a run on the caller's stream (ddx.h single_stream); default: a run of 48 or more
+            iterations goes out as two half-batch chains, one of them on a stream the engine owns (same results, bit for bit).
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
                  vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True, shade_slices=0,
-                 edge_slices=0, cull_backfaces=True, compat=None, separate_big_pass=False):
+                 edge_slices=0, cull_backfaces=True, compat=None, separate_big_pass=False, single_stream=False):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":
@@ -97,6 +99,7 @@ class RefineEngine:
         d.shade_slices, d.edge_slices = int(shade_slices), int(edge_slices)
         d.no_backface_cull = int(not cull_backfaces)
         d.separate_big_pass = int(bool(separate_big_pass))
+        d.single_stream = int(bool(single_stream))
         d.compat = {None: 0, "nvdiffrast": _lib.COMPAT_UNCLAMPED_BARY_GRAD}[compat]
         self.desc = d
         nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))

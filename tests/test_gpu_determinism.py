@@ -96,6 +96,41 @@ def test_tile_pass_inside_the_shading_launch_equals_the_separate_launch(name, B,
     assert torch.equal(b[0], b[4]) and torch.equal(b[0], b[6]) and torch.equal(b[1], b[5])  # group members == the engine alone
 
 
+@pytest.mark.parametrize("name,B", [("cfg2", 64), ("cfg4", 32), ("cfg3", 48), ("cfg50k64", 64)])
+def test_long_runs_on_two_streams_equal_the_single_chain(name, B):
+    """Round 4: a run of 48+ iterations goes out as two chains of half-batch launches, one on a stream the engine owns, forked
+    from and joined to the caller's stream by events (engine.hip engine_run_impl, ddx.h single_stream).  Every hypothesis runs
+    the slots, slices and sums of the full launches: parameters, loss log, pose log and status equal the single chain bit for
+    bit -- on the caller's stream WITHOUT a host synchronisation before the comparison (the join orders the copy after both
+    chains), run after run, on a side stream of the caller's, and through the fused selection."""
+    from diffdope_amd import dist as ddist, workloads as wl
+
+    dev = torch.device("cuda")
+    n_it = 120
+    w = wl.build(name, dev, B=B)
+    lrs = wl.bench_lr_schedule(n_it, "adam")
+    out = {}
+    for single in (True, False):
+        e, p = wl.engine_for(w, lrs, optimizer="adam", single_stream=single)
+        e.run(50)
+        snap = p.clone()  # (enqueued on the caller's stream right behind the run: sees both chains' parameters)
+        e.run(10)         # (short: one chain)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            e.run(50)
+            snap2 = p.clone()
+        torch.cuda.current_stream().wait_stream(st)
+        best = ddist.run_and_select(e, 10, lo=3)
+        e.finish()
+        out[single] = (snap, snap2, p.clone(), e.losses().clone(), e.mtx_log.clone(), best, e.check())
+    a, b = out[True], out[False]
+    assert a[6] == b[6]
+    assert a[5][:2] == b[5][:2] and torch.equal(a[5][2], b[5][2])
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+
+
 def test_selection_inside_the_last_kernel_equals_the_selection_kernel():
     """ddx_engine_run_select (round 4): the arg-min over the local hypotheses folded into finish_kernel -- atomicMin of (loss bits,
     index) + an arrival count -- against ddx_select_best on the same iteration's rows: same index (ties to the LOWEST index: two
