@@ -196,6 +196,11 @@ def main():
     ap.add_argument("--no-convergence", action="store_true", help="skip the untimed 200-iteration convergence leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (reference SGD, close-up at distance 3.75, repeats)")
     ap.add_argument("--repeats", type=int, default=5, help="extra timed windows of --steps iterations after the contract's one (median reported beside it)")
+    ap.add_argument("--settle-ms", type=float, default=15.0,
+                    help="before the W warm-up iterations: run the engine for this long, untimed, then restore the initial poses and a fresh optimiser "
+                         "state (0 = off).  The board's power management needs ~7 ms of the engine's own load to settle: an identical 20-iteration "
+                         "window takes 44.6 us per iteration 13 ms into a process and 40.0 us after 7 ms more of the same work, and 43.6 us again "
+                         "after 50 ms of idling (tools/ramp_probe.py, profiles/r4c_ramp_probe.log); other device work does not substitute")
     ap.add_argument("--graph", type=int, nargs="?", const=1, default=0, help="replay captured hipGraphs of K iterations (default 1; measured 9 %% slower than plain stream launches at K=1, equal at K=20)")
     args = ap.parse_args()
 
@@ -289,6 +294,15 @@ def main():
                 el = float(tmax.item())
             return el, best
 
+        if args.settle_ms > 0:
+            # steady state of the device before anything is timed (--settle-ms): the same engine, the same iterations; afterwards
+            # the engine is put back exactly as the repeat windows below put it back
+            t_s = time.perf_counter()
+            while time.perf_counter() - t_s < args.settle_ms * 1e-3:
+                eng.run(n_it)
+                torch.cuda.synchronize()
+                eng.rewind(0)
+            eng.new_observation(params=w["params0"])
         if args.warmup > 0:
             ddist.run_and_select(eng, args.warmup, lo=lo_w, use_graph=args.graph)  # (warms the selection path too: pinned row, RCCL channels)
         elapsed, best = window()
@@ -320,17 +334,31 @@ def main():
         V, T, HW = w["V"], w["T"], w["H"] * w["W"]
         alg = algorithmic_bytes(V, T, HW, Bl)
         # per-kernel launch durations, live, HIP events on the launch stream (a second engine: profiling mutates poses)
-        eng2, _ = wl.engine_for(w, r["lrs"], optimizer=args.optimizer, global_batch=B_job)
-        eng2.run(min(args.warmup, n_it - 1))
+        # (one chain of full-batch launches: what a launch duration means.  The timed region above runs 16+ iterations as two
+        # half-batch chains on two streams -- their kernels overlap each other --; the same window as ONE chain is timed here,
+        # untimed for the contract, and the per-kernel shares below are shares of THAT iteration)
+        eng2, _ = wl.engine_for(w, r["lrs"], optimizer=args.optimizer, global_batch=B_job, single_stream=True)
+        wu2 = min(args.warmup, n_it - 1)
+        eng2.run(wu2)
         torch.cuda.synchronize()
-        kms_ev = eng2.profile(it0=min(args.warmup, n_it - 1), iters=max(1, min(20, n_it - args.warmup)))
+        kms_ev = eng2.profile(it0=wu2, iters=max(1, min(20, n_it - args.warmup)))
+        one_chain = []
+        for _ in range(3):
+            eng2.new_observation(params=w["params0"])
+            eng2.run(wu2)
+            torch.cuda.synchronize()
+            t1c = time.perf_counter()
+            eng2.run(n_it - wu2)
+            torch.cuda.synchronize()
+            one_chain.append((time.perf_counter() - t1c) / (n_it - wu2) * 1e3)
+        ms_one_chain = sorted(one_chain)[1]
         ms_per_step = elapsed / args.steps * 1e3
         # An event between two kernels of the stream costs ~3-4 us per kernel (the launches are no longer back to back), so
-        # the event-bracketed durations sum to more than the iteration itself.  The timed region above IS the four kernels
-        # back to back (rocprofv3: they sum to the iteration within 1 us, profiles/), so each kernel's share of the timed
-        # iteration is its event-measured share: kernel_ms = kernel_ms_events * ms_per_step / sum(kernel_ms_events).
+        # the event-bracketed durations sum to more than the iteration itself.  The one-chain window IS the kernels back to
+        # back (rocprofv3: they sum to the iteration within 1 us, profiles/), so each kernel's share of that iteration is its
+        # event-measured share: kernel_ms = kernel_ms_events * ms_one_chain / sum(kernel_ms_events).
         per_it = [k for k in kms_ev if k != "finish_kernel"]  # (finish_kernel runs once per run, not per iteration)
-        ev_scale = min(1.0, ms_per_step / max(sum(kms_ev[k] for k in per_it), 1e-9))
+        ev_scale = min(1.0, ms_one_chain / max(sum(kms_ev[k] for k in per_it), 1e-9))
         kms = {k: v * (ev_scale if k in per_it else 1.0) for k, v in kms_ev.items()}
         groups = {"step_stage": kms["step_kernel"] + kms["big_pass_kernel"], "shade_stage": kms["shade_kernel"] + kms["edge_kernel"]}
         dom = max(("shade_kernel", "step_kernel"), key=lambda k: kms[k])
@@ -341,7 +369,8 @@ def main():
         pmc, pmc_src = _latest_profile(f"_pmc_sq_{wkey}.json")
         kp = None
         if pmc:
-            kp = next((v for k, v in pmc["kernels"].items() if dom in k and v.get("launches", 0) > 4), None)
+            # (the full-batch launches: the half-batch launches of a two-stream run carry a last template argument `true`)
+            kp = next((v for k, v in pmc["kernels"].items() if dom in k and not k.rstrip().endswith("true>") and v.get("launches", 0) > 4), None)
         # counters measured on other kernel sources than the ones running now are not this build's: reported as stale, never as frac
         stale = bool(pmc) and pmc.get("csrc_sha16") != csrc_sha16()
         valu_insts = kp.get("SQ_INSTS_VALU") if kp else None
@@ -380,7 +409,10 @@ def main():
                      # about twice `frac`; the larger of the two is the honest "how busy is the VALU" (0.72 at saturation)
                      "busy_frac": (valu_active_q * 4.0 / (1024 * 2.4e9 * dom_s)) if (valu_active_q and not stale) else None},
             "iteration": {"compulsory_bytes": comp["iteration"], "achieved_GBps": comp["iteration"] / (ms_per_step * 1e-3) / 1e9,
-                          "frac": comp["iteration"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          "frac": comp["iteration"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          # the timed window's iteration, and the same window as one chain of full-batch launches (median of 3, no
+                          # selection): the launch durations above are shares of the latter
+                          "ms": ms_per_step, "ms_one_chain": ms_one_chain},
             # the request view, per kind of line: lines NO lane shares (one 64-byte texel record per covered pixel: the colour role's
             # gather, the one load of the shading launch whose removal shortens it) against the measured rate of random 64-byte
             # records (tools/ubench/gather_rate.hip); COALESCED store lines of step_kernel (16 B clip + 8 B snap per vertex, whole
@@ -416,7 +448,7 @@ def main():
             "config": {"workload": f"{args.config}: blob mesh T={T} V={V}, tex {tex_hw[0]}^2, {w['W']}x{w['H']}, {Bl} hyps/GPU, "
                                    f"losses {'+'.join(sorted(w['weights']))}, {args.optimizer}, coverage {100 * w['coverage']:.2f}%",
                        "hypotheses_per_gpu": Bl, "global_hypotheses": B_job, "parallelism": f"hyp-shard x{world}",
-                       "hipgraph": bool(args.graph)},
+                       "hipgraph": bool(args.graph), "settle_ms": args.settle_ms},
             "dist": dist_info,
             "hypothesis_iters_per_s": B_job * job_iters,
             "roofline": roof,

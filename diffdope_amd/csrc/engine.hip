@@ -227,7 +227,8 @@ struct ddx_engine {
     bool small_mesh = false; // step_kernel variant: one triangle per lane in 64-thread workgroups (few triangles x hypotheses)
     int adam_parity = 0;  // which half of dev.adam holds the optimiser state of the last finished iteration
     int two_streams = 1;     // DDX_TWO_STREAMS: 1 = the iterations of a run after its first as two half-batch chains on two streams, 0 = never
-    int two_min_iters = 48;  // ... for runs of at least this many iterations (DDX_TWO_MIN)
+    bool two_min_env = false;
+    int two_min_iters = 16;  // ... for runs of at least this many iterations (DDX_TWO_MIN)
     hipStream_t side = nullptr;  // ... the second stream, and the events that fork it from / join it to the caller's
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
@@ -2321,7 +2322,7 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         e->inline_ok = !desc->separate_big_pass && desc->B % 8 == 0;
         if (const char* ov = getenv("DDX_BIG_INLINE")) e->inline_env = atoi(ov) != 0;
         if (const char* ov = getenv("DDX_TWO_STREAMS")) e->two_streams = atoi(ov);
-        if (const char* ov = getenv("DDX_TWO_MIN")) e->two_min_iters = std::max(2, atoi(ov));
+        if (const char* ov = getenv("DDX_TWO_MIN")) { e->two_min_iters = std::max(2, atoi(ov)); e->two_min_env = true; }
         E.big_inline = 0;
         E.big_workers = 64;
         if (const char* ov = getenv("DDX_BIG_WORKERS")) E.big_workers = std::max(1, atoi(ov));
@@ -2849,8 +2850,9 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
     // before it; finish_kernel steps it for the last one
     // Long runs: the iterations after the first as two chains of half-batch launches, one on the caller's stream and one on a
     // stream of the engine's own, forked from and joined to the caller's by events -- one chain's kernel boundaries and launch
-    // prologues are covered by the other chain's work (cfg2: 40.0 -> 38.0 us per iteration; fork + join cost 31 us per run, even
-    // at 40 iterations: hence two_min_iters).  Every hypothesis runs the slots, slices and sums it runs in the full launches --
+    // prologues are covered by the other chain's work (cfg2: 40.0 -> 37.8 us per iteration; fork + join cost 25-30 us per run: even
+    // at 14-16 iterations, 1.5 % ahead at 20, 4.7 % at 48, 6 % at 100 -- tools/two_stream_threshold.py --: hence two_min_iters).
+    // Every hypothesis runs the slots, slices and sums it runs in the full launches --
     // the same bits --; the words the halves share are the status counters (rewritten by finish_kernel after the join) and the
     // tile pass's global "a large triangle exists" word, which only the separate big_pass_kernel reads: hence big_inline only.
     // (Forking before the first iteration as well measured 7 us worse per run.)
@@ -2859,7 +2861,10 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         capturing = hipStreamIsCapturing(s, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
     }
-    const bool two = two_streams_possible(e) && !use_graph && !capturing && n >= e->two_min_iters && !e->dev.trace;
+    // (with the slot table -- the 51 200-triangle meshes -- the half launches only pay from ~40 iterations on: cfg50k64 +10 us at 20,
+    // -31 us at 48, -57 us at 64)
+    const int two_min = e->dev.slot_table ? std::max(e->two_min_iters, e->two_min_env ? 0 : 48) : e->two_min_iters;
+    const bool two = two_streams_possible(e) && !use_graph && !capturing && n >= two_min && !e->dev.trace;
     if (int err = launch_step(e, STEP_FIRST, it0, s)) return err;
     if (int err = launch_rest(e, it0, s, nullptr)) return err;
     if (use_graph && !e->exec && n > 1) {

@@ -49,7 +49,7 @@ class RefineEngine:
             no_backface_cull; identical visibility in exact arithmetic).  False = always draw both faces.
         separate_big_pass: True = the tile pass for large / near-clipped triangles always as its own launch (ddx.h separate_big_pass);
             default: the set-up decides from the expected triangle size (no launch where no large triangle is expected; same results).
-        single_stream: True = every launch of a run on the caller's stream (ddx.h single_stream); default: a run of 48 or more
+        single_stream: True = every launch of a run on the caller's stream (ddx.h single_stream); default: a run of 16 or more
             iterations goes out as two half-batch chains, one of them on a stream the engine owns (same results, bit for bit).
     """
 

@@ -98,7 +98,7 @@ def test_tile_pass_inside_the_shading_launch_equals_the_separate_launch(name, B,
 
 @pytest.mark.parametrize("name,B", [("cfg2", 64), ("cfg4", 32), ("cfg3", 48), ("cfg50k64", 64)])
 def test_long_runs_on_two_streams_equal_the_single_chain(name, B):
-    """Round 4: a run of 48+ iterations goes out as two chains of half-batch launches, one on a stream the engine owns, forked
+    """Round 4: a run of 16+ iterations goes out as two chains of half-batch launches, one on a stream the engine owns, forked
     from and joined to the caller's stream by events (engine.hip engine_run_impl, ddx.h single_stream).  Every hypothesis runs
     the slots, slices and sums of the full launches: parameters, loss log, pose log and status equal the single chain bit for
     bit -- on the caller's stream WITHOUT a host synchronisation before the comparison (the join orders the copy after both

@@ -14,4 +14,4 @@ G='MISMATCH\|ERROR\|cases,\|soups,\|bad,\|Traceback'
   echo "== engine soups, tile pass inside the shading launch forced"; DDX_BIG_INLINE=1 FUZZ_ENGINE_SOUPS=1 timeout 600 python tools/fuzz_parity.py 5000 7550000 | grep "$G"
   echo "== state"; FUZZ_STATE=1 timeout 600 python tools/fuzz_parity.py 1500 7600000 | grep "$G"
   echo "== api"; FUZZ_API=1 timeout 600 python tools/fuzz_parity.py 1200 7700000 | grep "$G"
-  echo "== ops"; FUZZ_OPS=1 timeout 600 python tools/fuzz_parity.py 8000 7800000 | grep "$G" ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4b_fuzz_final.log
+  echo "== ops"; FUZZ_OPS=1 timeout 600 python tools/fuzz_parity.py 8000 7800000 | grep "$G" ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4c_fuzz_final.log

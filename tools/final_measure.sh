@@ -1,7 +1,7 @@
 #!/bin/bash
-# final measurement session of the round: everything profiles/r4b_* is made of
+# final measurement session of the round: everything profiles/r4c_* is made of (r4b: the same before the two-stream runs)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-T=r4b
+T=r4c
 O=gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/${T}_pytest_gpu.log 2>&1; tail -3 $O/${T}_pytest_gpu.log
@@ -19,7 +19,7 @@ python - <<'PY'
 import json
 for k in ("cfg2_d7.5", "cfg2_d3.75", "cfg3_d7.5", "cfg4_gb512"):
     try:
-        d = json.load(open(f"gpurun_out/r4b_pmc_sq_{k}.json"))
+        d = json.load(open(f"gpurun_out/r4c_pmc_sq_{k}.json"))
         for n, v in d["kernels"].items():
             print(k, n[:40], {x: (round(v[x], 3) if isinstance(v.get(x), float) else v.get(x)) for x in ("avg_ns_unprofiled", "valu_issue_frac", "hbm_bytes_per_launch", "hbm_frac_of_peak", "l2_hit_rate", "SQ_WAVES")},
                   "wait", round(v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1), 3), "ldsconf", round(v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3))
@@ -30,6 +30,8 @@ timeout 600 bash tools/mfma_pass.sh $T > $O/${T}_mfma_util.json 2>$O/${T}_mfma.e
 timeout 60 tools/ubench/_build/store_rate > $O/${T}_ubench_store_rate.jsonl
 timeout 120 python tools/launch_sync_cost.py 2>/dev/null | tail -6 > $O/${T}_launch_sync_cost.txt; cat $O/${T}_launch_sync_cost.txt
 timeout 120 python tools/fixed_cost.py 2>/dev/null | tail -9 > $O/${T}_fixed_cost.txt; cat $O/${T}_fixed_cost.txt
+timeout 200 python tools/ramp_probe.py cfg2 2>&1 | grep "^cfg" > $O/${T}_ramp_probe.log; timeout 200 python tools/ramp_probe.py cfg4 2>&1 | grep "^cfg" >> $O/${T}_ramp_probe.log; cat $O/${T}_ramp_probe.log
+for c in cfg2 cfg4 cfg5 cfg50k64; do timeout 200 python tools/two_stream_threshold.py $c 2>&1 | grep "^cfg"; done > $O/${T}_two_stream_threshold.log; cat $O/${T}_two_stream_threshold.log
 DDX_LIB=/root/repo/diffdope_amd/libddx_exp.so timeout 600 python tools/experiments/exp_stagger.py cfg2 > $O/${T}_exp_stagger_cfg2.log 2>&1; cat $O/${T}_exp_stagger_cfg2.log
 timeout 120 tools/experiments/_build/scratch_probe > $O/${T}_scratch_probe.log 2>&1; tail -3 $O/${T}_scratch_probe.log
 DDX_TRACE=1 timeout 120 python tools/trace_kernels.py > $O/${T}_trace_cfg2.log 2>&1; cat $O/${T}_trace_cfg2.log

@@ -4,6 +4,7 @@
 tag=$1; shift
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
+export DDX_TWO_STREAMS=0  # (counters per full-batch launch)
 out=gpurun_out/mfma_$tag
 rm -rf $out; mkdir -p $out
 for cfg in cfg2 cfg3; do

@@ -8,6 +8,7 @@ set -u
 tag=$1; key=$2; shift 2
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
+export DDX_TWO_STREAMS=0  # (counters are per full-batch launch; under --pmc the kernels run one at a time anyway)
 out=gpurun_out/pmc_${tag}_${key}
 mkdir -p "$out"
 BENCH="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras $*"
