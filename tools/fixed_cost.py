@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffdope_amd import dist as ddist, workloads as wl
 w = wl.build("cfg2", torch.device("cuda"))
 N = 400
-eng, params = wl.engine_for(w, wl.bench_lr_schedule(N, "adam"), optimizer="adam")
+eng, params = wl.engine_for(w, wl.bench_lr_schedule(N, "adam"), optimizer="adam", single_stream=not os.environ.get("TWO_CHAINS"))  # (one regime for the fit)
 eng.run(20); torch.cuda.synchronize()
 rows = []
 for n in (1, 2, 5, 10, 20, 40, 80):
