@@ -13,5 +13,6 @@ G='MISMATCH\|ERROR\|cases,\|soups,\|bad,\|Traceback'
   echo "== engine soups"; FUZZ_ENGINE_SOUPS=1 timeout 600 python tools/fuzz_parity.py 8000 7500000 | grep "$G"
   echo "== engine soups, tile pass inside the shading launch forced"; DDX_BIG_INLINE=1 FUZZ_ENGINE_SOUPS=1 timeout 600 python tools/fuzz_parity.py 5000 7550000 | grep "$G"
   echo "== state"; FUZZ_STATE=1 timeout 600 python tools/fuzz_parity.py 1500 7600000 | grep "$G"
+  echo "== state, 32-64 hypotheses, every run of 2+ iterations as two chains against the one-chain run"; DDX_TWO_MIN=2 DDX_BIG_INLINE=1 FUZZ_WIDE=1 FUZZ_STATE=1 timeout 900 python tools/fuzz_parity.py 600 7650000 | grep "$G"
   echo "== api"; FUZZ_API=1 timeout 600 python tools/fuzz_parity.py 1200 7700000 | grep "$G"
   echo "== ops"; FUZZ_OPS=1 timeout 600 python tools/fuzz_parity.py 8000 7800000 | grep "$G" ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4c_fuzz_final.log

@@ -484,6 +484,9 @@ def sweep_state(n_cases=100, seed0=0, verbose=True):
         rows, cols = int(rng.randint(5, 24)), int(rng.randint(6, 28))
         H, W = int(rng.randint(30, 110)), int(rng.randint(40, 140))
         B = int(rng.randint(2, 9))
+        wide = bool(os.environ.get("FUZZ_WIDE"))  # batches wide enough for the two-chain runs (run with DDX_TWO_MIN=2): the reference
+        if wide:                                  # run of a case is then ONE chain (single_stream), everything else may fork
+            B = int(rng.choice([32, 48, 64]))
         names = [k for k in KEYS if rng.rand() < 0.6] or ["rgb"]
         weights = {k: float(rng.uniform(0.3, 1.5)) for k in names}
         optimizer = "adam" if rng.rand() < 0.5 else "sgd"
@@ -497,7 +500,7 @@ def sweep_state(n_cases=100, seed0=0, verbose=True):
             def engine(params, lr_mult, lo=0, hi=B, **kw):
                 return dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], gt, params, T(lr_mult[lo:hi]), lrs, weights, optimizer=optimizer, **tex, **kw)
             p_ref = T(sc["params"])
-            ref = engine(p_ref, sc["lr_mult"])
+            ref = engine(p_ref, sc["lr_mult"], single_stream=wide)
             ref.run(); ref.finish()
             want = (p_ref.clone(), ref.losses().clone(), ref.mtx_log.clone())
             same = lambda p, e: torch.equal(p, want[0]) and torch.equal(e.losses(), want[1]) and torch.equal(e.mtx_log, want[2])
