@@ -294,14 +294,19 @@ def main():
                 el = float(tmax.item())
             return el, best
 
+        cold = None
         if args.settle_ms > 0:
+            # what the same W + K read BEFORE the device has settled (reported beside the contract's window, never as `value`)
+            if args.warmup > 0:
+                ddist.run_and_select(eng, args.warmup, lo=lo_w, use_graph=args.graph)
+            cold = window()[0]
             # steady state of the device before anything is timed (--settle-ms): the same engine, the same iterations; afterwards
             # the engine is put back exactly as the repeat windows below put it back
             t_s = time.perf_counter()
             while time.perf_counter() - t_s < args.settle_ms * 1e-3:
+                eng.rewind(0)
                 eng.run(n_it)
                 torch.cuda.synchronize()
-                eng.rewind(0)
             eng.new_observation(params=w["params0"])
         if args.warmup > 0:
             ddist.run_and_select(eng, args.warmup, lo=lo_w, use_graph=args.graph)  # (warms the selection path too: pinned row, RCCL channels)
@@ -319,7 +324,7 @@ def main():
                 eng.run(args.warmup, use_graph=args.graph)
             extra.append(window()[0])
         gc.enable()
-        return dict(elapsed=elapsed, best=best, status=st, params=final, per_hyp=per_hyp, lrs=lrs, repeats=extra, eng=eng)
+        return dict(elapsed=elapsed, best=best, status=st, params=final, per_hyp=per_hyp, lrs=lrs, repeats=extra, eng=eng, cold=cold)
 
     w = wl.build(args.config, dev, B=Bl, global_lo=lo, global_B=B_job, distance=args.distance)
     extras_on = not args.no_extras and world == 1
@@ -477,6 +482,10 @@ def main():
                                   "rot_err_rad_median": float(np.median(rot_c)), "trans_err_m_median": float(np.median(tr_c)),
                                   "within_north_star_tolerance": bool(rot_c[bcv] < 1e-3 and tr_c[bcv] < 1e-3),
                                   "what": "same workload and engine, full 200-iteration schedule, untimed; errors against the generating pose"}
+        if r["cold"] is not None:
+            out["cold_window"] = {"ms_per_step": r["cold"] / args.steps * 1e3, "iters_per_s": (job_iters if strong else world * job_iters) * elapsed / r["cold"],
+                                  "what": "the same W warm-up + K timed iterations + selection as the first thing the engine does in this process, "
+                                          "before the --settle-ms phase (the board's power management still ramping: DESIGN.md section 6)"}
         if r["repeats"]:
             allw = sorted([elapsed] + r["repeats"])
             med = allw[len(allw) // 2]
