@@ -2805,7 +2805,19 @@ __global__ void side_wake_kernel() {}
 static bool two_streams_possible(const ddx_engine* e)
 {
     const EngineDev& E = e->dev;
-    return e->two_streams > 0 && !E.d.single_stream && E.big_inline && E.d.B >= 32 && E.d.B % 16 == 0;
+    if (!(e->two_streams > 0 && !E.d.single_stream && E.big_inline && E.d.B >= 32 && E.d.B % 16 == 0)) return false;
+    // Two half launches side by side win while a launch is short enough for its fixed parts (prologue, boundary, tail) to matter:
+    // by (meshlets x hypotheses) of the step launch, tools/two_stream_threshold.py at 100 iterations -- 2 560 (cfg2) -6 %, 3 200
+    // -13 %, 3 776 (cfg4) -4.6 %, 5 120 (cfg2 / cfg5 with 128 hypotheses) -6 %, 6 400 (cfg50k64) -2 %, 7 552 (cfg4 with 128) +4.4 %,
+    // 12 800 (cfg3 / cfg3ref / cfg50k64 with 128) +1.5 % / -1 % / 0.
+    return e->two_min_env || (long long)E.n_meshlets * E.d.B < 7000;
+}
+
+static int two_streams_min_iters(const ddx_engine* e)
+{
+    // (fork + join cost 25-30 us per run: even at 14-16 iterations for the short launches; cfg50k64 +10 us at 20, -31 at 48)
+    if (e->two_min_env) return e->two_min_iters;
+    return (long long)e->dev.n_meshlets * e->dev.d.B < 6000 ? e->two_min_iters : std::max(e->two_min_iters, 48);
 }
 
 static int ensure_side_stream(ddx_engine* e)
@@ -2861,10 +2873,7 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         capturing = hipStreamIsCapturing(s, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
     }
-    // (with the slot table -- the 51 200-triangle meshes -- the half launches only pay from ~40 iterations on: cfg50k64 +10 us at 20,
-    // -31 us at 48, -57 us at 64)
-    const int two_min = e->dev.slot_table ? std::max(e->two_min_iters, e->two_min_env ? 0 : 48) : e->two_min_iters;
-    const bool two = two_streams_possible(e) && !use_graph && !capturing && n >= two_min && !e->dev.trace;
+    const bool two = two_streams_possible(e) && !use_graph && !capturing && n >= two_streams_min_iters(e) && !e->dev.trace;
     if (int err = launch_step(e, STEP_FIRST, it0, s)) return err;
     if (int err = launch_rest(e, it0, s, nullptr)) return err;
     if (use_graph && !e->exec && n > 1) {

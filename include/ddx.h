@@ -230,13 +230,13 @@ typedef struct ddx_engine_desc {
      * DESIGN.md section 4).  1: always the separate launch.  Environment DDX_BIG_INLINE=0 / 1 overrides the estimate.  Same
      * results either way, bit for bit. */
     int32_t separate_big_pass;
-    /* 0 (default): ddx_engine_run / ddx_engine_run_select may issue a run of 16 or more iterations (48 or more where the step
-     * kernel runs with balanced meshlet shares; no graph replay, no capture in progress, tile pass inside the shading launch, B a
-     * multiple of 16) as two chains of half-batch launches: one on the
+    /* 0 (default): ddx_engine_run / ddx_engine_run_select may issue a run of 16 or more iterations (48 or more for larger step
+     * launches; never above 7 000 meshlet-hypothesis pairs, where one launch fills the chip; no graph replay, no capture in
+     * progress, tile pass inside the shading launch, B a multiple of 16) as two chains of half-batch launches: one on the
      * caller's stream, one on a stream the engine owns, forked from the caller's stream after the first iteration and joined to
      * it before the run's last kernel -- so everything the call enqueues is still ordered on `stream` as far as the caller can
      * see, and the results are the same bit for bit.  1: one chain on the caller's stream only.  Environment DDX_TWO_STREAMS=0
-     * has the same effect for every engine of the process; DDX_TWO_MIN sets the length. */
+     * has the same effect for every engine of the process; DDX_TWO_MIN=n forks every eligible run of n or more iterations. */
     int32_t single_stream;
 } ddx_engine_desc;
 

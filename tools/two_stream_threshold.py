@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffdope_amd import dist as ddist, workloads as wl
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-w = wl.build(cfg, torch.device("cuda"))
+B = int(sys.argv[2]) if len(sys.argv) > 2 else None  # (hypotheses; default: the config's)
+w = wl.build(cfg, torch.device("cuda"), **({"B": B} if B else {}))
+cfg = f"{cfg}/B{B}" if B else cfg
 N = 400
 engs = {}
 for single in (True, False):
