@@ -29,7 +29,7 @@ def owner_of(obj_index, world):
     return obj_index % world
 
 
-def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, optimizer="sgd", scale=0.01, mode="group"):
+def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, optimizer="sgd", scale=0.01, mode="streams"):
     """Refine every object of one frame.
 
     cfg: config mapping (losses / hyperparameters as configs/diffdope.yaml); camera: Camera; scene: Scene with the
@@ -38,11 +38,12 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
     masks: list of Image (mask_visib of object i).  Returns (table [n_obj,18] float64 tensor identical on every
     rank: loss, arg-min hypothesis, 4x4 pose row-major, and per-object DiffDope handles for the local objects).
 
-    mode: how the local objects (4 per GPU in config 5) share the GPU.  "group" (default): ONE engine group -- one launch of each
-    kernel per iteration for all of them (RefineEngineGroup; a 64-hypothesis launch is latency-bound and fills a fraction of
-    the chip); "streams": one HIP stream per object (every engine a chain of latency-bound launches, the other objects' kernels
-    fill its gaps); "sequential": one after the other.  End of round 4, config 5's share: 16.3 / 16.4 / 17.7 ms per 58 iterations;
-    four cfg2-sized objects: 7.2 / 7.8 / 9.4 ms.  Whatever the mode, an object's result is the same bits."""
+    mode: how the local objects (4 per GPU in config 5) share the GPU.  "streams" (default): one HIP stream per object (every
+    engine a chain of latency-bound launches -- two chains of half-batch launches each since the end of round 4 --, the other
+    objects' kernels fill its gaps); "group": ONE engine group -- one launch of each kernel per iteration for all of them
+    (RefineEngineGroup; a 64-hypothesis launch is latency-bound and fills a fraction of the chip); "sequential": one after the
+    other.  End of round 4, config 5's share, streams / group / sequential: 15.7 / 16.4 / 17.1 ms per 58 iterations; four
+    cfg2-sized objects: 7.3 / 7.2 / 9.1 ms (tools/multi_object_streams.py).  Whatever the mode, an object's result is the same bits."""
     n = len(objects)
     B = cfg["hyperparameters"]["batchsize"]
     dev = torch.device("cuda", torch.cuda.current_device())

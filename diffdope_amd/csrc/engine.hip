@@ -2864,9 +2864,9 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
     // stream of the engine's own, forked from and joined to the caller's by events -- one chain's kernel boundaries and launch
     // prologues are covered by the other chain's work (cfg2: 40.0 -> 37.8 us per iteration; fork + join cost 25-30 us per run: even
     // at 14-16 iterations, 1.5 % ahead at 20, 4.7 % at 48, 6 % at 100 -- tools/two_stream_threshold.py --: hence two_min_iters).
-    // Every hypothesis runs the slots, slices and sums it runs in the full launches --
-    // the same bits --; the words the halves share are the status counters (rewritten by finish_kernel after the join) and the
-    // tile pass's global "a large triangle exists" word, which only the separate big_pass_kernel reads: hence big_inline only.
+    // Every hypothesis runs the slots, slices and sums it runs in the full launches -- the same bits --; the words the halves share
+    // are the status counters (rewritten by finish_kernel after the join) and the tile pass's global "a large triangle exists"
+    // word, which only the separate big_pass_kernel reads: hence big_inline only.
     // (Forking before the first iteration as well measured 7 us worse per run.)
     bool capturing = false;
     {
@@ -2896,14 +2896,17 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         if (int err = ensure_side_stream(e)) return err;
         DDX_HIP(hipEventRecord(e->ev_fork, s));
         DDX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-        for (int i = 1; i < n; ++i) {
-            if (int err = launch_step(e, STEP_NORMAL, it0 + i, s, 0)) return err;
-            if (int err = launch_step(e, STEP_NORMAL, it0 + i, e->side, 1)) return err;
-            if (int err = launch_rest(e, it0 + i, s, nullptr, 0)) return err;
-            if (int err = launch_rest(e, it0 + i, e->side, nullptr, 1)) return err;
+        int err = 0;
+        for (int i = 1; i < n && !err; ++i) {
+            err = launch_step(e, STEP_NORMAL, it0 + i, s, 0);
+            if (!err) err = launch_step(e, STEP_NORMAL, it0 + i, e->side, 1);
+            if (!err) err = launch_rest(e, it0 + i, s, nullptr, 0);
+            if (!err) err = launch_rest(e, it0 + i, e->side, nullptr, 1);
         }
+        // (joined on the error path too: whatever did go out on the engine's stream stays ordered before the caller's next work)
         DDX_HIP(hipEventRecord(e->ev_join, e->side));
         DDX_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
+        if (err) return err;
     }
     for (int i = two ? n : 1; i < n;) {
         if (use_graph && e->exec && i + e->graph_chunk <= n) {
