@@ -109,15 +109,45 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                 gm = np.stack([p_.grad.cpu().numpy() for p_ in pl])
                 # (ids: the matrices of this path come from the device's pose op and torch's matmul, the oracle's from numpy: a last-bit
                 # difference in a clip coordinate can hand an exact-edge pixel to the neighbouring triangle -- seed 5001213, one pixel)
-                mat_ok = int((out["rast_out"][..., 3].detach().cpu().numpy() != r2["rast"][..., 3]).sum()) <= 2
+                id_diff = out["rast_out"][..., 3].detach().cpu().numpy() != r2["rast"][..., 3]
+                n_id = int(id_diff.sum())
+                mat_ok = n_id <= 2
+                # (round 4, seeds 7057321 / 8015421 / 8022537, FUZZ_MAT_DIAG: 10-11 of the 16 entries of proj @ pose differ in the last
+                # bit between the two sides, ONE pixel goes to the other triangle or to the background, and the oracle's rasteriser fed
+                # the device path's own clip coordinates reproduces the device's ids exactly.  Such a pixel -- and its neighbours, which
+                # the antialias blends with it -- is a different INPUT, not a different result: left out of the image comparison, and
+                # the loss may differ by what that many pixels can contribute)
+                excl = np.zeros_like(id_diff)
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        excl |= np.roll(np.roll(id_diff, dy, 1), dx, 2)
                 for k in ("rgb", "depth", "mask"):
                     # (the clip-space vertices come from torch's proj @ mtx here, the oracle's from numpy's: last-bit differences that
                     # a sliver pixel's barycentrics amplify -- seed 702717: one pixel off by 1.6e-4; hence the median-tight, max-loose pair)
                     dk = np.abs(out[k].detach().cpu().numpy() - r2[k])
+                    dk[excl] = 0.0
                     mat_ok &= bool(dk.max() < 2e-3 * max(1.0, float(np.abs(r2[k]).max())) and np.percentile(dk, 99.9) < 2e-4 * max(1.0, float(np.abs(r2[k]).max())))
-                mat_ok &= abs(float(loss.detach()) - tot2) < 2e-5 * max(1, abs(tot2))
+                loss_slack = 9 * n_id * 8.0 * max(1.0, float(np.abs(r2["depth"]).max())) / (H * W)
+                mat_ok &= abs(float(loss.detach()) - tot2) < 2e-5 * max(1, abs(tot2)) + loss_slack
                 mat_ok &= np.abs(gm - g2).max() < 1e-2 * max(np.abs(g2).max(), 1e-7)
                 stats["materialising"] = stats.get("materialising", 0) + 1
+                if not mat_ok and os.environ.get("FUZZ_MAT_DIAG"):
+                    # which criterion failed, and are the two sides even rasterising the same clip coordinates?
+                    ids_d, ids_o = out["rast_out"][..., 3].detach().cpu().numpy(), r2["rast"][..., 3]
+                    print("  diag", tag)
+                    print("  diag ids differ at", int((ids_d != ids_o).sum()), "pixels of", ids_o.size)
+                    for k in ("rgb", "depth", "mask"):
+                        dk = np.abs(out[k].detach().cpu().numpy() - r2[k]); sk = max(1.0, float(np.abs(r2[k]).max()))
+                        print(f"  diag {k}: max {dk.max():.3e} (limit {2e-3 * sk:.1e}), 99.9 % {np.percentile(dk, 99.9):.3e} (limit {2e-4 * sk:.1e}), pixels over the max limit {int((dk.reshape(dk.shape[0], H, W, -1).max(-1) >= 2e-3 * sk).sum())}")
+                    print(f"  diag loss {float(loss.detach()):.8f} vs {tot2:.8f}; gradient rel {np.abs(gm - g2).max() / max(np.abs(g2).max(), 1e-7):.3e}")
+                    m_o = np.matmul(sc["proj"][None], orc.pose_fwd(sc["params"])).astype(np.float32)
+                    m_d = torch.matmul(T(sc["proj"])[None], mtx.detach()).cpu().numpy()
+                    c_o = orc.xfm_fwd(sc["pos"][None].repeat(B, 0), m_o, True)
+                    c_d = orc.xfm_fwd(sc["pos"][None].repeat(B, 0), m_d, True)
+                    print(f"  diag proj @ pose: {int((m_o != m_d).sum())} of {m_o.size} entries differ (max {np.abs(m_o - m_d).max():.2e}); clip coordinates: "
+                          f"{int((c_o != c_d).sum())} of {c_o.size} differ (max {np.abs(c_o - c_d).max():.2e})")
+                    ref_d = orc.rasterize_fwd(c_d, sc["tri"], H, W)
+                    print("  diag oracle rasteriser on the DEVICE path's clip coordinates: ids differ from the device's at", int((ref_d[..., 3] != ids_d).sum()), "pixels")
             # every 4th case: three fused SGD iterations, the oracle teacher-forced on the engine's own parameters before each (a free-
             # running comparison measures the chaos of L1 sign flips under large steps, not the kernels: seed 203758 differs by 3e-3
             # after three steps although every single gradient agrees to 3e-7).  State carried between iterations -- zbuf / tile-flag
