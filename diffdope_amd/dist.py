@@ -99,10 +99,18 @@ def run_and_select(eng, n, lo=0, group=None, use_graph=False):
             t = table.numpy()
             return int(t[0, 1]), float(t[0, 0]), table[0, 2:].clone().reshape(4, 4)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    table = torch.zeros((world, 18), dtype=torch.float32, device=eng.params.device)
-    eng.run_select(table[rank], n, lo=lo, use_graph=use_graph)
-    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
-    t = table.cpu().numpy()
+    # (the exchange table is kept per (device, world) and zeroed again right AFTER it has been read -- off the path of the next call,
+    # which would otherwise begin with a fill launch in front of its first kernel)
+    key = (eng.params.device, world)
+    table = _TABLES.get(key)
+    if table is None:
+        table = _TABLES[key] = torch.zeros((world, 18), dtype=torch.float32, device=eng.params.device)
+    try:
+        eng.run_select(table[rank], n, lo=lo, use_graph=use_graph)
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+        t = table.cpu().numpy()
+    finally:
+        table.zero_()
     losses, gidx = t[:, 0], t[:, 1]
     cand = [(gidx[r], r) for r in range(world) if losses[r] == losses.min()]
     row = min(cand)[1]
@@ -112,6 +120,7 @@ def run_and_select(eng, n, lo=0, group=None, use_graph=False):
 import threading
 
 _PINNED = None
+_TABLES = {}
 _PINNED_LOCK = threading.Lock()
 
 
