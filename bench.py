@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--no-convergence", action="store_true", help="skip the untimed 200-iteration convergence leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (reference SGD, close-up at distance 3.75, repeats)")
     ap.add_argument("--repeats", type=int, default=5, help="extra timed windows of --steps iterations after the contract's one (median reported beside it)")
+    ap.add_argument("--closing-barrier", action="store_true",
+                    help="N > 1: a torch.distributed.barrier() behind the job's all_reduce inside the timed window (default: the all_reduce "
+                         "itself is the closing barrier, followed by torch.cuda.synchronize())")
     ap.add_argument("--settle-ms", type=float, default=15.0,
                     help="before the W warm-up iterations: run the engine for this long, untimed, then restore the initial poses and a fresh optimiser "
                          "state (0 = off).  The board's power management needs ~7 ms of the engine's own load to settle: an identical 20-iteration "
@@ -286,7 +289,14 @@ def main():
             barrier()
             t0 = time.perf_counter()
             best = ddist.run_and_select(eng, args.steps, lo=lo_w, use_graph=args.graph)
-            barrier()
+            # the closing barrier: with more than one rank the job's own all_reduce IS one -- no rank holds the global result
+            # before every rank has finished its K iterations and contributed its row -- and run_and_select has already copied
+            # that result to the host; a second collective behind it (torch.distributed.barrier() = another all_reduce, 24-27 us
+            # with one RCCL rank) would only time itself.  --closing-barrier adds it back.
+            if use_dist and not args.closing_barrier:
+                torch.cuda.synchronize()
+            else:
+                barrier()
             el = time.perf_counter() - t0
             if use_dist:
                 tmax = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -453,7 +463,8 @@ def main():
             "config": {"workload": f"{args.config}: blob mesh T={T} V={V}, tex {tex_hw[0]}^2, {w['W']}x{w['H']}, {Bl} hyps/GPU, "
                                    f"losses {'+'.join(sorted(w['weights']))}, {args.optimizer}, coverage {100 * w['coverage']:.2f}%",
                        "hypotheses_per_gpu": Bl, "global_hypotheses": B_job, "parallelism": f"hyp-shard x{world}",
-                       "hipgraph": bool(args.graph), "settle_ms": args.settle_ms},
+                       "hipgraph": bool(args.graph), "settle_ms": args.settle_ms,
+                       "closing_barrier": ("torch.distributed.barrier()" if args.closing_barrier else "the job's all_reduce") if use_dist else "synchronize (one rank)"},
             "dist": dist_info,
             "hypothesis_iters_per_s": B_job * job_iters,
             "roofline": roof,

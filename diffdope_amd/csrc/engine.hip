@@ -231,6 +231,8 @@ struct ddx_engine {
     int two_min_iters = 16;  // ... for runs of at least this many iterations (DDX_TWO_MIN)
     hipStream_t side = nullptr;  // ... the second stream, and the events that fork it from / join it to the caller's
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_p[3] = {nullptr, nullptr, nullptr};       // (timing events of the probe below)
+    std::vector<std::pair<hipStream_t, bool>> side_checked;  // caller streams met so far: do kernels of `side` run beside theirs?
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
@@ -2798,9 +2800,13 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
 
 static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* stream, float* sel_out, int sel_lo);
 
-// the engine's own stream for the second chain of a two-stream run (engine_run_impl), created -- and its queue woken with an
-// empty launch -- by the set-up of an engine that may use it: a stream's first submission costs milliseconds
-__global__ void side_wake_kernel() {}
+// the engine's own stream for the second chain of a two-stream run (engine_run_impl), created -- and its queue woken -- by the
+// set-up of an engine that may use it: a stream's first submission costs milliseconds
+__global__ void side_spin_kernel(unsigned ticks)  // one wave busy for `ticks` of the 100 MHz clock
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
 
 static bool two_streams_possible(const ddx_engine* e)
 {
@@ -2820,14 +2826,73 @@ static int two_streams_min_iters(const ddx_engine* e)
     return (long long)e->dev.n_meshlets * e->dev.d.B < 6000 ? e->two_min_iters : std::max(e->two_min_iters, 48);
 }
 
-static int ensure_side_stream(ddx_engine* e)
+// Do kernels of `cand` run BESIDE kernels of `s`?  HIP multiplexes its streams onto a few hardware queues, and two streams that
+// share one take turns: a two-chain run is then not 5 % faster but 1.7x SLOWER than one chain (measured: a bench process with an
+// RCCL process group, whose streams had shifted the assignment -- 73 instead of 43 us per iteration; GPU_MAX_HW_QUEUES=8 likewise).
+// Nothing in the API tells; so: one 30-us single-wave kernel on each, started together, timed with events -- side by side they
+// end 38-41 us after the fork (the second stream starts 8-10 us late: its event wait), in turn after 70-85.  Synchronises both
+// streams (set-up time).
+static int side_runs_beside(ddx_engine* e, hipStream_t s, hipStream_t cand, bool* ok)
 {
-    if (e->side) return 0;
-    DDX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    DDX_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    DDX_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    side_wake_kernel<<<1, 64, 0, e->side>>>();
-    DDX_LAUNCH_CHECK();
+    if (!e->ev_p[0])
+        for (int i = 0; i < 3; ++i) DDX_HIP(hipEventCreate(&e->ev_p[i]));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        DDX_HIP(hipEventRecord(e->ev_p[0], s));
+        DDX_HIP(hipStreamWaitEvent(cand, e->ev_p[0], 0));
+        side_spin_kernel<<<1, 64, 0, s>>>(3000u);
+        side_spin_kernel<<<1, 64, 0, cand>>>(3000u);
+        DDX_HIP(hipEventRecord(e->ev_p[1], s));
+        DDX_HIP(hipEventRecord(e->ev_p[2], cand));
+        DDX_HIP(hipEventSynchronize(e->ev_p[1]));
+        DDX_HIP(hipEventSynchronize(e->ev_p[2]));
+        float t1 = 0.f, t2 = 0.f;
+        DDX_HIP(hipEventElapsedTime(&t1, e->ev_p[0], e->ev_p[1]));
+        DDX_HIP(hipEventElapsedTime(&t2, e->ev_p[0], e->ev_p[2]));
+        best = std::min(best, std::max(t1, t2));  // (the best of three: an unrelated launch in between must not fail a good pair)
+    }
+    *ok = best < 0.050f;  // ms
+    if (getenv("DDX_DEBUG_INLINE")) fprintf(stderr, "ddx: second stream %p beside %p: %.1f us for two 30-us kernels -> %s\n", (void*)cand, (void*)s, best * 1e3f, *ok ? "beside" : "in turn");
+    return 0;
+}
+
+// the engine's stream for caller stream `s`: created at the first call (up to 6 candidates until one runs beside `s`; none: this
+// engine keeps one chain), checked once against every other caller stream it meets
+static int ensure_side_stream(ddx_engine* e, hipStream_t s, bool* usable)
+{
+    *usable = false;
+    for (const auto& pr : e->side_checked)
+        if (pr.first == s) { *usable = pr.second; return 0; }
+    bool ok = false;
+    if (!e->side) {
+        if (e->two_streams <= 0) return 0;
+        std::vector<hipStream_t> rejected;
+        int err = 0;
+        for (int attempt = 0; attempt < 6 && !ok && !err; ++attempt) {
+            hipStream_t cand = nullptr;
+            const hipError_t ce = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+            if (ce != hipSuccess) {
+                ddx_set_error("hipStreamCreateWithFlags failed: %s (%s:%d)", hipGetErrorString(ce), __FILE__, __LINE__);
+                err = (int)ce;
+                break;
+            }
+            err = side_runs_beside(e, s, cand, &ok);
+            if (!err && ok) e->side = cand;
+            else rejected.push_back(cand);  // (kept until the search is over: a destroyed stream's queue slot would be handed out again)
+        }
+        for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+        if (err) return err;
+        if (!e->side) {
+            e->two_streams = 0;  // (no stream of this process runs beside the caller's: one chain)
+            return 0;
+        }
+        DDX_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        DDX_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    } else {
+        if (int err = side_runs_beside(e, s, e->side, &ok)) return err;
+    }
+    e->side_checked.push_back(std::make_pair(s, ok));
+    *usable = ok;
     return 0;
 }
 
@@ -2852,8 +2917,10 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
     hipStream_t s = (hipStream_t)stream;
     if (!e->setup_done) {
         if (int err = engine_setup(e, s)) return err;
-        if (two_streams_possible(e))
-            if (int err = ensure_side_stream(e)) return err;
+        if (two_streams_possible(e)) {
+            bool usable = false;  // (the set-up has just synchronised: the place for the probe)
+            if (int err = ensure_side_stream(e, s, &usable)) return err;
+        }
     }
     if (n == 0) return 0;
     RoctxRange rr("ddx_engine_run");
@@ -2873,7 +2940,9 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         capturing = hipStreamIsCapturing(s, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
     }
-    const bool two = two_streams_possible(e) && !use_graph && !capturing && n >= two_streams_min_iters(e) && !e->dev.trace;
+    bool two = two_streams_possible(e) && !use_graph && !capturing && n >= two_streams_min_iters(e) && !e->dev.trace;
+    if (two)  // (a caller stream this engine has not met yet is probed here, once: synchronises it)
+        if (int err = ensure_side_stream(e, s, &two)) return err;
     if (int err = launch_step(e, STEP_FIRST, it0, s)) return err;
     if (int err = launch_rest(e, it0, s, nullptr)) return err;
     if (use_graph && !e->exec && n > 1) {
@@ -2893,7 +2962,6 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         DDX_HIP(hipStreamDestroy(cs));
     }
     if (two) {
-        if (int err = ensure_side_stream(e)) return err;
         DDX_HIP(hipEventRecord(e->ev_fork, s));
         DDX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         int err = 0;
@@ -3321,6 +3389,8 @@ extern "C" void ddx_engine_destroy(ddx_engine* e)
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    for (int i = 0; i < 3; ++i)
+        if (e->ev_p[i]) (void)hipEventDestroy(e->ev_p[i]);
     delete e;
 }
 

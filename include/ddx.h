@@ -235,7 +235,10 @@ typedef struct ddx_engine_desc {
      * progress, tile pass inside the shading launch, B a multiple of 16) as two chains of half-batch launches: one on the
      * caller's stream, one on a stream the engine owns, forked from the caller's stream after the first iteration and joined to
      * it before the run's last kernel -- so everything the call enqueues is still ordered on `stream` as far as the caller can
-     * see, and the results are the same bit for bit.  1: one chain on the caller's stream only.  Environment DDX_TWO_STREAMS=0
+     * see, and the results are the same bit for bit.  The set-up checks with two 30-us kernels that the engine's stream really
+     * runs beside the caller's (streams that share a hardware queue take turns) and keeps one chain if no such stream can be
+     * had; a caller stream the engine meets later is checked at its first long run (synchronises it once).  1: one chain on the
+     * caller's stream only.  Environment DDX_TWO_STREAMS=0
      * has the same effect for every engine of the process; DDX_TWO_MIN=n forks every eligible run of n or more iterations. */
     int32_t single_stream;
 } ddx_engine_desc;
