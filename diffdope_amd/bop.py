@@ -42,7 +42,7 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
     engine a chain of latency-bound launches -- two chains of half-batch launches each since the end of round 4 --, the other
     objects' kernels fill its gaps); "group": ONE engine group -- one launch of each kernel per iteration for all of them
     (RefineEngineGroup; a 64-hypothesis launch is latency-bound and fills a fraction of the chip); "sequential": one after the
-    other.  End of round 4, config 5's share, streams / group / sequential: 15.7 / 16.4 / 17.1 ms per 58 iterations; four
+    other.  End of round 4, config 5's share, streams / group / sequential: 15.7-15.8 / 15.9-16.4 / 17.1 ms per 58 iterations; four
     cfg2-sized objects: 7.3 / 7.2 / 9.1 ms (tools/multi_object_streams.py).  Whatever the mode, an object's result is the same bits."""
     n = len(objects)
     B = cfg["hyperparameters"]["batchsize"]
