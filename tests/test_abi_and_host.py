@@ -35,6 +35,38 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.EngineDesc) == 27 * 4 and ctypes.sizeof(_lib.EngineBuffers) == 17 * 8
 
 
+def test_ctypes_structs_follow_the_header_member_for_member():
+    """ddx_engine_desc / ddx_engine_buffers in include/ddx.h against their ctypes mirrors: same members, same order, same scalar
+    types (the size check above would not notice two swapped int32 fields)."""
+    import re
+
+    from diffdope_amd import _lib
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ddx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+    def members(name):
+        body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", text, flags=re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(const )?(\w+)\s*(\*?)\s*(.*)$", decl)
+            ctype, ptr = m.group(2), bool(m.group(3))
+            for nm in m.group(4).split(","):
+                nm = nm.strip()
+                p = ptr or nm.startswith("*")
+                out.append((nm.lstrip("* ").strip(), "ptr" if p else ctype))
+        return out
+
+    kinds = {ctypes.c_int32: "int32_t", ctypes.c_float: "float", ctypes.c_void_p: "ptr", ctypes.c_size_t: "size_t"}
+    for cname, struct in (("ddx_engine_desc", _lib.EngineDesc), ("ddx_engine_buffers", _lib.EngineBuffers)):
+        want = members(cname)
+        got = [(n, kinds[t]) for n, t in struct._fields_]
+        assert got == want, (cname, [x for x in zip(got, want) if x[0] != x[1]][:3], len(got), len(want))
+
+
 def test_no_cpu_fallback_in_the_product_path():
     import diffdope_amd as dd
 
