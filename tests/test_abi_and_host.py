@@ -67,6 +67,37 @@ def test_ctypes_structs_follow_the_header_member_for_member():
         assert got == want, (cname, [x for x in zip(got, want) if x[0] != x[1]][:3], len(got), len(want))
 
 
+def test_ctypes_signatures_follow_the_header_prototypes():
+    """Every prototype of include/ddx.h against the ctypes signature it is bound with: return type, number of arguments, and the
+    kind of each (pointer / int / long long / size_t / float) -- a float handed over where the C side expects an int would be
+    passed in the wrong register without any error."""
+    import re
+
+    from diffdope_amd import _lib
+
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER).read(), flags=re.S)
+    protos = re.findall(r"^\s*([\w][\w\s\*]*?)\s*\b(ddx_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.M)
+    assert len(protos) >= 45
+
+    def kind(decl, ret=False):
+        decl = " ".join(decl.split())
+        if "*" in decl:
+            return ctypes.c_char_p if (ret and "char" in decl) else ctypes.c_void_p
+        base = decl if ret else " ".join(decl.split()[:-1])  # (an argument carries its name)
+        return {"int": ctypes.c_int, "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t, "float": ctypes.c_float, "void": None}[base]
+
+    seen = set()
+    for ret, name, args in protos:
+        res, argt = _lib._SIGNATURES[name]
+        want_args = [kind(a) for a in args.split(",") if " ".join(a.split()) not in ("", "void")]
+        assert kind(ret, ret=True) == res, (name, "return type", ret, res)
+        norm = lambda t: ctypes.c_void_p if (isinstance(t, type) and issubclass(t, ctypes._Pointer)) else t  # (typed pointers count as pointers)
+        got_args = [norm(t) for t in argt]
+        assert got_args == want_args, (name, [i for i, (g, w) in enumerate(zip(got_args, want_args)) if g != w], len(got_args), len(want_args))
+        seen.add(name)
+    assert seen == set(_lib._SIGNATURES), set(_lib._SIGNATURES) ^ seen
+
+
 def test_no_cpu_fallback_in_the_product_path():
     import diffdope_amd as dd
 
