@@ -171,6 +171,16 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def _flush_c_stdio():
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def _latest_profile(suffix):
     d = os.path.join(ROOT, "profiles")
     try:
@@ -260,6 +270,7 @@ def main():
         ids[rank] = dev_index + 1
         torch.distributed.all_reduce(ids)  # (also the first collective: RCCL channel set-up happens here, outside every timed window)
         dist_info["device_ids"] = [int(x) - 1 for x in ids.cpu().tolist()]
+        _flush_c_stdio()  # (RCCL's banner, if any, now and not at exit)
         dist_info["hsa_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
 
     def barrier():
@@ -523,10 +534,16 @@ def main():
                     del wx, rx
         if not args.no_cpu_baseline and world == 1:  # (the CPU leg is timed on rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out))
+    # rank 0's JSON line is the LAST thing on the job's stdout: whatever the native libraries still hold in C stdio buffers (with
+    # NCCL_DEBUG=VERSION, as on the GPU boxes, RCCL's version banner would otherwise be flushed at process exit, behind the line)
+    # goes out first on every rank, and the line is printed behind the last collective
+    _flush_c_stdio()
     if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+        _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
