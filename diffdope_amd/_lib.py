@@ -77,6 +77,8 @@ _SIGNATURES = {
     "ddx_engine_create": (_I, [ctypes.POINTER(EngineDesc), ctypes.POINTER(EngineBuffers), ctypes.POINTER(_P)]),
     "ddx_engine_run": (_I, [_P, _I, _I, _I, _P]),
     "ddx_engine_run_select": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "ddx_engine_run_check": (_I, [_P, _P]),
+    "ddx_engine_group_run_check": (_I, [_P, _P]),
     "ddx_engine_eval": (_I, [_P, _I, _P, _P, _P]),
     "ddx_select_best": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "ddx_render_loss_fwd": (_I, [_P, _I, _P, _P]),
@@ -85,6 +87,7 @@ _SIGNATURES = {
     "ddx_adam_step": (_I, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "ddx_engine_status_ptr": (_P, [_P]),
     "ddx_engine_cull_sign": (_I, [_P]),
+    "ddx_engine_two_chains": (_I, [_P]),
     "ddx_engine_new_observation": (_I, [_P]),
     "ddx_engine_profile": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I, _P]),
     "ddx_engine_destroy": (None, [_P]),

@@ -100,7 +100,7 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
                      // reads a word that the same launch writes
     int outside;     // hypotheses of the last iteration whose bounding box left the view volume (w <= 0 or |z| > w at a corner):
                      // their triangles at w <= 0 were clipped at the near plane by the tile pass and their back faces drawn (D5 off)
-    int pad[1];
+    int flags;       // ENGINE_FLAG_* bits (ddx.h, status word 7): sticky until ddx_engine_run_check has acted on them
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
     double c_edge;   // sum over the frame of |Gx| + |Gy| of the observed, masked image (edge extension)
@@ -112,9 +112,12 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int sel_pad;
 };
 
+// EngineState::flags
+#define ENGINE_FLAG_INLINE_TIMEOUT 1  // a shading workgroup gave up waiting for the workers of the in-launch tile pass (big_wait)
+
 // step_kernel(mode): STEP_FIRST draws the first iteration of a run from the caller's parameters (no optimiser step);
 // STEP_NORMAL steps the optimiser for iteration it - 1 and draws iteration it
-enum { STEP_FIRST = 0, STEP_NORMAL = 1 };
+enum { STEP_FIRST = 0, STEP_NORMAL = 1, STEP_EVAL = 2 };  // STEP_EVAL: STEP_FIRST of an evaluation / profile pass (leaves run_snap alone)
 
 struct EngineDev {
     ddx_engine_desc d;
@@ -199,6 +202,11 @@ struct EngineDev {
     float* sel_out;          // [18] or null.  Non-null (finish_kernel of ddx_engine_run_select): (mean loss of the best hypothesis, its
     int sel_lo;              // global index = sel_lo + local index, its 4x4 pose) is written here by the last writer workgroup
     int b_off;               // first hypothesis of this launch (0 except in the half-batch launches of a two-stream run, engine_run_impl)
+    float* run_snap;         // [21,B] parameters (7) and optimiser moments (14) as the LAST run / evaluation found them, written by its first
+                             // step launch: what ddx_engine_run_check restores before it repeats a run whose in-launch tile pass timed out
+    unsigned wait_ticks;     // big_wait's budget in ticks of the 100 MHz clock (DDX_BIG_WAIT_US; default 20 ms)
+    int dbg_reverse;         // DDX_DEBUG_REVERSE_SLABS=1 (tests): the worker slab of the in-launch tile pass BEHIND the shading slabs --
+                             // the dispatch order in which the wait cannot be satisfied while the shading workgroups fill the chip
 };
 
 #define TRACE_WG 4096
@@ -233,6 +241,9 @@ struct ddx_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_p[3] = {nullptr, nullptr, nullptr};       // (timing events of the probe below)
     std::vector<std::pair<hipStream_t, bool>> side_checked;  // caller streams met so far: do kernels of `side` run beside theirs?
+    int probe_outcome = -1;  // ddx_engine_two_chains: the last answer of ensure_side_stream (-1: never asked)
+    // the last run that ddx_engine_run_check has not yet seen clean, as it would have to be repeated (kind 0: none)
+    struct { int kind = 0, it0 = 0, n = 0, use_graph = 0, sel_lo = 0; float* sel_out = nullptr; } last;
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
@@ -286,6 +297,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_adam = carve((size_t)2 * 14 * d.B * sizeof(float));
     const size_t o_par = carve((size_t)2 * 7 * d.B * sizeof(float));
     const size_t o_etmp = carve((size_t)7 * d.B * sizeof(float));
+    const size_t o_rsnap = carve((size_t)21 * d.B * sizeof(float));
     const size_t o_inside = carve((size_t)d.B * sizeof(int));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
@@ -322,6 +334,7 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.adam = (float*)(p + o_adam);
     E.params2 = (float*)(p + o_par);
     E.eval_tmp = (float*)(p + o_etmp);
+    E.run_snap = (float*)(p + o_rsnap);
     E.inside = (int*)(p + o_inside);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
@@ -1159,20 +1172,24 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
 
 // Two builds of the same kernel: without and with the edge role, so that the register allocation (and scratch
 // footprint) of the reference-loss configurations does not depend on the extension.
-// THE TILE PASS INSIDE THE SHADING LAUNCH (EngineDev::big_inline, round 4).  big_pass_kernel between step_kernel and shade_kernel
-// costs a kernel boundary in every iteration -- 2.4 of cfg2's 43 us, measured by leaving it out -- and exits at once in nearly all
-// of them: the dense meshes of the benchmark never have a LARGE triangle.  With big_inline the launch is dropped and the shading
-// grid gets one more slab of workgroups IN FRONT (grid z = 0: the "workers", S per hypothesis): a worker reads its hypothesis'
-// count of large triangles and leaves if it is zero; otherwise the S workers of the hypothesis split its large tiles (a wave per
-// tile, big_tile_wave with a 16-triangle stage), and each adds one to the hypothesis' arrival counter when its atomics have been
-// performed.  A shading workgroup looks at the same count (one scalar load, requested before its flag scan) and, only if it is not
-// zero, waits until all S workers have arrived.  Why that cannot hang: workgroups are dispatched in the order of their linear id,
-// per XCD, and the workers of hypothesis b (block ids b + B (...), B % 8 == 0) sit on the same XCD b % 8 as its shading workgroups
-// with smaller ids -- a shading workgroup that runs implies that every worker of its hypothesis has been dispatched, and a worker
-// waits for nothing.  What crosses the wait is zbuf, written by atomics only and not read by the shading workgroups before; no
-// fence (agent-scope fences cost 23-34 us per round here, tools/ubench/group_barrier.hip), no heavy code in the shading path (the
-// round-3 form -- the shading workgroups running the tile pass themselves through a call -- cost the kernel 13 spilled registers
-// and 2.5 us whether or not a large triangle existed).  Same triangles, same keys, same zbuf as the separate launch.
+// THE TILE PASS INSIDE THE SHADING LAUNCH (EngineDev::big_inline, round 4; made placement-independent in round 5).  big_pass_kernel
+// between step_kernel and shade_kernel costs a kernel boundary in every iteration -- 2.4 of cfg2's 43 us, measured by leaving it out
+// -- and exits at once in nearly all of them: the dense meshes of the benchmark never have a LARGE triangle.  With big_inline the
+// launch is dropped and the shading grid gets one more slab of workgroups IN FRONT (grid z = 0: the "workers", S per hypothesis): a
+// worker reads its hypothesis' count of large triangles and leaves if it is zero; otherwise the S workers of the hypothesis split its
+// large tiles (a wave per tile, big_tile_wave with a 16-triangle stage), and each adds one to the hypothesis' arrival counter -- behind
+// an agent-scope RELEASE -- when its atomics have been performed.  A shading workgroup looks at the same count (one scalar load,
+// requested before its flag scan) and, only if it is not zero, waits until all S workers have arrived, then executes an agent-scope
+// ACQUIRE (both fences sit on this rare path only: a hypothesis with large triangles on a mesh where none were expected).
+// LIVENESS: HIP promises nothing about dispatch order or workgroup -> XCD placement (MI355X_MICROARCH.md).  On this stack workgroups
+// are observed to start in the order of their linear id, so a shading workgroup that runs implies that its workers -- smaller ids --
+// have started, and the wait is short.  Nothing depends on that: the wait is BOUNDED (EngineDev::wait_ticks of the 100 MHz clock);
+// a workgroup whose budget runs out sets ENGINE_FLAG_INLINE_TIMEOUT in the status block and goes on with what the depth buffer
+// holds.  Every kernel of the run still terminates and leaves the buffers re-armed, its numbers are void, and the host
+// (ddx_engine_run_check, called by whoever synchronises next) restores the parameters and optimiser state the run started from
+// (EngineDev::run_snap) and repeats it with the tile pass as its own launch, for good.  Same triangles, same keys, same zbuf as the
+// separate launch.  No heavy code in the shading path (the round-3 form -- the shading workgroups running the tile pass themselves
+// through a call -- cost the kernel 13 spilled registers and 2.5 us whether or not a large triangle existed).
 __device__ __forceinline__ void big_worker_wg(const EngineDev& E, int b, int sl, int S, int it_arg)
 {
     S = min(S, E.big_workers);
@@ -1197,14 +1214,28 @@ __device__ __forceinline__ void big_worker_wg(const EngineDev& E, int b, int sl,
     }
     __builtin_amdgcn_s_waitcnt(0);  // this wave's atomics have been performed
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(L.bigarrive + hb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        // (the depth keys went out as agent-scope atomics; the release covers whatever else a future worker may store)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind buffer_wbl2: MI355X_MICROARCH.md "Compiler hazard")
+        __hip_atomic_fetch_add(L.bigarrive + hb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-// a shading workgroup of a hypothesis that HAS large triangles: until its S workers have arrived
-__device__ __forceinline__ void big_wait(int* arrive, int S)
+// a shading workgroup of a hypothesis that HAS large triangles: until its S workers have arrived, or until the budget is spent
+// (then: the status flag, and on with whatever zbuf holds -- the run is repeated by the host, see above).  Out of line: rare path.
+__device__ __attribute__((noinline)) static void big_wait(int* arrive, int S, unsigned budget, int* flags)
 {
-    if (threadIdx.x == 0)
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool ok = true;
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)budget) { ok = false; break; }
+        }
+        if (!ok) __hip_atomic_fetch_or(flags, ENGINE_FLAG_INLINE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 holds nothing older than the workers' arrival
+    }
     __syncthreads();
 }
 
@@ -1246,7 +1277,7 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
     tw.n_mine = tw.n_flags > tw.sl ? (tw.n_flags - tw.sl + tw.S - 1) / tw.S : 0;
     wave_lds_sync();
     if (lister && tw.sl == 0 && lane == 0) L.b_count[tw.b] = tw.n_flags;
-    if (n_big_list > 0) big_wait(L.bigarrive + (size_t)tw.par * E.d.B + b, min(S, E.big_workers));  // (workgroup-uniform; rare)
+    if (n_big_list > 0) big_wait(L.bigarrive + (size_t)tw.par * E.d.B + b, min(S, E.big_workers), E.wait_ticks, &E.st->flags);  // (workgroup-uniform; rare)
     STAMP(E, 1, wg_id, 1);
     const int role = z == 0 ? E.roles[0] : E.roles[1];
     if (role == 0) shade_body<0, EDGE>(E, pool, tw);
@@ -1263,6 +1294,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
     // grid (B, S, roles), or (B, S, 1 + roles) with the tile pass inside the launch: slab z = 0 = its workers
     int z = blockIdx.z;
     if (E.big_inline) {
+        if (E.dbg_reverse) z = z + 1 == (int)gridDim.z ? 0 : z + 1;  // (tests: the workers get the LARGEST ids)
         if (z == 0) {
             big_worker_wg(E, E.b_off + blockIdx.x, blockIdx.y, gridDim.y, it_arg);
             return;
@@ -1281,6 +1313,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_group_kernel(const
     if ((int)blockIdx.y >= E.s_shade) return;
     int z = blockIdx.z;
     if (E.big_inline) {  // (the same for every member of a launch: grid z = 3)
+        if (E.dbg_reverse) z = z + 1 == (int)gridDim.z ? 0 : z + 1;
         if (z == 0) {
             big_worker_wg(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_shade, it_arg);
             return;
@@ -1652,7 +1685,9 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
                         best = __uint_as_float(ub);
                         w = (int)(unsigned)(key & 0xffffffffull);
                     }
-                    E.sel_out[0] = best;
+                    // (a run whose in-launch tile pass timed out is void: NaN tells the reader of the row to call ddx_engine_run_check)
+                    const int fl = __hip_atomic_load(&E.st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    E.sel_out[0] = fl ? __uint_as_float(0x7fc00000u) : best;
                     E.sel_out[1] = (float)(w + E.sel_lo);
                     const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the step_kernel that drew it)
                     for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
@@ -1786,6 +1821,9 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
         // first iteration of a run: the parameters as the caller holds them (un-normalised)
         if (tid < 7) snew[tid] = E.b.params[(size_t)tid * B + b];
         if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
+        if (mode == STEP_FIRST && slot == 0 && tid < 21) {  // what ddx_engine_run_check restores should this run have to be repeated (EngineDev::run_snap)
+            E.run_snap[(size_t)tid * B + b] = tid < 7 ? E.b.params[(size_t)tid * B + b] : E.adam[((size_t)par * 14 + (tid - 7)) * B + b];
+        }
         __syncthreads();
     }
     const bool writer = slot == 0;
@@ -1831,7 +1869,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     }
     const int cull = (E.cull_sign != 0 && inside_all) ? E.cull_sign : 0;
     if (writer) {
-        if (mode == STEP_FIRST && tid < 7) E.params2[((size_t)par * 7 + tid) * B + b] = snew[tid];
+        if (mode != STEP_NORMAL && tid < 7) E.params2[((size_t)par * 7 + tid) * B + b] = snew[tid];
         if (tid == 0) {
             E.inside[b] = inside_all ? 1 : 0;
             E.L.bigcount[(size_t)(1 - par) * B + b] = 0;  // the other parity's list of large triangles: consumed, nobody reads it now
@@ -1839,7 +1877,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
             if (b == 0) {
                 E.L.counters[3 + (1 - par)] = 0;  // ... and its "a large triangle exists" word
                 E.st->it_next = it + 1;           // (read by big_pass / shade / edge of this iteration)
-                if (mode == STEP_FIRST) E.st->it = it;
+                if (mode != STEP_NORMAL) E.st->it = it;
             }
         }
     }
@@ -2171,7 +2209,7 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s, int half 
         capturing = hipStreamIsCapturing(s, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
     }
     // (the calibration reads its measurements back and synchronises the stream once per set-up -- ddx.h; never inside a capture)
-    const bool calibrate = can_balance && !e->balanced && mode == STEP_FIRST && !E.eval_grad && !capturing;
+    const bool calibrate = can_balance && !e->balanced && mode != STEP_NORMAL && !capturing;
     if (calibrate) { E.slot_table = 0; E.mcost_rec = 1; }
     const bool tab = can_balance && (calibrate || E.slot_table);
     const dim3 g = (tab || E.step_xcd) ? dim3(nb, SL) : dim3(SL, nb);
@@ -2326,6 +2364,10 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         if (const char* ov = getenv("DDX_TWO_STREAMS")) e->two_streams = atoi(ov);
         if (const char* ov = getenv("DDX_TWO_MIN")) { e->two_min_iters = std::max(2, atoi(ov)); e->two_min_env = true; }
         E.big_inline = 0;
+        E.wait_ticks = 2000000u;  // 20 ms of the 100 MHz clock: a tile pass that really runs takes 0.1-2 ms on the heaviest cases measured
+        if (const char* ov = getenv("DDX_BIG_WAIT_US")) E.wait_ticks = (unsigned)std::max(1, atoi(ov)) * 100u;
+        E.dbg_reverse = 0;
+        if (const char* ov = getenv("DDX_DEBUG_REVERSE_SLABS")) E.dbg_reverse = atoi(ov) != 0;
         E.big_workers = 64;
         if (const char* ov = getenv("DDX_BIG_WORKERS")) E.big_workers = std::max(1, atoi(ov));
         E.scatter_mode = 0;
@@ -2884,6 +2926,7 @@ static int ensure_side_stream(ddx_engine* e, hipStream_t s, bool* usable)
         if (err) return err;
         if (!e->side) {
             e->two_streams = 0;  // (no stream of this process runs beside the caller's: one chain)
+            e->probe_outcome = 0;
             return 0;
         }
         DDX_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -2892,6 +2935,7 @@ static int ensure_side_stream(ddx_engine* e, hipStream_t s, bool* usable)
         if (int err = side_runs_beside(e, s, e->side, &ok)) return err;
     }
     e->side_checked.push_back(std::make_pair(s, ok));
+    e->probe_outcome = ok ? 1 : 0;
     *usable = ok;
     return 0;
 }
@@ -2991,7 +3035,68 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
     e->dev.sel_out = nullptr;
     if (ferr) return ferr;
     e->adam_parity = (it0 + n) & 1;
+    e->last.kind = 1; e->last.it0 = it0; e->last.n = n; e->last.use_graph = use_graph; e->last.sel_out = sel_out; e->last.sel_lo = sel_lo;
     return 0;
+}
+
+// The host half of the bounded wait (big_wait): synchronises `stream`, reads the engine's flag word, and if a shading workgroup of
+// the last run gave up waiting for the in-launch tile pass: clears the flag, moves the tile pass of this engine into its own launch
+// for good, puts parameters and optimiser state back to what the run started from (run_snap, written by the run's first launch) and
+// runs it again -- same iterations, same selection target -- then synchronises once more.  Returns 0 (nothing to do), 1 (the run
+// was repeated), or an error code.  An evaluation pass that timed out is simply repeated by its caller after this has returned 1.
+static int read_flags(ddx_engine* e, hipStream_t s, int* flags)
+{
+    DDX_HIP(hipStreamSynchronize(s));
+    DDX_HIP(hipMemcpy(flags, &e->dev.st->flags, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int disable_inline(ddx_engine* e, hipStream_t s)
+{
+    const int zero = 0;
+    DDX_HIP(hipMemcpy(&e->dev.st->flags, &zero, sizeof(int), hipMemcpyHostToDevice));
+    e->inline_ok = false;
+    e->dev.big_inline = 0;
+    // a captured graph holds launches of the in-launch form: captured again by the next run that asks for one
+    if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    ++e->setup_gen;  // (a group compares generations: its table row of this member is stale now)
+    (void)s;
+    return 0;
+}
+
+static int restore_run_start(ddx_engine* e, int it0, hipStream_t s)
+{
+    EngineDev& E = e->dev;
+    const size_t B = (size_t)E.d.B;
+    const int par = it0 & 1;
+    DDX_HIP(hipMemcpyAsync(E.b.params, E.run_snap, 7 * B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DDX_HIP(hipMemcpyAsync(E.adam + (size_t)par * 14 * B, E.run_snap + 7 * B, 14 * B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->adam_parity = par;
+    return 0;
+}
+
+extern "C" int ddx_engine_run_check(ddx_engine* e, void* stream)
+{
+    DDX_REQUIRE(e, DDX_E_NULL, "engine_run_check: NULL engine");
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->setup_done) return 0;
+    int flags = 0;
+    if (int err = read_flags(e, s, &flags)) return err;
+    if (!(flags & ENGINE_FLAG_INLINE_TIMEOUT)) {
+        e->last.kind = 0;  // (checked and clean: nothing to repeat, whatever times out later)
+        return 0;
+    }
+    if (getenv("DDX_DEBUG_INLINE")) fprintf(stderr, "ddx: the in-launch tile pass timed out (flags %d): separate launch from now on, repeating the run\n", flags);
+    if (int err = disable_inline(e, s)) return err;
+    // (the flag is sticky: it may stem from the last run or from an evaluation behind it.  Repeating the run is right in both cases --
+    // an evaluation changes nothing the run's result depends on -- and the caller repeats its evaluation when this returns 1)
+    if (e->last.kind == 1) {
+        if (int err = restore_run_start(e, e->last.it0, s)) return err;
+        if (int err = engine_run_impl(e, e->last.it0, e->last.n, e->last.use_graph, stream, e->last.sel_out, e->last.sel_lo)) return err;
+        DDX_HIP(hipStreamSynchronize(s));
+    }
+    return 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3049,8 +3154,13 @@ extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* lo
     if (!e->setup_done)
         if (int err = engine_setup(e, s)) return err;
     if (int err = run_prologue(e, it, s)) return err;
-    int err = launch_step(e, STEP_FIRST, it, s);
+    // (an evaluation always takes the tile pass as its own launch: nothing in it can time out, so ddx_engine_run_check only ever has
+    // runs to repeat; same bits either way)
+    const int keep_inline = e->dev.big_inline;
+    e->dev.big_inline = 0;
+    int err = launch_step(e, STEP_EVAL, it, s);
     if (!err) err = launch_rest(e, it, s, nullptr);
+    e->dev.big_inline = keep_inline;
     e->dev.eval_grad = grad_out;  // (finish_kernel in evaluation mode: hands out gradient and losses, steps nothing)
     e->dev.eval_loss = loss_out;
     if (!err) err = launch_finish(e, it + 1, s);
@@ -3136,10 +3246,19 @@ extern "C" int ddx_engine_new_observation(ddx_engine* e)
     if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     e->adam_parity = 0;
     e->fwd_cached_it = -1;
+    e->last.kind = 0;
     return 0;
 }
 
 extern "C" int ddx_engine_cull_sign(ddx_engine* e) { return (e && e->setup_done) ? e->dev.cull_sign : 0; }
+
+// the outcome of the two-stream probe (ensure_side_stream): 1 = a stream of the engine's runs beside the caller stream it met last,
+// long runs go out as two half-batch chains; 0 = probed, no such stream (or switched off): one chain; -1 = never probed (the engine
+// is not eligible: launches that fill the chip, tile pass as its own launch, B not a multiple of 16)
+extern "C" int ddx_engine_two_chains(ddx_engine* e)
+{
+    return e ? e->probe_outcome : -1;
+}
 
 extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_out, const char** names_out, int max_k, void* stream)
 {
@@ -3158,7 +3277,7 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     int timed = 0;
     for (int i = 0; i < iters; ++i) {
         DDX_HIP(hipEventRecord(ev[K_STEP], s));
-        if (int err = launch_step(e, i == 0 ? STEP_FIRST : STEP_NORMAL, it0 + i, s)) return err;
+        if (int err = launch_step(e, i == 0 ? STEP_EVAL : STEP_NORMAL, it0 + i, s)) return err;
         if (int err = launch_rest(e, it0 + i, s, ev)) return err;
         DDX_HIP(hipEventSynchronize(ev[K_FINISH]));
         if (i == 0 && iters > 1) continue;
@@ -3174,6 +3293,7 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     DDX_HIP(hipEventRecord(ev[K_COUNT], s));
     DDX_HIP(hipEventSynchronize(ev[K_COUNT]));
     e->adam_parity = (it0 + iters) & 1;
+    e->last.kind = 0;  // (a profile steps the optimiser without a snapshot: nothing to repeat)
     for (int k = K_STEP; k < K_FINISH; ++k) ms_out[k] /= (float)timed;
     if (!e->dev.d.use_edge) ms_out[K_EDGE] = 0.f;  // (not launched)
     if (e->dev.big_inline) ms_out[K_BIG] = 0.f;    // (not launched: the tile pass rides in the shading launch; the interval is two event records)
@@ -3193,6 +3313,7 @@ struct ddx_engine_group {
     std::vector<unsigned> gen_up;      // set-up generation of each member when its row was uploaded (0 = never)
     bool uploaded = false;
     bool big_inline = false;  // decided with the table upload
+    int last_it0 = 0, last_n = 0;  // the last run, for ddx_engine_group_run_check (last_n = 0: none, or seen clean)
 };
 
 extern "C" int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_group** out)
@@ -3357,8 +3478,36 @@ extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* s
         finish_group_kernel<<<dim3(UPD_SLICES, H.bpre[H.n]), 256, 0, s>>>(g->d_tab, H, it0 + n);
         DDX_LAUNCH_CHECK();
     }
-    for (auto* e : g->members) e->adam_parity = (it0 + n) & 1;
+    for (auto* e : g->members) { e->adam_parity = (it0 + n) & 1; e->last.kind = 0; }
+    g->last_it0 = it0;
+    g->last_n = n;
     return 0;
+}
+
+// ddx_engine_run_check for a group: any member's flag repeats the group's last run with the tile pass of EVERY member in its own launch
+extern "C" int ddx_engine_group_run_check(ddx_engine_group* g, void* stream)
+{
+    DDX_REQUIRE(g, DDX_E_NULL, "engine_group_run_check: NULL group");
+    hipStream_t s = (hipStream_t)stream;
+    bool any = false;
+    for (auto* e : g->members) {
+        if (!e->setup_done) continue;
+        int flags = 0;
+        if (int err = read_flags(e, s, &flags)) return err;
+        any = any || (flags & ENGINE_FLAG_INLINE_TIMEOUT);
+    }
+    if (!any) { g->last_n = 0; return 0; }
+    for (auto* e : g->members) {
+        if (int err = disable_inline(e, s)) return err;
+        if (g->last_n > 0)
+            if (int err = restore_run_start(e, g->last_it0, s)) return err;
+    }
+    g->uploaded = false;
+    if (g->last_n > 0) {
+        if (int err = ddx_engine_group_run(g, g->last_it0, g->last_n, stream)) return err;
+        DDX_HIP(hipStreamSynchronize(s));
+    }
+    return 1;
 }
 
 // a member's observation changed (ddx_engine_new_observation): its table row is uploaded again by the next run

@@ -88,7 +88,11 @@ def global_argmin_fused(loss_rows, row_mask, mtx, lo=0, group=None):
 def run_and_select(eng, n, lo=0, group=None, use_graph=False):
     """eng.run(n) + global_argmin_fused of its last iteration with the local selection folded into the run's LAST kernel
     (ddx_engine_run_select): no selection launch, and in one process the 18 floats land in pinned host memory, so the end of a
-    run is one kernel and one synchronisation.  Returns (global index, loss, pose [4,4] on the host), identical on every rank."""
+    run is one kernel and one synchronisation.  Returns (global index, loss, pose [4,4] on the host), identical on every rank.
+    A NaN loss in a row says that rank's run was void (its in-launch tile pass timed out, ddx.h ddx_engine_run_check): the owner
+    repeats the run -- which rewrites its row -- and the exchange is made once more."""
+    import math
+
     import torch.distributed as dist
 
     if not dist.is_initialized():
@@ -96,21 +100,40 @@ def run_and_select(eng, n, lo=0, group=None, use_graph=False):
             table = _pinned_row()
             eng.run_select(table, n, lo=lo, use_graph=use_graph)
             torch.cuda.current_stream().synchronize()
+            if math.isnan(float(table[0, 0])):
+                eng.finish()  # (repeats the run with the separate tile-pass launch; the same pinned row receives the result)
+            else:
+                eng._unchecked = False
             t = table.numpy()
             return int(t[0, 1]), float(t[0, 0]), table[0, 2:].clone().reshape(4, 4)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    # (the exchange table is kept per (device, world) and zeroed again right AFTER it has been read -- off the path of the next call,
-    # which would otherwise begin with a fill launch in front of its first kernel)
-    key = (eng.params.device, world)
-    table = _TABLES.get(key)
-    if table is None:
-        table = _TABLES[key] = torch.zeros((world, 18), dtype=torch.float32, device=eng.params.device)
-    try:
-        eng.run_select(table[rank], n, lo=lo, use_graph=use_graph)
-        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
-        t = table.cpu().numpy()
-    finally:
-        table.zero_()
+    # (the exchange table is kept per (device, group, stream) and zeroed again right AFTER it has been read -- off the path of the
+    # next call, which would otherwise begin with a fill launch in front of its first kernel; the lock keeps two threads of a
+    # process from summing each other's rows)
+    key = (eng.params.device, world, id(group), torch.cuda.current_stream().cuda_stream)
+    with _TABLES_LOCK:
+        table = _TABLES.get(key)
+        if table is None:
+            table = _TABLES[key] = torch.zeros((world, 18), dtype=torch.float32, device=eng.params.device)
+        try:
+            eng.run_select(table[rank], n, lo=lo, use_graph=use_graph)
+            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+            t = table.cpu().numpy()
+            if any(math.isnan(float(v)) for v in t[:, 0]):
+                # some rank's run was void: every rank keeps its own row (the void one's is rewritten by the repeated run)
+                own = torch.from_numpy(t[rank].copy())
+                table.zero_()
+                if math.isnan(float(t[rank, 0])):
+                    eng.finish()
+                else:
+                    table[rank].copy_(own)
+                    eng._unchecked = False
+                dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+                t = table.cpu().numpy()
+            else:
+                eng._unchecked = False
+        finally:
+            table.zero_()
     losses, gidx = t[:, 0], t[:, 1]
     cand = [(gidx[r], r) for r in range(world) if losses[r] == losses.min()]
     row = min(cand)[1]
@@ -122,6 +145,7 @@ import threading
 _PINNED = None
 _TABLES = {}
 _PINNED_LOCK = threading.Lock()
+_TABLES_LOCK = threading.Lock()
 
 
 def _pinned_row():

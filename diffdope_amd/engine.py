@@ -120,14 +120,28 @@ class RefineEngine:
         _lib.check(self.lib.ddx_engine_create(ctypes.byref(d), ctypes.byref(b), ctypes.byref(h)), "ddx_engine_create")
         self.handle = h
         self.it = 0
+        self._unchecked = False  # a run has been enqueued that ddx_engine_run_check has not seen yet
+        self.repeated_runs = 0   # runs ddx_engine_run_check had to repeat (the in-launch tile pass timed out: ddx.h)
+
+    def _run_check(self):
+        """ddx_engine_run_check: synchronises the current stream; True when the last run was void and has been repeated."""
+        rc = self.lib.ddx_engine_run_check(self.handle, _lib.stream_ptr())
+        if rc not in (0, 1):
+            _lib.check(rc, "ddx_engine_run_check")
+        self._unchecked = False
+        self.repeated_runs += int(rc == 1)
+        return rc == 1
 
     def run(self, n=None, use_graph=False):
         """Run n iterations (default: all remaining) asynchronously on the current stream.
         use_graph=k (or True = 1) replays a captured hipGraph of k iterations; with 4 launches per iteration plain
         stream launches measured 9 % faster than k = 1 and equal to k = 20 on MI355X, so streams are the default."""
         n = self.max_iters - self.it if n is None else n
+        if self._unchecked:  # (a run behind a void one would start from void parameters: ddx.h ddx_engine_run_check)
+            self._run_check()
         _lib.check(self.lib.ddx_engine_run(self.handle, self.it, n, int(use_graph), _lib.stream_ptr()), "ddx_engine_run")
         self.it += n
+        self._unchecked = n > 0
 
     def run_select(self, out18, n=None, lo=0, use_graph=False):
         """run(n) with the arg-min selection of its last iteration folded into the run's last kernel (ddx_engine_run_select):
@@ -135,9 +149,12 @@ class RefineEngine:
         hypothesis over the enabled terms, lo + its index, its 4x4 pose), as ddx_select_best would write it."""
         n = self.max_iters - self.it if n is None else n
         assert out18.dtype == torch.float32 and out18.numel() >= 18 and out18.is_contiguous() and (out18.is_cuda or out18.is_pinned())
+        if self._unchecked:
+            self._run_check()
         _lib.check(self.lib.ddx_engine_run_select(self.handle, self.it, n, int(use_graph), int(lo), out18.data_ptr(), _lib.stream_ptr()),
                    "ddx_engine_run_select")
         self.it += n
+        self._unchecked = True  # (cleared without a further call by a reader that finds out18[0] finite: dist.run_and_select)
 
     def new_observation(self, gt=None, params=None, lr_mult=None, lr_sched=None):
         """The same object in a new frame (ddx_engine_new_observation): copies the given observed images (dict with the keys
@@ -163,16 +180,24 @@ class RefineEngine:
             put(self.lr_sched, torch.as_tensor(lr_sched, dtype=torch.float64).to(torch.float32), "lr_sched")
         _lib.check(self.lib.ddx_engine_new_observation(self.handle), "ddx_engine_new_observation")
         self.it = 0
+        self._unchecked = False
 
     def finish(self):
-        """Wait until everything run() enqueued on the current stream has executed (run() itself is asynchronous)."""
+        """Wait until everything run() enqueued on the current stream has executed (run() itself is asynchronous) and make sure
+        it is valid (ddx_engine_run_check: a run whose in-launch tile pass timed out is repeated here, with the separate launch).
+        Returns True when that happened."""
+        if self._unchecked:
+            return self._run_check()
         torch.cuda.current_stream().synchronize()
+        return False
 
     def loss_and_grad(self):
         """One evaluation pass at the CURRENT contents of `params`, no optimiser step: returns (losses [4,B] weighted,
         un-LR'd per hypothesis (rgb, depth, mask, edge), grad [7,B] = d loss / d params with
         loss = sum_k sum_b lr_mult[b] * losses[k,b] / global_batch).  For callers that bring their own optimiser."""
         B = self.B
+        if self._unchecked:
+            self._run_check()
         grad = torch.empty((7, B), dtype=torch.float32, device=self.params.device)
         losses = torch.empty((4, B), dtype=torch.float32, device=self.params.device)
         it = min(self.it, self.max_iters - 1)
@@ -198,17 +223,27 @@ class RefineEngine:
         """0 = both faces drawn; +-1 = back faces (snapped area of that sign) culled (decided by the first run / eval)."""
         return int(self.lib.ddx_engine_cull_sign(self.handle))
 
+    @property
+    def two_chains(self):
+        """1 = long runs go out as two half-batch chains (the set-up's probe found a stream that runs beside the caller's), 0 = probed
+        and refused (one chain), -1 = not eligible / not probed yet (ddx.h ddx_engine_two_chains)."""
+        return int(self.lib.ddx_engine_two_chains(self.handle))
+
     def rewind(self, it=0):
         self.it = it
 
     def status(self):
         """dict(overflow (always 0), big_triangles (0/1: the tile pass ran), active_tiles, it (the last iteration drawn), n_seg,
         outside_view_volume (hypotheses of the last iteration whose bounding box had a corner at w <= 0 or |z| > w: near-plane
-        clipping and two-sided drawing for those)) -- synchronises."""
+        clipping and two-sided drawing for those), flags (ddx.h status word 7; 0 after the check this call makes),
+        repeated_runs) -- synchronises."""
+        if self._unchecked:
+            self._run_check()
         p = self.lib.ddx_engine_status_ptr(self.handle)
         off = p - self.scratch.data_ptr()
         st = self.scratch[off:off + 32].view(torch.int32).cpu().tolist()
-        return dict(overflow=st[0], big_triangles=st[1], active_tiles=st[2], it=st[5] - 1, n_seg=st[4], outside_view_volume=st[6])
+        return dict(overflow=st[0], big_triangles=st[1], active_tiles=st[2], it=st[5] - 1, n_seg=st[4], outside_view_volume=st[6],
+                    flags=st[7], repeated_runs=self.repeated_runs)
 
     def check(self):
         st = self.status()
@@ -220,13 +255,19 @@ class RefineEngine:
         """Per-kernel average launch duration in ms (hipEvents on the current stream).  Mutates params."""
         ms = (ctypes.c_float * KERNEL_NAMES_MAX)()
         names = (ctypes.c_char_p * KERNEL_NAMES_MAX)()
+        if self._unchecked:
+            self._run_check()
         k = self.lib.ddx_engine_profile(self.handle, it0, iters, ms, names, KERNEL_NAMES_MAX, _lib.stream_ptr())
         if k <= 0:
             _lib.check(k if k else -99, "ddx_engine_profile")
+        if self.lib.ddx_engine_run_check(self.handle, _lib.stream_ptr()) == 1:  # (a profile is not repeated: measure again)
+            raise RuntimeError("profile: the in-launch tile pass timed out; the engine now uses the separate launch -- profile again")
         return {names[i].decode(): float(ms[i]) for i in range(k)}
 
     def losses(self):
         """[iters_done, 4, B] weighted un-LR'd per-hypothesis losses (rgb, depth, mask, edge)."""
+        if self._unchecked:
+            self._run_check()
         return self.loss_log[: self.it]
 
     def __del__(self):
@@ -256,6 +297,16 @@ class RefineEngineGroup:
         h = ctypes.c_void_p()
         _lib.check(self.lib.ddx_engine_group_create(arr, len(self.engines), ctypes.byref(h)), "ddx_engine_group_create")
         self.handle = h
+        self._unchecked = False
+        self.repeated_runs = 0
+
+    def _run_check(self):
+        rc = self.lib.ddx_engine_group_run_check(self.handle, _lib.stream_ptr())
+        if rc not in (0, 1):
+            _lib.check(rc, "ddx_engine_group_run_check")
+        self._unchecked = False
+        self.repeated_runs += int(rc == 1)
+        return rc == 1
 
     @property
     def it(self):
@@ -267,9 +318,12 @@ class RefineEngineGroup:
         if len({e.it for e in self.engines}) != 1:  # (a member was run, rewound or given a new observation on its own)
             raise ValueError("the members of a group must sit at the same iteration: " + str([e.it for e in self.engines]))
         n = e0.max_iters - e0.it if n is None else n
+        if self._unchecked:
+            self._run_check()
         _lib.check(self.lib.ddx_engine_group_run(self.handle, e0.it, n, _lib.stream_ptr()), "ddx_engine_group_run")
         for e in self.engines:
             e.it += n
+        self._unchecked = n > 0
 
     def invalidate(self):
         """A member was re-created in place (same handle, other buffers): its table row is uploaded again by the next run.  Not
@@ -277,7 +331,11 @@ class RefineEngineGroup:
         _lib.check(self.lib.ddx_engine_group_invalidate(self.handle), "ddx_engine_group_invalidate")
 
     def finish(self):
+        """Synchronise and validate (ddx_engine_group_run_check); True when the group's last run had to be repeated."""
+        if self._unchecked:
+            return self._run_check()
         torch.cuda.current_stream().synchronize()
+        return False
 
     def __del__(self):
         try:

@@ -225,10 +225,12 @@ typedef struct ddx_engine_desc {
     /* Where the tile pass for LARGE / near-clipped triangles runs.  0 (default): the set-up estimates the longest edge of the mesh in
      * pixels from the observed object's size; where no large triangle is to be expected (dense meshes) and B is a multiple of 8,
      * the launch between the rasterising and the shading kernel is dropped and worker workgroups in the first slab of the shading
-     * launch run the pass for a hypothesis that has such triangles after all (no waiting that could hang: workgroups are
-     * dispatched in id order per XCD, and a hypothesis' workers have smaller ids than its shading workgroups on the same XCD;
-     * DESIGN.md section 4).  1: always the separate launch.  Environment DDX_BIG_INLINE=0 / 1 overrides the estimate.  Same
-     * results either way, bit for bit. */
+     * launch run the pass for a hypothesis that has such triangles after all.  The shading workgroups of such a hypothesis wait
+     * for its workers behind agent-scope release / acquire fences and for a BOUNDED time (20 ms; DDX_BIG_WAIT_US): nothing is
+     * assumed about dispatch order or workgroup placement.  A wait that runs out sets bit 0 of status word 7, the run still
+     * terminates, its numbers are void, and ddx_engine_run_check repeats it with the separate launch.
+     * 1: always the separate launch.  Environment DDX_BIG_INLINE=0 / 1 overrides the estimate.  Same results either way, bit
+     * for bit. */
     int32_t separate_big_pass;
     /* 0 (default): ddx_engine_run / ddx_engine_run_select may issue a run of 16 or more iterations (48 or more for larger step
      * launches; never above 7 000 meshlet-hypothesis pairs, where one launch fills the chip; no graph replay, no capture in
@@ -288,6 +290,16 @@ int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
  * loss terms of the winner's weighted losses, lo + its local index, its 4x4 pose row-major), ties to the lowest index, a NaN
  * loss never wins.  With out18 in mapped host memory the end of a run costs one kernel and one synchronisation. */
 int ddx_engine_run_select(ddx_engine* e, int it0, int n, int use_graph, int lo, float* out18, void* stream);
+/* The host half of every bounded in-kernel wait (at present: the tile pass inside the shading launch, separate_big_pass above).
+ * Synchronises `stream` and reads status word 7.  0: the work enqueued so far is valid.  1: a wait of the last ddx_engine_run /
+ * ddx_engine_run_select ran out -- the engine has been switched to the separate tile-pass launch for good, parameters and
+ * optimiser state have been put back to what that run started from (a snapshot its first kernel takes) and the run has been
+ * repeated, same iterations, same out18, and has finished: its results are valid now, bit for bit those of an engine created
+ * with separate_big_pass = 1.  An evaluation pass (ddx_engine_eval / ddx_render_loss_*) enqueued since must be repeated by the
+ * caller.  Call it wherever the results of a run are consumed and before the next run is enqueued (a second run behind a void
+ * one starts from void parameters); the Python RefineEngine does both.  ddx_engine_run_select also signals the condition in
+ * band: out18[0] is NaN (never otherwise) when the run was void.  Negative / positive > 1: error codes as everywhere. */
+int ddx_engine_run_check(ddx_engine* e, void* stream);
 /* Evaluation pass without an optimiser step (for callers that bring their own optimiser): renders the hypotheses
  * at the CURRENT contents of `params`, writes d loss / d params to grad_out [7,B] and the weighted, un-LR'd
  * per-hypothesis losses (rgb, depth, mask, edge) to loss_out [4,B] (may be NULL); parameters, optimiser state and logs
@@ -314,7 +326,8 @@ int ddx_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
  * lo = global index of the first local hypothesis; out18 = (mean loss of the winner, its global index, its 4x4
  * pose row-major): this rank's row of the [world,18] table that ONE all_reduce(SUM) exchanges. */
 int ddx_select_best(const float* loss_rows, int row_mask, int B, const float* mtx, int lo, float* out18, void* stream);
-/* device int32[8] inside scratch: [0] reserved (always 0), [1] large triangles (tile-pass) of the last
+/* device int32[8] inside scratch ([7]: bit 0 = a bounded wait of the in-launch tile pass ran out since the last
+ * ddx_engine_run_check -- every number produced since is void until that call has returned): [0] reserved (always 0), [1] large triangles (tile-pass) of the last
  * iteration, [2] active tiles of the last iteration, [3] internal, [4] pixels with seg != 0, [5] last iteration drawn + 1,
  * [6] hypotheses of the last iteration whose object-space bounding box had a corner outside the view volume (w <= 0 or
  * |z| > w): their triangles with a vertex at w <= 0 took the near-plane clipping path and their back faces were drawn -- 0 in any
@@ -324,6 +337,10 @@ const int32_t* ddx_engine_status_ptr(ddx_engine* e);
  * decision is taken by the first run / eval); +1 / -1: triangles whose snapped screen area has this sign are culled as back
  * faces in hypotheses that lie inside the view volume. */
 int ddx_engine_cull_sign(ddx_engine* e);
+/* Outcome of the set-up's two-stream probe (single_stream above): 1 = long runs of this engine go out as two half-batch chains
+ * (a stream of the engine's was measured to run beside the caller's); 0 = probed and refused (streams sharing a hardware queue
+ * take turns: one chain); -1 = not eligible or not probed yet. */
+int ddx_engine_two_chains(ddx_engine* e);
 /* The same object in a new frame (tracking): the caller has overwritten the contents of gt_rgb / gt_depth / gt_seg, params, lr_mult
  * and / or lr_sched IN PLACE (same buffers, same shapes); mesh, texture and projection are unchanged.  The next run / eval redoes
  * the observation half of the set-up only (frame constants, sorted segmentation list, optimiser state, iteration 0) and keeps the
@@ -347,6 +364,9 @@ typedef struct ddx_engine_group ddx_engine_group;
 int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_group** out);
 /* iterations [it0, it0 + n) of every member; asynchronous on `stream` (plain stream launches) */
 int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* stream);
+/* ddx_engine_run_check for a group: 1 = a member's wait ran out; every member now runs the separate tile-pass launch, all have
+ * been put back to the start of the group's last run, and that run has been repeated and has finished */
+int ddx_engine_group_run_check(ddx_engine_group* g, void* stream);
 /* after ddx_engine_new_observation on a member nothing is needed, also when that member was then run, evaluated or profiled on
  * its own (every set-up bumps a generation counter the group compares); call this if a member was re-created in place */
 int ddx_engine_group_invalidate(ddx_engine_group* g);

@@ -3,6 +3,7 @@ from run to run (the inline tile pass); nothing in the suit
 kernels, so this repeats ddx_engine_group_run of four unlike members 50 times per shading-grid size and compares every bit --
 parameters, loss log, pose log -- with the first repetition and with each member's own run."""
 import os
+import time
 
 import pytest
 import torch
@@ -94,6 +95,64 @@ def test_tile_pass_inside_the_shading_launch_equals_the_separate_launch(name, B,
     for x, y in zip(a[:3] + a[4:], b[:3] + b[4:]):
         assert torch.equal(x, y)
     assert torch.equal(b[0], b[4]) and torch.equal(b[0], b[6]) and torch.equal(b[1], b[5])  # group members == the engine alone
+
+
+def test_bounded_wait_of_the_in_launch_tile_pass_falls_back_to_the_separate_launch():
+    """Round 5: nothing about the tile pass inside the shading launch may depend on dispatch order or placement.  With the debug
+    switch DDX_DEBUG_REVERSE_SLABS the worker slab gets the LARGEST block ids: the 64 x 8 x 2 = 1024 shading workgroups of a batch in
+    which every hypothesis has large triangles fill the chip and wait for workers that cannot start.  The wait is bounded
+    (DDX_BIG_WAIT_US), sets status word 7, every kernel still terminates, and ddx_engine_run_check -- through RefineEngine.finish(),
+    through the NaN loss dist.run_and_select finds in the selection row, and for an engine group -- restores the run's start,
+    switches the engine to the separate launch and repeats the run: parameters, loss log, pose log and the selected hypothesis
+    equal an engine that used the separate launch from the start, bit for bit."""
+    import diffdope_amd as dd
+    from diffdope_amd import dist as ddist, workloads as wl
+
+    dev = torch.device("cuda")
+    n_it = 6
+    w = wl.build("hugetri", dev, B=64)
+    lrs = wl.bench_lr_schedule(n_it, "adam")
+    keys = ("DDX_BIG_INLINE", "DDX_DEBUG_REVERSE_SLABS", "DDX_BIG_WAIT_US")
+    old = {k: os.environ.get(k) for k in keys}
+
+    def scenario():
+        e, p = wl.engine_for(w, lrs, optimizer="adam")
+        e.run(2)
+        e.run()
+        rep = e.finish()
+        st = e.check()
+        e1, p1 = wl.engine_for(w, lrs, optimizer="adam")
+        best = ddist.run_and_select(e1, n_it, lo=5)
+        e2, p2 = wl.engine_for(w, lrs, optimizer="adam")
+        e3, p3 = wl.engine_for(w, lrs, optimizer="adam")
+        g = dd.RefineEngineGroup([e2, e3])
+        g.run()
+        grep = g.finish()
+        return dict(p=p.clone(), ll=e.losses().clone(), ml=e.mtx_log.clone(), st=st, rep=e.repeated_runs, rep_now=rep, best=best, p1=p1.clone(),
+                    rep1=e1.repeated_runs, p2=p2.clone(), l2=e2.losses().clone(), p3=p3.clone(), grep=grep, flags2=e2.status()["flags"])
+
+    try:
+        os.environ.update(DDX_BIG_INLINE="0")
+        os.environ.pop("DDX_DEBUG_REVERSE_SLABS", None)
+        ref = scenario()
+        os.environ.update(DDX_BIG_INLINE="1", DDX_DEBUG_REVERSE_SLABS="1", DDX_BIG_WAIT_US="300")
+        t0 = time.time()
+        got = scenario()
+        took = time.time() - t0
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert ref["st"]["big_triangles"] == 1 and ref["rep"] == 0 and ref["rep1"] == 0 and not ref["grep"]
+    assert got["rep"] == 1 and got["rep1"] == 1 and got["grep"], "the reversed slab order must run into the bounded wait"
+    assert not got["rep_now"]  # (the first run() was repeated by the check in front of the second; nothing left for finish())
+    assert got["st"]["flags"] == 0 and got["flags2"] == 0 and took < 120
+    for k in ("p", "ll", "ml", "p1", "p2", "l2", "p3"):
+        assert torch.equal(ref[k], got[k]), k
+    assert ref["best"][:2] == got["best"][:2] and torch.equal(ref["best"][2], got["best"][2])
+    assert {k: v for k, v in ref["st"].items() if k != "repeated_runs"} == {k: v for k, v in got["st"].items() if k != "repeated_runs"}
 
 
 @pytest.mark.parametrize("name,B", [("cfg2", 64), ("cfg4", 32), ("cfg3", 48), ("cfg50k64", 64)])

@@ -105,6 +105,36 @@ def test_config4_fixed_job_two_ranks_sharing_the_gpu_matches_one_process():
     assert abs(a["final_pose"]["argmin_loss"] - b["final_pose"]["argmin_loss"]) <= 1e-3 * abs(a["final_pose"]["argmin_loss"])
 
 
+def test_config4_as_the_node_runs_it_eight_ranks_sharing_the_gpu_matches_one_process():
+    """Round 5 (the last thing that can be checked before a node exists): BASELINE configs[3] exactly as the 8-GPU node runs it --
+    `bench.py --gpus 8 --config cfg4 --global-batch 512 --steps 20 --warmup 5` under torch.distributed.run with EIGHT ranks -- on
+    the one GPU (gloo, DDX_BENCH_SHARE_GPU) against the same 512-hypothesis job in one process: eight distinct contiguous shard
+    ranges of 64 in the line, world size 8, strong scaling, the same arg-min hypothesis / loss / pose error, and every rank's
+    two-stream probe (eight processes share the GPU's hardware queues) came back with an answer instead of a hang."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DDX_BENCH_SHARE_GPU", None)
+    common = ["--config", "cfg4", "--steps", "20", "--warmup", "5", "--global-batch", "512", "--no-cpu-baseline", "--no-extras", "--no-convergence"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8"] + common
+    many = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(env, DDX_BENCH_SHARE_GPU="1"), cwd=ROOT)
+    assert many.returncode == 0, many.stdout[-2000:] + many.stderr[-4000:]
+    lines = [l for l in many.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 8 and b["dist"]["world_size"] == 8 and b["scaling"] == a["scaling"] == "strong"
+    assert b["dist"]["shard_ranges"] == [[64 * r, 64 * r + 64] for r in range(8)]
+    assert b["config"]["global_hypotheses"] == a["config"]["global_hypotheses"] == 512 and b["config"]["hypotheses_per_gpu"] == 64
+    assert len(b["dist"]["two_chains"]) == 8 and all(x in (-1, 0, 1) for x in b["dist"]["two_chains"])
+    assert a["final_pose"]["argmin_global_index"] == b["final_pose"]["argmin_global_index"]
+    assert abs(a["final_pose"]["argmin_loss"] - b["final_pose"]["argmin_loss"]) <= 1e-3 * abs(a["final_pose"]["argmin_loss"])
+    for k in ("rot_err_rad_best", "trans_err_m_best"):
+        assert abs(a["final_pose"][k] - b["final_pose"][k]) <= 1e-3 * max(abs(a["final_pose"][k]), 1e-6) + 1e-7
+    print("eight ranks on one GPU:", b["value"], "it/s of the 512-hypothesis job; one process:", a["value"], "| two-chain probe per rank:", b["dist"]["two_chains"])
+
+
 def test_multi_object_frame_with_two_ranks_sharing_the_gpu():
     """examples/run_bop_scene.py (bop.refine_frame: objects sharded over ranks, one all_reduce of the object table) with two ranks on
     the one GPU over gloo: the same poses as the single-process run, every object's owner reported."""
