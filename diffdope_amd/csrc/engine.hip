@@ -114,6 +114,8 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
 
 // EngineState::flags
 #define ENGINE_FLAG_INLINE_TIMEOUT 1  // a shading workgroup gave up waiting for the workers of the in-launch tile pass (big_wait)
+#define ENGINE_FLAG_RUN_TIMEOUT 2     // run_kernel (the one-launch form of a run): a bounded wait of a team ran out
+#define ENGINE_FLAG_RUN_BIG 4         // run_kernel met a large / near-clipped triangle (its teams do not run the tile pass): the run is void
 
 // step_kernel(mode): STEP_FIRST draws the first iteration of a run from the caller's parameters (no optimiser step);
 // STEP_NORMAL steps the optimiser for iteration it - 1 and draws iteration it
@@ -205,6 +207,13 @@ struct EngineDev {
     float* run_snap;         // [21,B] parameters (7) and optimiser moments (14) as the LAST run / evaluation found them, written by its first
                              // step launch: what ddx_engine_run_check restores before it repeats a run whose in-launch tile pass timed out
     unsigned wait_ticks;     // big_wait's budget in ticks of the 100 MHz clock (DDX_BIG_WAIT_US; default 20 ms)
+    struct RunCtl* rctl;     // run_kernel's control block (tickets, team slots, queues): all zero between runs
+    float* fin_mtx;          // [B,16] run_kernel: the pose each hypothesis drew its run's LAST iteration with (system-scope stores: read by the
+                             // workgroup that writes the selection row, on whatever XCD it runs)
+    unsigned close_ticks;    // run_kernel: how long the first member of a team waits for the team to fill before it closes it undersized
+    int dbg_run;             // DDX_DEBUG_RUN (tests), bits: 1 = every team closes at once (teams of whatever has arrived: sizes 1..G);
+                             // 2 = the members of a team never learn its size (their wait runs out: the host's fallback);
+                             // 4 = the arrivals at the team barriers as workgroup-scope atomics (measurement)
     int dbg_reverse;         // DDX_DEBUG_REVERSE_SLABS=1 (tests): the worker slab of the in-launch tile pass BEHIND the shading slabs --
                              // the dispatch order in which the wait cannot be satisfied while the shading workgroups fill the chip
 };
@@ -244,6 +253,12 @@ struct ddx_engine {
     int probe_outcome = -1;  // ddx_engine_two_chains: the last answer of ensure_side_stream (-1: never asked)
     // the last run that ddx_engine_run_check has not yet seen clean, as it would have to be repeated (kind 0: none)
     struct { int kind = 0, it0 = 0, n = 0, use_graph = 0, sel_lo = 0; float* sel_out = nullptr; } last;
+    // the one-launch form of a run (run_kernel)
+    int run_kernel_on = 0;     // desc.one_launch_run / DDX_RUN_KERNEL=1: eligible runs take the one-launch form (default: launches -- measured faster)
+    bool run_kernel_off = false;  // a run in that form was void (ddx_engine_run_check): launches from then on
+    int run_resident = 0;      // run_kernel workgroups the chip holds at once (asked once); DDX_RUN_RESIDENT overrides
+    int run_team = 0;          // DDX_RUN_TEAM: workgroups per team (a power of two), 0 = from B and the residency
+    int run_form = 0;          // the form of the last run: 0 launches, 1 one launch (ddx_engine_run_form)
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
@@ -267,6 +282,25 @@ __device__ __forceinline__ int group_find(const GroupHdr& G, int g)  // the memb
     for (int i = 1; i < G.n; ++i) o += g >= G.bpre[i] ? 1 : 0;
     return o;
 }
+
+// ---- run_kernel's control block (see there)
+#define RUN_MAXT 128  // team slots per XCD (a workgroup whose ticket lies beyond them leaves at once)
+struct RunTeam {      // one 128-byte line per team
+    unsigned join;    // members so far | RUN_CLOSED once its first member has closed it undersized
+    unsigned size;    // 0 until the team is complete / closed, then its size
+    unsigned hyp;     // the hypothesis the team works on (>= B: none left), published before a team barrier
+    unsigned bar;     // arrivals at the team's barriers, monotonic over the launch
+    unsigned pad[28];
+};
+struct RunCtl {
+    unsigned xq[8][32];   // [x][0]: workgroups that have started on XCD x (their tickets)
+    unsigned hq[32];      // [0]: next hypothesis
+    unsigned exits[32];   // [0]: workgroups that have left
+    unsigned acc[32];     // [0] active tiles, [1] hypotheses outside the view volume, [2] large triangles -- of every hypothesis' last iteration
+    RunTeam team[8][RUN_MAXT];
+};
+#define RUN_CLOSED 0x10000u
+static inline size_t run_ctl_bytes() { return sizeof(RunCtl); }
 
 // meshlet geometry of the two step_kernel variants (triangles, vertex slots): dense = (2, 256), small = (1, 64) threads
 static inline void mesh_geometry(bool small_mesh, int& ntri, int& nvc)
@@ -299,6 +333,8 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_etmp = carve((size_t)7 * d.B * sizeof(float));
     const size_t o_rsnap = carve((size_t)21 * d.B * sizeof(float));
     const size_t o_inside = carve((size_t)d.B * sizeof(int));
+    const size_t o_rctl = carve(run_ctl_bytes());
+    const size_t o_fin = carve((size_t)d.B * 16 * sizeof(float));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_spart = carve(((size_t)d.H * d.W / 4096 + 1) * 40);  // SetupPart per chunk of SETUP_CHUNK = 4096 pixels
@@ -336,6 +372,8 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.eval_tmp = (float*)(p + o_etmp);
     E.run_snap = (float*)(p + o_rsnap);
     E.inside = (int*)(p + o_inside);
+    E.rctl = (struct RunCtl*)(p + o_rctl);
+    E.fin_mtx = (float*)(p + o_fin);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.setup_part = (struct SetupPart*)(p + o_spart);
@@ -610,6 +648,50 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// LOADS OF WHAT ANOTHER WORKGROUP OF THE SAME LAUNCH HAS WRITTEN (run_kernel, the one-launch form of a run: template argument
+// PERS).  A CU's vector L1 is never refreshed by another CU's stores, and a launch that lives for a whole run sees the same
+// addresses rewritten every iteration: such a load must be served by the XCD's L2 -- `sc1` (what a relaxed agent-scope atomic load
+// lowers to; the 16-byte form is two 8-byte ones).  The producers use plain stores (write-through to L2, the line stays there) and
+// agent-scope atomics, drained (s_waitcnt vmcnt(0)) before the team barrier; producer and consumer sit on ONE XCD by construction
+// (run_kernel forms its teams per XCC_ID), so nothing has to travel further than that L2: tools/ubench/persist_proto.hip checks
+// exactly this protocol word by word under uneven load with an L1-warm consumer (profiles/r5a_ubench_persist_proto.jsonl).
+// PERS = false: the plain load the kernels of the launch form have always used -- their code does not change.
+template <bool PERS, typename T>
+__device__ __forceinline__ T ldd(const T* p)
+{
+    if (PERS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool PERS>
+__device__ __forceinline__ float4 ldd4(const float* p)
+{
+    if (PERS) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+    }
+    return ld4(p);
+}
+template <bool PERS>
+__device__ __forceinline__ uint4 ldd4u(const unsigned* p)
+{
+    if (PERS) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
+// (a uniform value of that kind back into a scalar register: the plain form is a scalar load already)
+template <bool PERS>
+__device__ __forceinline__ float ldd_uniform(const float* p)
+{
+    if (PERS) return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+    return *p;
+}
+
 // decode candidate pair `desc` = pixel lane | kind << 6 of the quadrant at (qx,qy):
 // kind 0: (p, right)  1: (p, up)  2: (left, p)  3: (down, p).  h0/h1 = halo indices of pixel0 / pixel1.
 __device__ __forceinline__ void pair_decode(int desc, int& h0, int& h1, int& d)
@@ -637,17 +719,19 @@ struct AAUnit {
 
 // silhouette flags (bit k = edge k) of a triangle cut by the eye plane; out of line and with its own loads (L2 hits): the rare path
 // must not cost the mask role registers
+template <bool PERS = false>
 __device__ __attribute__((noinline)) static int aa_sil_straddler(const float* __restrict__ P, int v0, int v1, int v2, int o0, int o1, int o2)
 {
-    const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
+    const float4 p0 = ldd4<PERS>(P + (size_t)v0 * 4), p1 = ldd4<PERS>(P + (size_t)v1 * 4), p2 = ldd4<PERS>(P + (size_t)v2 * 4);
     const float D = aa_det3_xyw(p0, p1, p2);
     int m = 7;
-    if (o0 >= 0) { const float4 q = ld4(P + (size_t)o0 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p1, p2)) != sign_bit(D)) m &= ~1; }
-    if (o1 >= 0) { const float4 q = ld4(P + (size_t)o1 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p2, p0)) != sign_bit(D)) m &= ~2; }
-    if (o2 >= 0) { const float4 q = ld4(P + (size_t)o2 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p0, p1)) != sign_bit(D)) m &= ~4; }
+    if (o0 >= 0) { const float4 q = ldd4<PERS>(P + (size_t)o0 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p1, p2)) != sign_bit(D)) m &= ~1; }
+    if (o1 >= 0) { const float4 q = ldd4<PERS>(P + (size_t)o1 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p2, p0)) != sign_bit(D)) m &= ~2; }
+    if (o2 >= 0) { const float4 q = ldd4<PERS>(P + (size_t)o2 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p0, p1)) != sign_bit(D)) m &= ~4; }
     return m;
 }
 
+template <bool PERS = false>
 __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const int4* __restrict__ rec, const float* __restrict__ pos,
                                              int H, int W, int px, int py, int d, int t0, int t1, AAUnit& o)
 {
@@ -671,10 +755,19 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     float ps[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        p[i] = ld4(P + (size_t)vi[i] * 4);
-        q[i] = ld4(P + (size_t)(ov[i] >= 0 ? ov[i] : vi[i]) * 4);
+        p[i] = ldd4<PERS>(P + (size_t)vi[i] * 4);
+        q[i] = ldd4<PERS>(P + (size_t)(ov[i] >= 0 ? ov[i] : vi[i]) * 4);
         ps[i][0] = pos[(size_t)vi[i] * 3 + 0]; ps[i][1] = pos[(size_t)vi[i] * 3 + 1]; ps[i][2] = pos[(size_t)vi[i] * 3 + 2];
     }
+#ifdef DDX_EXP_AA_ONE_LEVEL
+    // (every component of the six vertices is wanted HERE: left alone the compiler narrows the 16-byte loads -- w first, for the
+    // eye-plane test, x y z behind it, the opposite vertices behind that -- into three dependent round trips)
+    asm volatile("" : "+v"(p[0].x), "+v"(p[0].y), "+v"(p[0].z), "+v"(p[0].w), "+v"(p[1].x), "+v"(p[1].y), "+v"(p[1].z), "+v"(p[1].w),
+                      "+v"(p[2].x), "+v"(p[2].y), "+v"(p[2].z), "+v"(p[2].w));
+    asm volatile("" : "+v"(q[0].x), "+v"(q[0].y), "+v"(q[0].z), "+v"(q[0].w), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[1].z), "+v"(q[1].w),
+                      "+v"(q[2].x), "+v"(q[2].y), "+v"(q[2].z), "+v"(q[2].w));
+    asm volatile("" : "+v"(ps[0][0]), "+v"(ps[0][1]), "+v"(ps[0][2]), "+v"(ps[1][0]), "+v"(ps[1][1]), "+v"(ps[1][2]), "+v"(ps[2][0]), "+v"(ps[2][1]), "+v"(ps[2][2]));
+#endif
     float x[3], y[3], ox[3], oy[3], iw[3];
     bool behind[3];
 #pragma unroll
@@ -707,7 +800,7 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     } else {
         // a triangle cut by the eye plane (oracle aa_eval_pair, raster_math.h aa_eval_pair): homogeneous orientation tests; only
         // the edges with both endpoints in front can be the crossed edge
-        const int m = aa_sil_straddler(P, vi[0], vi[1], vi[2], ov[0], ov[1], ov[2]);
+        const int m = aa_sil_straddler<PERS>(P, vi[0], vi[1], vi[2], ov[0], ov[1], ov[2]);
         sil[0] = (m & 1) != 0; sil[1] = (m & 2) != 0; sil[2] = (m & 4) != 0;
     }
     if (!(sil[0] || sil[1] || sil[2])) return;
@@ -775,6 +868,7 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
 // whose rank is sl mod S are this slice's: those numbered [win, win + SCAN_LIST) among them go to list[] (ty << 8 | tx); g_active
 // (nullable) receives the whole ordered list.  Returns the number of set flags of the row.  Kept out of line: inlined, its loop
 // nest around the shading loop cost the kernel 34 spilled registers.
+template <bool PERS = false>
 __device__ __attribute__((noinline)) static int tile_scan(const unsigned* __restrict__ frow, int n_dw, int S, int sl, float invS, int ntx, int win,
                                                           unsigned short* list, int* g_active)
 {
@@ -786,7 +880,7 @@ __device__ __attribute__((noinline)) static int tile_scan(const unsigned* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int di = d0 + u * 256 + lane * 4;
-            dd[u] = di < n_dw ? *reinterpret_cast<const uint4*>(frow + di) : make_uint4(0u, 0u, 0u, 0u);
+            dd[u] = di < n_dw ? ldd4u<PERS>(frow + di) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -841,7 +935,7 @@ struct TileWork {
     unsigned short* list;      // LDS, this wave's: tiles [win, win + SCAN_LIST) of the slice, ty << 8 | tx
 };
 
-template <int ROLE, bool WLUM /* edge build: the colour role also feeds the edge term */>
+template <int ROLE, bool WLUM /* edge build: the colour role also feeds the edge term */, bool PERS = false /* inside run_kernel: ldd */>
 __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict__ pool, const TileWork& tw)
 {
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
@@ -860,7 +954,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     if (ROLE == 0) {
         const float* Fm = E.mats + ((size_t)par * d.B + b) * 32 + 16;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { Fx[c] = Fm[c]; Fy[c] = Fm[4 + c]; Fw[c] = Fm[12 + c]; }
+        for (int c = 0; c < 4; ++c) { Fx[c] = ldd_uniform<PERS>(Fm + c); Fy[c] = ldd_uniform<PERS>(Fm + 4 + c); Fw[c] = ldd_uniform<PERS>(Fm + 12 + c); }
     }
     // every lane accumulates its pixels' terms over ALL the tiles of the workgroup; one wave reduction, one fold over the four
     // waves and one partial row per (slice, role) at the end (update_head sums min(slices, tiles) rows per role)
@@ -876,7 +970,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     for (int k = 0; k < n_mine; ++k) {
         if ((k & (SCAN_LIST - 1)) == 0 && k > 0) {  // further windows (a frame-filling object with few slices) on demand
             wave_lds_sync();
-            tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, k, tw.list, nullptr);
+            tile_scan<PERS>(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, k, tw.list, nullptr);
             wave_lds_sync();
         }
         const int txy8 = tw.list[k & (SCAN_LIST - 1)];
@@ -892,12 +986,19 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         const size_t pix = (size_t)py * W + px;
         if (px < W && py < H) { s0 = E.b.gt_seg[pix * 3 + 0]; s1 = E.b.gt_seg[pix * 3 + 1]; s2 = E.b.gt_seg[pix * 3 + 2]; }
+#ifdef DDX_EXP_GT_EARLY
+        float gte[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ROLE == 0 && px < W && py < H) {
+            if (d.use_rgb) { gte[0] = E.b.gt_rgb[pix * 3 + 0]; gte[1] = E.b.gt_rgb[pix * 3 + 1]; gte[2] = E.b.gt_rgb[pix * 3 + 2]; }
+            if (d.use_depth) gte[3] = E.b.gt_depth[pix];
+        }
+#endif
         int id;
         if (ROLE == 0) {
             // the colour / depth role only needs its own pixel: one zbuf entry per lane, no LDS staging
             id = -1;
             if (px < W && py < H) {
-                const unsigned long long key = zb[zaddr(px, py, L.zwb)];
+                const unsigned long long key = ldd<PERS>(zb + zaddr(px, py, L.zwb));
                 id = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
             }
             if (__ballot(id > 0) == 0ull) continue;  // nothing drawn in this quadrant: only background terms
@@ -912,7 +1013,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 const int gx = qx - 1 + e % QH, gy = qy - 1 + e / QH;
                 int v = -1;
                 if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
-                    const unsigned long long key = zb[zaddr(gx, gy, L.zwb)];
+                    const unsigned long long key = ldd<PERS>(zb + zaddr(gx, gy, L.zwb));
                     v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
                 }
                 ids[e] = v;
@@ -978,7 +1079,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 }
                 if (d.use_rgb) {
                     const float k = d.w_rgb * lrb * inv_b / (3.0f * (float)H * (float)W);
+#ifdef DDX_EXP_GT_EARLY
+                    const float gt[3] = {gte[0], gte[1], gte[2]}, sg[3] = {s0, s1, s2};
+#else
                     const float gt[3] = {E.b.gt_rgb[pix * 3 + 0], E.b.gt_rgb[pix * 3 + 1], E.b.gt_rgb[pix * 3 + 2]}, sg[3] = {s0, s1, s2};
+#endif
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float diff = (col[c] - gt[c]) * sg[c];
@@ -1012,7 +1117,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             if (d.use_depth) {
                 const float k = d.w_depth * lrb * inv_b / ((float)H * (float)W);
                 const float* M = E.mats + ((size_t)par * d.B + b) * 32;
-                const float m20 = M[8], m21 = M[9], m22 = M[10], m23 = M[11];
+                const float m20 = ldd_uniform<PERS>(M + 8), m21 = ldd_uniform<PERS>(M + 9), m22 = ldd_uniform<PERS>(M + 10), m23 = ldd_uniform<PERS>(M + 11);
                 const float gbx = __fmaf_rn(w2, x2, __fmaf_rn(v, x1, u * x0));
                 const float gby = __fmaf_rn(w2, y2, __fmaf_rn(v, y1, u * y0));
                 const float gbz = __fmaf_rn(w2, z2, __fmaf_rn(v, z1, u * z0));
@@ -1021,7 +1126,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 zc = __fmaf_rn(m22, gbz, zc);
                 zc = __fmaf_rn(m23, 1.0f, zc);
                 const float depth = -zc, dbg = -m23;
+#ifdef DDX_EXP_GT_EARLY
+                const float gtd = gte[3];
+#else
                 const float gtd = E.b.gt_depth[pix];
+#endif
                 const float diff = (depth - gtd) * s0, dbase = (dbg - gtd) * s0;
                 A.L[1] += fabsf(diff) - fabsf(dbase);
                 const float g = k * sgnf(diff) * s0;  // d loss / d depth
@@ -1072,7 +1181,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     int h0, h1, dd;
                     pair_decode(s_pairs[wave][j], h0, h1, dd);
                     const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
-                    aa_eval_unit(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
+                    aa_eval_unit<PERS>(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
                     if (pr.valid) {
                         const int ht = pr.target0 ? h0 : h1;
                         const int tx = ht % QH - 1, ty = ht / QH - 1;
@@ -1117,7 +1226,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                         pair_decode(s_pairs[wave][j], h0, h1, dd);
                         const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
                         AAUnit pr;
-                        aa_eval_unit(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
+                        aa_eval_unit<PERS>(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
                         if (pr.valid && !pr.clamped) {
                             const int ht = pr.target0 ? h0 : h1;
                             const int tx = ht % QH - 1, ty = ht / QH - 1;
@@ -1239,7 +1348,7 @@ __device__ __attribute__((noinline)) static void big_wait(int* arrive, int S, un
     __syncthreads();
 }
 
-template <bool EDGE>
+template <bool EDGE, bool PERS = false /* inside run_kernel: the iteration is named, the tile pass is the team's business, loads are ldd */>
 __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int S, int z, int it_arg)
 {
     // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's active tiles in ascending tile order.  There is no list kernel:
@@ -1261,7 +1370,7 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
     tw.b = b;
     const int it_cur = it_arg >= 0 ? it_arg : E.st->it_next - 1;  // the iteration being drawn (it_next is stable during this launch)
     tw.par = it_cur & 1;
-    if (z == 0 && sl == 0 && b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
+    if (!PERS && z == 0 && sl == 0 && b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
     tw.sl = sl;
     tw.S = S;
     tw.frow = reinterpret_cast<const unsigned*>(L.tile_flag + ((size_t)tw.par * E.d.B + tw.b) * L.NTp);
@@ -1272,16 +1381,16 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
     const int wg_id = (z * S + sl) * E.d.B + b;
     STAMP(E, 1, wg_id, 0);
     // (inline tile pass: the hypothesis' count of large triangles, requested before the scan and looked at after it)
-    const int n_big_list = E.big_inline ? __builtin_amdgcn_readfirstlane(L.bigcount[(size_t)tw.par * E.d.B + b]) : 0;
-    tw.n_flags = tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, 0, tw.list, lister ? L.active + (size_t)tw.b * L.NT : nullptr);
+    const int n_big_list = (!PERS && E.big_inline) ? __builtin_amdgcn_readfirstlane(L.bigcount[(size_t)tw.par * E.d.B + b]) : 0;
+    tw.n_flags = tile_scan<PERS>(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, 0, tw.list, lister ? L.active + (size_t)tw.b * L.NT : nullptr);
     tw.n_mine = tw.n_flags > tw.sl ? (tw.n_flags - tw.sl + tw.S - 1) / tw.S : 0;
     wave_lds_sync();
     if (lister && tw.sl == 0 && lane == 0) L.b_count[tw.b] = tw.n_flags;
     if (n_big_list > 0) big_wait(L.bigarrive + (size_t)tw.par * E.d.B + b, min(S, E.big_workers), E.wait_ticks, &E.st->flags);  // (workgroup-uniform; rare)
     STAMP(E, 1, wg_id, 1);
     const int role = z == 0 ? E.roles[0] : E.roles[1];
-    if (role == 0) shade_body<0, EDGE>(E, pool, tw);
-    else shade_body<1, EDGE>(E, pool, tw);
+    if (role == 0) shade_body<0, EDGE, PERS>(E, pool, tw);
+    else shade_body<1, EDGE, PERS>(E, pool, tw);
     STAMP(E, 1, wg_id, 2);
     STAMP(E, 1, wg_id, 3);
     if (tid == 0 && E.trace && wg_id < TRACE_WG) E.trace[((size_t)TRACE_WG + wg_id) * 8 + 4] = ((unsigned long long)z << 32) | (unsigned)tw.n_mine;
@@ -1495,7 +1604,7 @@ __global__ __launch_bounds__(256) void edge_group_kernel(const EngineDev* __rest
 // 64- and 256-thread variants of step_kernel produce the same bits.
 #define UPD_SLICES 8  // workgroups per hypothesis of finish_kernel; fewer for large batches (upd_slices())
 
-template <int NTH, bool SEL = false /* finish_kernel: the selection of ddx_engine_run_select is compiled in */>
+template <int NTH, bool SEL = false /* finish_kernel: the selection of ddx_engine_run_select is compiled in */, bool PERS = false /* inside run_kernel: ldd */>
 __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, int slice, int n_slices, float* snew, float* sc)
 {
     constexpr int NG = NTH / 32, NW = NTH / 64, NBK = 8 / NG;  // groups of 32 threads, waves, row buckets per thread
@@ -1511,7 +1620,13 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
     const int NT = E.L.NT;
     const int cur = j & 1;
     const int jj = tid % 32, grp = tid / 32;  // thread jj < NVALS of group g sums value jj of the rows of its buckets
-    const int n_act = E.L.b_count[b];
+#ifdef DDX_TRACE_HEAD
+#define HSTAMP(i) do { if (E.trace && tid == 0 && NTH == 256 && b * n_slices + slice < TRACE_WG) E.trace[((size_t)2 * TRACE_WG + b * n_slices + slice) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HSTAMP(i)
+#endif
+    HSTAMP(0);
+    const int n_act = ldd<PERS>(E.L.b_count + b);
     const int* tiles = E.L.active + (size_t)b * NT;
     // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the partial
     // rows (speculative: rows of slices beyond the tile count are stale and masked below), the first tile of the re-arm
@@ -1530,19 +1645,19 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
 #pragma unroll
         for (int u = 0; u < SPEC; ++u) {
             const int q = (grp + NG * i) + 8 * u;
-            v0[i][u] = (jj < NVALS && row_ok(q)) ? pbase[(size_t)q * NPART] : 0.f;
+            v0[i][u] = (jj < NVALS && row_ok(q)) ? ldd<PERS>(pbase + (size_t)q * NPART) : 0.f;
         }
-    const int txy_first = slice < NT ? tiles[slice] : 0;
+    const int txy_first = slice < NT ? ldd<PERS>(tiles + slice) : 0;
     const int ns = d.use_depth ? E.nseg : 0;  // (the size of the sorted seg list is known to the host since setup)
     const double segWn = E.seg_W[ns], segGn = E.seg_G[ns];
     // ---- the scalars of the tail, one per thread, into LDS: params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45
     float sc_val = 0.f;
-    if (tid < 7) sc_val = E.params2[((size_t)cur * 7 + tid) * B + b];
+    if (tid < 7) sc_val = ldd<PERS>(E.params2 + ((size_t)cur * 7 + tid) * B + b);
     else if (tid == 7) sc_val = E.b.lr_mult[b];
     else if (tid == 8) sc_val = E.b.lr_sched[j];
     else if (tid >= 16 && tid < 32) sc_val = E.b.proj[tid - 16];
-    else if (tid >= 32 && tid < 46) sc_val = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
-    const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
+    else if (tid >= 32 && tid < 46) sc_val = ldd<PERS>(E.adam + ((size_t)cur * 14 + (tid - 32)) * B + b);
+    const float dbg = -ldd<PERS>(E.mats + ((size_t)cur * B + b) * 32 + 11);
     // ---- partial sums, fixed order => bit-reproducible
     float acc[NBK];
     {
@@ -1559,13 +1674,14 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per row)
                         const int q = q1 + 8 * u;
-                        v[u] = (q < nlive && row_ok(q)) ? pbase[(size_t)q * NPART] : 0.f;
+                        v[u] = (q < nlive && row_ok(q)) ? ldd<PERS>(pbase + (size_t)q * NPART) : 0.f;
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) acc[i] += v[u];
                 }
         }
     }
+    HSTAMP(1);
     if (tid < 46) sc[tid] = sc_val;
     // ---- re-arm what iteration j dirtied (zbuf of its active tiles, their flags; parity j & 1) so that no pass needs a
     // memset: tile k of the hypothesis' list is re-armed by workgroup k % n_slices.  Independent of the sums.
@@ -1574,7 +1690,7 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
         unsigned char* flag = E.L.tile_flag + ((size_t)cur * B + b) * E.L.NTp;
         unsigned char* big = E.L.tile_big + ((size_t)cur * B + b) * E.L.NTp;
         for (int k = slice; k < n_act; k += n_slices) {  // (workgroup-uniform)
-            const int txy = k == slice ? txy_first : tiles[k];
+            const int txy = k == slice ? txy_first : ldd<PERS>(tiles + k);
             const int tx = txy & 0xffff, ty = txy >> 16;
             if (tid == 0) {
                 flag[ty * E.L.ntx + tx] = 0;
@@ -1597,13 +1713,9 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
             for (int i = 0; i < NBK; ++i) red[i % 4][lane] = acc[i];  // (NTH = 64: thread group g in {0,1} holds buckets g, g+2, g+4, g+6 = pairs 0..3)
         }
     }
-#ifdef DDX_TRACE_HEAD
-    if (E.trace && tid == 0 && blockDim.x == 256 && gridDim.z == 1) E.trace[((size_t)(b * n_slices + slice) % TRACE_WG) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-#endif
+    HSTAMP(2);
     __syncthreads();
-#ifdef DDX_TRACE_HEAD
-    if (E.trace && tid == 0 && blockDim.x == 256) E.trace[((size_t)(b * n_slices + slice) % TRACE_WG) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-#endif
+    HSTAMP(3);
     if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     // ---- whole-frame background depth term: sum_i w_i |dbg - g_i| and sum_i w_i sgn(dbg - g_i) (w = |seg0|, g = observed depth)
     // from the sorted list: k1 = #(g < dbg), k2 = #(g <= dbg) by a 64-way search per round on the last wave (no barrier), then
@@ -1635,6 +1747,7 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
         }
     }
     __syncthreads();
+    HSTAMP(4);
     const float bgsum = d.use_depth ? s_bg[0] : 0.f, bgder = d.use_depth ? s_bg[1] : 0.f;
     // ---- tail on wave 0, one lane per output where the work allows
     const bool writer = slice == 0;
@@ -1689,8 +1802,14 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
                     const int fl = __hip_atomic_load(&E.st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     E.sel_out[0] = fl ? __uint_as_float(0x7fc00000u) : best;
                     E.sel_out[1] = (float)(w + E.sel_lo);
-                    const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the step_kernel that drew it)
-                    for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
+                    if (PERS) {
+                        // (run_kernel: the winner's team may sit on another XCD -- its writer left the pose of the run's last iteration in
+                        // fin_mtx with system-scope stores, drained before it counted itself in sel_arrive)
+                        for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = __hip_atomic_load(E.fin_mtx + (size_t)w * 16 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else {
+                        const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the step_kernel that drew it)
+                        for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
+                    }
                     __hip_atomic_store(&E.st->sel_key, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&E.st->sel_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1750,8 +1869,8 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
                 E.b.params[(size_t)lane * B + b] = pnew;
             }
         }
-        if (writer && b == 0) {
-            // status of iteration j (single lanes across kernel boundaries, no atomics)
+        if (!PERS && writer && b == 0) {
+            // status of iteration j (single lanes across kernel boundaries, no atomics; run_kernel: its last workgroup, from accumulators)
             int tot = 0, out = 0;
             for (int i = lane; i < B; i += 64) {
                 tot += E.L.b_count[i];
@@ -1766,7 +1885,10 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
             }
         }
     }
+    HSTAMP(5);
     __syncthreads();
+    HSTAMP(6);
+#undef HSTAMP
 }
 
 // Meshlet geometry of a step_kernel instantiation: TPL triangles per thread, two vertex slots per thread.
@@ -1775,8 +1897,9 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
 // The chain of one iteration used to be four launches (transform+update, scatter, compaction, shade) with the clip-space
 // vertices and their window snap travelling through HBM in between; here the optimiser step, the transform and the scatter
 // rasteriser are one workgroup-local pipeline and the compaction is gone (shade_kernel scans the flags itself).
-template <int TPL, int NTH, int MODE, bool TAB = false /* balanced shares: the slot's meshlets come from the table, and the launch may record their times */>
-__device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int SL, int mode, int it_arg)
+template <int TPL, int NTH, int MODE, bool TAB = false /* balanced shares: the slot's meshlets come from the table, and the launch may record their times */,
+          bool PERS = false /* inside run_kernel: slot = member of the hypothesis' team, loads of the team's data are ldd */>
+__device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int SL, int mode, int it_arg, bool last_it = false)
 {
     constexpr int NTRI = TPL * NTH, NVC = 2 * NTH;
     const ddx_engine_desc& d = E.d;
@@ -1802,7 +1925,9 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     // the pose: the launch used to wait for the workgroups whose meshlets were all visible).  (Handing meshlets out through a
     // per-hypothesis ticket counter instead was built and measured: 64 hot words of returning device-scope atomics made every
     // workgroup slower -- head 5.1 -> 9.4 us, cfg2 44.4 -> 54 us per iteration.)
-    const int npw = (M + SL - 1) / SL, m_begin = slot * npw, m_end = min(M, m_begin + npw);
+    // (run_kernel: the team's members share the meshlets as evenly as the count allows -- 40 over 16: eight threes and eight twos)
+    const int npw = PERS ? M / SL + (slot < M % SL ? 1 : 0) : (M + SL - 1) / SL;
+    const int m_begin = PERS ? slot * (M / SL) + min(slot, M % SL) : slot * npw, m_end = min(M, m_begin + npw);
     const bool tabled = TAB && E.slot_table != 0;
     const int n_my = tabled ? (int)E.slot_cnt[slot] : max(0, m_end - m_begin), t_off = tabled ? (int)E.slot_off[slot] : 0;
     // (the slot's list goes to LDS once: indexing the kernel arguments inside the meshlet loop would put a scalar load and its wait,
@@ -1816,12 +1941,12 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
 #pragma unroll
     for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)m0 * NTRI + k * NTH + tid];
     if (mode == STEP_NORMAL) {
-        update_head<NTH>(E, b, it - 1, slot, SL, snew, sc);
+        update_head<NTH, false, PERS>(E, b, it - 1, slot, SL, snew, sc);
     } else {
         // first iteration of a run: the parameters as the caller holds them (un-normalised)
         if (tid < 7) snew[tid] = E.b.params[(size_t)tid * B + b];
         if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
-        if (mode == STEP_FIRST && slot == 0 && tid < 21) {  // what ddx_engine_run_check restores should this run have to be repeated (EngineDev::run_snap)
+        if (!PERS && mode == STEP_FIRST && slot == 0 && tid < 21) {  // what ddx_engine_run_check restores should this run have to be repeated (EngineDev::run_snap)
             E.run_snap[(size_t)tid * B + b] = tid < 7 ? E.b.params[(size_t)tid * B + b] : E.adam[((size_t)par * 14 + (tid - 7)) * B + b];
         }
         __syncthreads();
@@ -1855,6 +1980,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
                 dst[tid * 4 + c] = Mr[c];
                 dst[16 + tid * 4 + c] = Fr[c];
                 if (logm) logm[tid * 4 + c] = Mr[c];
+                if (PERS && last_it) __hip_atomic_store(E.fin_mtx + (size_t)b * 16 + tid * 4 + c, Mr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (update_head: the selection)
             }
         }
     }
@@ -1874,7 +2000,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
             E.inside[b] = inside_all ? 1 : 0;
             E.L.bigcount[(size_t)(1 - par) * B + b] = 0;  // the other parity's list of large triangles: consumed, nobody reads it now
             E.L.bigarrive[(size_t)(1 - par) * B + b] = 0;
-            if (b == 0) {
+            if (!PERS && b == 0) {  // (run_kernel: its teams are at different iterations; the launch's last workgroup leaves these words as a run of launches would)
                 E.L.counters[3 + (1 - par)] = 0;  // ... and its "a large triangle exists" word
                 E.st->it_next = it + 1;           // (read by big_pass / shade / edge of this iteration)
                 if (mode != STEP_NORMAL) E.st->it = it;
@@ -2000,6 +2126,239 @@ __global__ __launch_bounds__(256) void finish_group_kernel(const EngineDev* __re
 {
     const int o = group_find(G, blockIdx.y);
     finish_wg(tab[G.idx[o]], (int)blockIdx.y - G.bpre[o], blockIdx.x, gridDim.x, it_arg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// THE ONE-LAUNCH FORM OF A RUN (round 5).  ddx_engine_run(it0, n) as ONE kernel: the hypotheses are independent
+// (diffdope/diffdope.py:534-544, 1019-1026 -- a batch of poses optimised side by side), so nothing in the loop body
+// (diffdope.py:1656-1714) needs a grid-wide barrier, only the workgroups of ONE hypothesis have to meet between its rasterising
+// and its shading phase.  Per iteration the launch form pays two kernel prologues on a cold L2 (2 x 3.5 us), two kernel
+// boundaries (2 x 2.4 us) and the tail of two grids: 12-17 of cfg2's 40 us in which a hypothesis waits for
+// things that are not its own.
+//
+// Teams.  Every workgroup reads HW_REG_XCC_ID and takes a ticket from THAT XCD's counter; G consecutive tickets of an XCD form a
+// team -- its members share one L2 BY CONSTRUCTION, whatever the dispatcher did (HIP promises nothing about workgroup -> XCD
+// placement, MI355X_MICROARCH.md).  The first member to join a team waits until it is full or, after close_ticks, closes it with
+// whoever has arrived (a co-tenant on the chip, a grid larger than what is resident): every phase below is written for a team of
+// ANY size 1..G -- meshlets, shading units and re-arm shares are dealt out modulo the team size, and none of that reaches the
+// result (64-bit atomicMin, one partial row per (slice, role), idempotent flags) -- so placement and residency decide the speed
+// and nothing else.  A closed team takes hypotheses from one global queue until it is empty; per hypothesis it runs
+//     for every iteration:  step phase (step_wg: optimiser step of the iteration before, pose, meshlets -> zbuf)
+//                           team barrier
+//                           shade phase (shade_wg: the (slice, role) units of the launch form's grid, same slices => same bits)
+//                           team barrier
+//     the optimiser step of the last iteration (+ the selection of ddx_engine_run_select): update_head, as finish_kernel
+// What crosses a team barrier travels through the XCD's L2: plain stores and atomics, drained before the arrival; consumer loads
+// `sc1` (ldd<true>: a CU's L1 is never refreshed by another CU's stores).  No fence: no L2 write-back (the data never leaves the
+// XCD), no L1 invalidate (nothing stale-able is read through L1).  Protocol checked word by word under uneven load, L1-warm:
+// tools/ubench/persist_proto.hip.
+// EVERY SPIN IS BOUNDED (wait_ticks).  A wait that runs out sets ENGINE_FLAG_RUN_TIMEOUT; a hypothesis that turns out to have
+// large / near-clipped triangles (the teams do not run the tile pass: this form is only chosen where the set-up expects none)
+// sets ENGINE_FLAG_RUN_BIG.  Either way the launch still terminates, its numbers are void, ddx_engine_run_select's row says NaN,
+// and ddx_engine_run_check repeats the run in the launch form, for good.
+// The last workgroup to leave re-arms the control block (all zero between runs: no memset in front of a run) and leaves the
+// status words as a run of launches would.
+#define XCC_ID_REG ((3 << 11) | 20)  // hwreg(HW_REG_XCC_ID, 0, 4)
+
+// arrive at the team's barrier (its p-th: target = p * team size) and wait for the others; false = the budget ran out
+__device__ __forceinline__ bool team_barrier(unsigned* ctr, unsigned target, unsigned budget, int* flags, int wg_scope)
+{
+    __shared__ int s_ok;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every wave: its stores and atomics of the phase have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (the arrival is performed in the XCD's L2 either way; without sc1 -- workgroup scope -- the line stays there for the polls)
+        if (wg_scope) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)budget) { ok = false; break; }
+            } while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target);
+        }
+        if (!ok) __hip_atomic_fetch_or(flags, ENGINE_FLAG_RUN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// The phases are CALLS.  Inlined into the loops of run_kernel they handed the optimiser three loop nests to hoist address arithmetic
+// and kernel-argument loads out of: 189 spilled vector registers and three more holding spilled scalars, at 128 registers.  As
+// functions each phase is allocated on its own (the kernel's register count is their maximum), and the engine's description is read
+// where it lies -- at the head of run_kernel's argument segment (its FIRST parameter), through the constant address space, so its
+// fields arrive by scalar loads as in a kernel.  (The address travels as an argument -- the kernarg-pointer intrinsic is null inside a
+// callee -- and through v_readfirstlane: arguments arrive in vector registers, and loads through a "divergent" pointer would be
+// vector loads.)
+typedef const EngineDev __attribute__((address_space(4))) * EngineArgPtr;
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }  // (an argument every lane holds the same value of)
+__device__ __forceinline__ const EngineDev& run_engine(unsigned long long ek)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ek), hi = __builtin_amdgcn_readfirstlane((unsigned)(ek >> 32));
+    return *(const EngineDev*)(EngineArgPtr)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int MODE>
+__device__ __attribute__((noinline)) void run_step_phase(unsigned long long ek, int b, int k, int Gt, int mode, int it, int last_it)
+{
+    step_wg<2, 256, MODE, false, true>(run_engine(ek), uni(b), uni(k), uni(Gt), uni(mode), uni(it), uni(last_it) != 0);
+}
+
+__device__ __attribute__((noinline)) void run_shade_phase(unsigned long long ek, int b, int k, int Gt, int it)
+{
+    const EngineDev& E = run_engine(ek);
+    b = uni(b); k = uni(k); Gt = uni(Gt); it = uni(it);
+    const int S = E.s_shade, units = S * E.n_roles;
+    for (int u = k; u < units; u += Gt) {  // (workgroup-uniform) the (slice, role) units of the launch form's grid: z = 0 is roles[0]
+        shade_wg<false, true>(E, b, u % S, S, u / S, it);
+        __syncthreads();  // (the next unit reuses the body's LDS)
+    }
+}
+
+// the optimiser step of the run's last iteration, the selection, both parities clean (finish_wg), and this hypothesis' share of the
+// status words
+__device__ __attribute__((noinline)) void run_finish_phase(unsigned long long ek, int b, int k, int Gt, int itn)
+{
+    __shared__ float snew_f[8];
+    __shared__ float sc_f[64];
+    const EngineDev& E = run_engine(ek);
+    b = uni(b); k = uni(k); Gt = uni(Gt); itn = uni(itn);
+    const int B = E.d.B, par = itn & 1;
+    update_head<256, true, true>(E, b, itn - 1, k, Gt, snew_f, sc_f);
+    if (k == 0 && threadIdx.x == 0) {
+        RunCtl& C = *E.rctl;
+        const int nbig = ldd<true>(E.L.bigcount + (size_t)(1 - par) * B + b);
+        __hip_atomic_fetch_add(&C.acc[0], (unsigned)ldd<true>(E.L.b_count + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ldd<true>(E.inside + b) == 0) __hip_atomic_fetch_add(&C.acc[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nbig > 0) __hip_atomic_fetch_add(&C.acc[2], (unsigned)nbig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        E.L.bigcount[(size_t)(1 - par) * B + b] = 0;
+        E.L.bigarrive[(size_t)(1 - par) * B + b] = 0;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void run_kernel(EngineDev E /* must stay the first parameter: run_engine() */, int it0, int n, int G, int n_wg)
+{
+    __shared__ unsigned s_u[4];
+    const int tid = threadIdx.x;
+    const unsigned long long ek = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();  // &E
+    RunCtl& C = *E.rctl;
+    const int B = E.d.B;
+    int* flags = &E.st->flags;
+    // ---- join a team of this XCD
+    if (tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(XCC_ID_REG) & 7u;
+        unsigned team = ~0u, k = 0, size = 0;
+        // (a workgroup that starts when every hypothesis has been handed out -- a grid larger than what is resident -- only leaves)
+        if (__hip_atomic_load(&C.hq[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)B) {
+            const unsigned t = __hip_atomic_fetch_add(&C.xq[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            team = t / (unsigned)G;
+        }
+        if (team < RUN_MAXT) {
+            RunTeam& T = C.team[xcc][team];
+            const unsigned j = __hip_atomic_fetch_add(&T.join, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            if (j & RUN_CLOSED) {
+                team = ~0u;  // closed before this workgroup came: not a member
+            } else if (j == 0) {
+                // first member: until the team is full, or close it with whoever has arrived
+                unsigned v = 1;
+                while ((v = __hip_atomic_load(&T.join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned)G) {
+                    if ((E.dbg_run & 1) || __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)E.close_ticks) {
+                        v = __hip_atomic_fetch_or(&T.join, RUN_CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                size = min(v & 0xffffu, (unsigned)G);
+                if (!(E.dbg_run & 2)) __hip_atomic_store(&T.size, size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                k = 0;
+            } else {
+                k = j;
+                while ((size = __hip_atomic_load(&T.size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)E.wait_ticks) {
+                        __hip_atomic_fetch_or(flags, ENGINE_FLAG_RUN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        team = ~0u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        } else {
+            team = ~0u;
+        }
+        s_u[0] = team; s_u[1] = k; s_u[2] = size; s_u[3] = xcc;
+    }
+    __syncthreads();
+    const unsigned team = s_u[0];
+    const int k = (int)s_u[1], Gt = (int)s_u[2];
+    const unsigned xcc = s_u[3];
+    if (team != ~0u) {
+        RunTeam& T = C.team[xcc][team];
+        unsigned n_bar = 0;  // barriers of this team so far
+        bool dead = false;
+        while (!dead) {
+            // ---- the team's next hypothesis
+            if (k == 0 && tid == 0) {
+                const unsigned nb = __hip_atomic_fetch_add(&C.hq[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&T.hyp, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ++n_bar;
+            if (!team_barrier(&T.bar, n_bar * (unsigned)Gt, E.wait_ticks, flags, E.dbg_run & 4)) break;
+            const int b = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&T.hyp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (b >= B) break;
+            for (int i = 0; i < n; ++i) {
+                const int it = it0 + i;
+                run_step_phase<MODE>(ek, b, k, Gt, i == 0 ? STEP_FIRST : STEP_NORMAL, it, i == n - 1);
+                ++n_bar;
+                if (!team_barrier(&T.bar, n_bar * (unsigned)Gt, E.wait_ticks, flags, E.dbg_run & 4)) { dead = true; break; }
+                if (k == 0 && tid == 0 && ldd<true>(E.L.bigcount + (size_t)(it & 1) * B + b) > 0)
+                    __hip_atomic_fetch_or(flags, ENGINE_FLAG_RUN_BIG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run_shade_phase(ek, b, k, Gt, it);
+                ++n_bar;
+                if (!team_barrier(&T.bar, n_bar * (unsigned)Gt, E.wait_ticks, flags, E.dbg_run & 4)) { dead = true; break; }
+            }
+            if (dead) break;
+            run_finish_phase(ek, b, k, Gt, it0 + n);
+        }
+    }
+    // ---- leave; the last one re-arms the control block
+    __syncthreads();
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        s_u[0] = __hip_atomic_fetch_add(&C.exits[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_u[0] != (unsigned)n_wg - 1u) return;
+    if (tid == 0) {
+        E.st->last_active = (int)__hip_atomic_load(&C.acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        E.st->outside = (int)__hip_atomic_load(&C.acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        E.st->last_pairs = (int)__hip_atomic_load(&C.acc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        E.st->it = it0 + n;
+        E.st->it_next = it0 + n;
+        E.L.counters[3] = 0;
+        E.L.counters[4] = 0;
+        // a void run says so in band (ddx_engine_run_select: NaN, as after a timed-out tile pass) -- here the row may never have been
+        // written: workgroups that gave up did not reach the selection -- and leaves the selection words armed
+        if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            if (E.sel_out) E.sel_out[0] = __uint_as_float(0x7fc00000u);
+            __hip_atomic_store(&E.st->sel_key, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&E.st->sel_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    for (int x = 0; x < 8; ++x) {
+        const unsigned nt = min((unsigned)RUN_MAXT, (__hip_atomic_load(&C.xq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned)G - 1u) / (unsigned)G);
+        __syncthreads();  // (everybody has read the ticket count before it is zeroed)
+        for (unsigned i = tid; i < nt * 4u; i += 256u) __hip_atomic_store(&C.team[x][i >> 2].join + (i & 3u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&C.xq[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&C.hq[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&C.exits[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 3) __hip_atomic_store(&C.acc[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the tile pass for large / near-clipped triangles of the iteration being drawn (raster_dev.h big_pass_body); exits on one
@@ -2368,6 +2727,14 @@ extern "C" int ddx_engine_create(const ddx_engine_desc* desc, const ddx_engine_b
         if (const char* ov = getenv("DDX_BIG_WAIT_US")) E.wait_ticks = (unsigned)std::max(1, atoi(ov)) * 100u;
         E.dbg_reverse = 0;
         if (const char* ov = getenv("DDX_DEBUG_REVERSE_SLABS")) E.dbg_reverse = atoi(ov) != 0;
+        E.close_ticks = 5000u;  // 50 us: a grid that fits the chip starts within a microsecond
+        if (const char* ov = getenv("DDX_RUN_CLOSE_US")) E.close_ticks = (unsigned)std::max(0, atoi(ov)) * 100u;
+        E.dbg_run = 0;
+        if (const char* ov = getenv("DDX_DEBUG_RUN")) E.dbg_run = atoi(ov);
+        e->run_kernel_on = desc->one_launch_run ? 1 : 0;
+        if (const char* ov = getenv("DDX_RUN_KERNEL")) e->run_kernel_on = atoi(ov) != 0;
+        if (const char* ov = getenv("DDX_RUN_RESIDENT")) e->run_resident = std::max(1, atoi(ov));
+        if (const char* ov = getenv("DDX_RUN_TEAM")) e->run_team = std::max(0, atoi(ov));
         E.big_workers = 64;
         if (const char* ov = getenv("DDX_BIG_WORKERS")) E.big_workers = std::max(1, atoi(ov));
         E.scatter_mode = 0;
@@ -2463,6 +2830,7 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
 {
     EngineDev& E = e->dev;
     DDX_HIP(hipMemsetAsync(E.st, 0, sizeof(EngineState), s));
+    DDX_HIP(hipMemsetAsync(E.rctl, 0, run_ctl_bytes(), s));  // (run_kernel keeps it zero between runs)
     DDX_HIP(hipMemsetAsync(&E.st->sel_key, 0xFF, sizeof(unsigned long long), s));
     DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)2 * 14 * E.d.B * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // (both parities) kept zero by update_head afterwards
@@ -2940,6 +3308,74 @@ static int ensure_side_stream(ddx_engine* e, hipStream_t s, bool* usable)
     return 0;
 }
 
+// ---- the one-launch form of a run (run_kernel)
+// (one instantiation: the plain scatter variant.  The exchange / compacting variants keep 16-19 KB of LDS stages beside the shading
+// phase's 20 KB -- the sum, not the maximum: static LDS of different phases is not overlaid -- which leaves three workgroups per CU
+// instead of four; the variants are bit-identical, so a mesh that takes the compacting one as launches runs the plain one here)
+#define RUN_DISPATCH(CALL) \
+    do {                   \
+        CALL(0);           \
+    } while (0)
+
+static int run_capacity(ddx_engine* e)
+{
+    if (e->run_resident > 0) return e->run_resident;
+    int per_cu = 0, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+#define RUN_OCC(MODE) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, run_kernel<MODE>, 256, 0)
+    RUN_DISPATCH(RUN_OCC);
+#undef RUN_OCC
+    if (per_cu < 1) per_cu = 1;
+    e->run_resident = per_cu * cus;
+    return e->run_resident;
+}
+
+// workgroups per team: the largest power of two that lets every hypothesis have its team resident at once (at most 64: the team
+// slots hold a member index in 16 bits and the shading phase has at most 64 x 2 units); large batches get teams of one or two
+// that work through the queue
+static int run_team_size(ddx_engine* e)
+{
+    if (e->run_team > 0) { int g = 1; while (g * 2 <= std::min(e->run_team, 64)) g *= 2; return g; }
+    const int per = std::max(1, run_capacity(e) / e->dev.d.B);
+    int g = 1;
+    while (g * 2 <= std::min(per, 64)) g *= 2;
+    return g;
+}
+
+// Which runs take this form: the tile pass is expected to have nothing to do (big_inline: the set-up's estimate, as for the worker
+// slab), no edge term (its kernel would be a third phase: not built), the dense step variants, no trace, no graph, no capture.
+static bool run_kernel_possible(const ddx_engine* e)
+{
+    const EngineDev& E = e->dev;
+    return e->run_kernel_on > 0 && !e->run_kernel_off && E.big_inline && !E.d.use_edge && !e->small_mesh && (!E.trace || getenv("DDX_RUN_TRACE")) && E.scatter_mode != 2;
+}
+
+static int launch_run_kernel(ddx_engine* e, int it0, int n, hipStream_t s)
+{
+    RoctxRange rr("ddx.run_kernel");
+    EngineDev& E = e->dev;
+    const int G = run_team_size(e);
+    const int cap = run_capacity(e);
+    // one team per hypothesis if the chip holds them, whole teams per XCD if the dispatcher deals the workgroups out evenly
+    long long want = (long long)E.d.B * G;
+    want = (want + 8LL * G - 1) / (8LL * G) * (8LL * G);
+    int grid = (int)std::min<long long>(want, std::max(cap / (8 * G) * (8 * G), G));
+    if (const char* ov = getenv("DDX_RUN_GRID")) grid = std::max(1, atoi(ov));  // (tests: more workgroups than are resident, odd counts)
+    // what ddx_engine_run_check restores should the run be void: taken HERE, not by the kernel -- a team whose wait runs out may
+    // never have started its hypothesis (the launch form's first kernel always runs to its end)
+    {
+        const size_t Bn = (size_t)E.d.B;
+        DDX_HIP(hipMemcpyAsync(E.run_snap, E.b.params, 7 * Bn * sizeof(float), hipMemcpyDeviceToDevice, s));
+        DDX_HIP(hipMemcpyAsync(E.run_snap + 7 * Bn, E.adam + (size_t)(it0 & 1) * 14 * Bn, 14 * Bn * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+#define RUN_LAUNCH(MODE) run_kernel<MODE><<<grid, 256, 0, s>>>(E, it0, n, G, grid)
+    RUN_DISPATCH(RUN_LAUNCH);
+#undef RUN_LAUNCH
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream)
 {
     return engine_run_impl(e, it0, n, use_graph, stream, nullptr, 0);
@@ -2984,6 +3420,19 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         capturing = hipStreamIsCapturing(s, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
     }
+    if (run_kernel_possible(e) && !use_graph && !capturing) {
+        // the whole run -- first iteration, optimiser steps, selection -- as ONE launch (run_kernel)
+        e->dev.sel_out = sel_out;  // (the by-value copy of the arguments carries it)
+        e->dev.sel_lo = sel_lo;
+        const int rerr = launch_run_kernel(e, it0, n, s);
+        e->dev.sel_out = nullptr;
+        if (rerr) return rerr;
+        e->adam_parity = (it0 + n) & 1;
+        e->run_form = 1;
+        e->last.kind = 1; e->last.it0 = it0; e->last.n = n; e->last.use_graph = use_graph; e->last.sel_out = sel_out; e->last.sel_lo = sel_lo;
+        return 0;
+    }
+    e->run_form = 0;
     bool two = two_streams_possible(e) && !use_graph && !capturing && n >= two_streams_min_iters(e) && !e->dev.trace;
     if (two)  // (a caller stream this engine has not met yet is probed here, once: synchronises it)
         if (int err = ensure_side_stream(e, s, &two)) return err;
@@ -3083,12 +3532,31 @@ extern "C" int ddx_engine_run_check(ddx_engine* e, void* stream)
     if (!e->setup_done) return 0;
     int flags = 0;
     if (int err = read_flags(e, s, &flags)) return err;
-    if (!(flags & ENGINE_FLAG_INLINE_TIMEOUT)) {
+    if (!(flags & (ENGINE_FLAG_INLINE_TIMEOUT | ENGINE_FLAG_RUN_TIMEOUT | ENGINE_FLAG_RUN_BIG))) {
         e->last.kind = 0;  // (checked and clean: nothing to repeat, whatever times out later)
         return 0;
     }
-    if (getenv("DDX_DEBUG_INLINE")) fprintf(stderr, "ddx: the in-launch tile pass timed out (flags %d): separate launch from now on, repeating the run\n", flags);
-    if (int err = disable_inline(e, s)) return err;
+    if (getenv("DDX_DEBUG_INLINE")) fprintf(stderr, "ddx: a bounded in-kernel wait ran out / the one-launch run met a large triangle (flags %d): falling back, repeating the run\n", flags);
+    if (flags & (ENGINE_FLAG_RUN_TIMEOUT | ENGINE_FLAG_RUN_BIG)) {
+        // the one-launch form is off for this engine from now on; its control block may have been left mid-run
+        e->run_kernel_off = true;
+        if (flags & ENGINE_FLAG_RUN_TIMEOUT) {
+            // (workgroups that gave up left their hypotheses mid-iteration: everything a run expects clean, as the set-up leaves it)
+            EngineDev& E = e->dev;
+            DDX_HIP(hipMemsetAsync(E.rctl, 0, run_ctl_bytes(), s));
+            DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));
+            DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));
+            DDX_HIP(hipMemsetAsync(&E.st->sel_key, 0xFF, sizeof(unsigned long long), s));
+            DDX_HIP(hipMemsetAsync(&E.st->sel_arrive, 0, sizeof(int), s));
+        }
+        DDX_HIP(hipStreamSynchronize(s));
+        if (!(flags & ENGINE_FLAG_INLINE_TIMEOUT)) {
+            const int zero = 0;
+            DDX_HIP(hipMemcpy(&e->dev.st->flags, &zero, sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    if (flags & ENGINE_FLAG_INLINE_TIMEOUT)
+        if (int err = disable_inline(e, s)) return err;
     // (the flag is sticky: it may stem from the last run or from an evaluation behind it.  Repeating the run is right in both cases --
     // an evaluation changes nothing the run's result depends on -- and the caller repeats its evaluation when this returns 1)
     if (e->last.kind == 1) {
@@ -3255,6 +3723,8 @@ extern "C" int ddx_engine_cull_sign(ddx_engine* e) { return (e && e->setup_done)
 // the outcome of the two-stream probe (ensure_side_stream): 1 = a stream of the engine's runs beside the caller stream it met last,
 // long runs go out as two half-batch chains; 0 = probed, no such stream (or switched off): one chain; -1 = never probed (the engine
 // is not eligible: launches that fill the chip, tile pass as its own launch, B not a multiple of 16)
+extern "C" int ddx_engine_run_form(ddx_engine* e) { return e ? e->run_form : -1; }
+
 extern "C" int ddx_engine_two_chains(ddx_engine* e)
 {
     return e ? e->probe_outcome : -1;

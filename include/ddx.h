@@ -243,6 +243,18 @@ typedef struct ddx_engine_desc {
      * caller's stream only.  Environment DDX_TWO_STREAMS=0
      * has the same effect for every engine of the process; DDX_TWO_MIN=n forks every eligible run of n or more iterations. */
     int32_t single_stream;
+    /* 1: a run (ddx_engine_run / ddx_engine_run_select without graph replay, outside a capture) of an engine without the edge term,
+     * on a dense mesh (the 256-thread rasteriser variants) where the set-up expects no large triangle (see separate_big_pass), is
+     * ONE kernel launch: the hypotheses are independent, so each is advanced through all n iterations by a team of workgroups
+     * that meet at two team barriers per iteration -- no kernel boundary inside the run (engine.hip
+     * run_kernel).  Teams are formed per XCD from HW_REG_XCC_ID at run time and every phase works for any team size, so nothing is
+     * assumed about dispatch order, placement or residency; every wait is bounded (DDX_BIG_WAIT_US).  A wait that runs out sets
+     * bit 1 of status word 7, a hypothesis that has a large / near-clipped triangle after all sets bit 2; either way the launch
+     * terminates, its numbers are void (out18[0] = NaN) and ddx_engine_run_check repeats the run as launches, which this engine
+     * then keeps.  Same results as the launches, bit for bit.  0 (default): launches -- on MI355X they are the faster form at
+     * every batch size measured (cfg2: 38.4 against 53 us per iteration; profiles/r5b_run_kernel_*), which is why this form is an
+     * option and not the default.  Environment DDX_RUN_KERNEL=1 / 0 switches it for every engine of the process. */
+    int32_t one_launch_run;
 } ddx_engine_desc;
 
 typedef struct ddx_engine_buffers {
@@ -291,7 +303,8 @@ int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
  * loss never wins.  With out18 in mapped host memory the end of a run costs one kernel and one synchronisation. */
 int ddx_engine_run_select(ddx_engine* e, int it0, int n, int use_graph, int lo, float* out18, void* stream);
 /* The host half of every bounded in-kernel wait (at present: the tile pass inside the shading launch, separate_big_pass above).
- * Synchronises `stream` and reads status word 7.  0: the work enqueued so far is valid.  1: a wait of the last ddx_engine_run /
+ * Synchronises `stream` and reads status word 7 (bit 0: the in-launch tile pass; bits 1, 2: the one-launch run, one_launch_run
+ * above, which is then repeated as launches).  0: the work enqueued so far is valid.  1: a wait of the last ddx_engine_run /
  * ddx_engine_run_select ran out -- the engine has been switched to the separate tile-pass launch for good, parameters and
  * optimiser state have been put back to what that run started from (a snapshot its first kernel takes) and the run has been
  * repeated, same iterations, same out18, and has finished: its results are valid now, bit for bit those of an engine created
@@ -341,6 +354,8 @@ int ddx_engine_cull_sign(ddx_engine* e);
  * (a stream of the engine's was measured to run beside the caller's); 0 = probed and refused (streams sharing a hardware queue
  * take turns: one chain); -1 = not eligible or not probed yet. */
 int ddx_engine_two_chains(ddx_engine* e);
+/* The form the last run of this engine took: 1 = one launch (one_launch_run above), 0 = launches, -1 = NULL engine. */
+int ddx_engine_run_form(ddx_engine* e);
 /* The same object in a new frame (tracking): the caller has overwritten the contents of gt_rgb / gt_depth / gt_seg, params, lr_mult
  * and / or lr_sched IN PLACE (same buffers, same shapes); mesh, texture and projection are unchanged.  The next run / eval redoes
  * the observation half of the set-up only (frame constants, sorted segmentation list, optimiser state, iteration 0) and keeps the

@@ -1,5 +1,5 @@
 """Measurement tool: build a VARIANT of libddx.so (extra -D flags, or the sources of another checkout) next to the product library,
-as diffdope_amd/libddx_<name>.so.  A process picks it with DDX_LIB=<path> (diffdope_amd/_lib.py) -- experiments only; the product
+as tools/_variants/libddx_<name>.so (git-ignored; it travels to the GPU box).  A process picks it with DDX_LIB=<path> (diffdope_amd/_lib.py) -- experiments only; the product
 and the tests load diffdope_amd/libddx.so.
 usage: python tools/build_variant.py <name> [--src <checkout root>] [-DFLAG ...]"""
 import glob
@@ -35,7 +35,8 @@ def main():
         out, _ = p.communicate()
         if p.returncode != 0:
             raise SystemExit(f"hipcc failed for {s}:\n{out}")
-    lib = os.path.join(ROOT, "diffdope_amd", f"libddx_{name}.so")
+    os.makedirs(os.path.join(ROOT, "tools", "_variants"), exist_ok=True)
+    lib = os.path.join(ROOT, "tools", "_variants", f"libddx_{name}.so")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise SystemExit("link failed:\n" + r.stdout)
