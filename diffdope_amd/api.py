@@ -587,6 +587,19 @@ class DiffDope:
         if not isinstance(self.losses_values, _LossLog):  # (a caller replaced the log by a plain dict)
             log_, self.losses_values = self.losses_values, _LossLog()
             self.losses_values.update(log_)
+        cap = getattr(self, "_capture", None)
+        if cap is not None:
+            # (inside the captured iteration of run_optimization(graph=True): the row goes to a [iterations, B] device buffer at the
+            # row a device counter names -- a Python-side append would happen once, at capture time)
+            buf = cap["logs"].get(key)
+            if buf is None:
+                raise RuntimeError(f"run_optimization(graph=True): the loss functions logged '{key}' for the first time inside the captured "
+                                   "iteration (a key must appear in every iteration: the log buffers are laid out from the eager ones)")
+            buf.index_copy_(0, cap["it"], values.detach()[None])
+            return
+        shapes = getattr(self, "_log_shapes", None)
+        if shapes is not None:
+            shapes[key] = (tuple(values.shape), values.dtype)
         self.losses_values.add(key, values.detach().clone())
 
     # ---- rendering -------------------------------------------------------------------------------
@@ -672,11 +685,20 @@ class DiffDope:
         self._pending = (eng, params, weights, torch.cuda.current_stream())
         return eng
 
-    def run_optimization(self, fused=None, optimizer="sgd", global_batch=None, wait=True):
+    def run_optimization(self, fused=None, optimizer="sgd", global_batch=None, wait=True, graph=None):
         """diffdope.py:1634-1714.  fused=None picks the fused engine when every loss function is a built-in.
         wait=False (fused path only) enqueues the whole optimisation on the current stream and returns; call
         finish_optimization() to synchronise and fetch the results -- several objects can then run on one stream each
-        and fill each other's launch tails (bop.refine_frame)."""
+        and fill each other's launch tails (bop.refine_frame).
+        graph (op-by-op path, fused=False): the loop body -- Object3D.forward, the pose matrices, render_texture_batch, every loss
+        function, backward, the SGD step -- is ~60 framework launches per iteration and host-bound; with graph=True the first two
+        iterations run eagerly and the third is captured ONCE into a hipGraph that is replayed for the rest of this call (the learning
+        rate, the loss rows and the pose log are indexed by a device-side iteration counter inside the graph; the graph is destroyed
+        before the call returns).  A loss function must
+        then be capture-safe: tensor operations and ddope.add_loss_value only -- no .item() / .cpu(), and no Python-side state
+        that has to change every iteration (it would change once).  Default (None / False): eager, as the reference runs it.
+        Measured on cfg2 (64 hypotheses, 640x480, tools/bench_opbyop.py --api): 0.79-0.92 k it/s eager, 0.96-0.99 k captured over
+        101 iterations; no gain at 41 -- capture and instantiation cost about 15 ms per call."""
         self.losses_values = _LossLog()
         self.optimization_results = []
         self._refresh_gt()
@@ -690,7 +712,7 @@ class DiffDope:
             if wait:
                 self.finish_optimization()
         else:
-            self._run_autograd()
+            self._run_autograd(bool(graph))
 
     def finish_optimization(self):
         """Synchronise with a run_optimization(wait=False) and fetch its results (no-op otherwise)."""
@@ -754,26 +776,99 @@ class DiffDope:
         self.optimization_results = [_LazyResult(mtx[i], self._render_cpu) for i in range(mtx.shape[0])]
         self.last_engine = eng
 
-    def _run_autograd(self):
-        hp = self.cfg.hyperparameters
-        self.optimizer = torch.optim.SGD(self.object3d.parameters(), lr=hp.learning_rate_base)
-        for lr in self.lr_schedule():
+    def _iteration(self, lr):
+        """One pass of the loop body (diffdope.py:1656-1714).  `lr`: a Python float (eager: through torch.optim.SGD, as the reference
+        steps) or a one-element device tensor (captured: the same update p <- p - lr g written as tensor operations)."""
+        self.optimizer.zero_grad()
+        result = self.object3d()
+        mtx_gu = matrix_batch_44_from_position_quat(p=result["trans"], q=result["quat"])
+        self.renders = self._render(mtx_gu)
+        loss = torch.zeros(1, device=mtx_gu.device)
+        for loss_function in self.loss_functions:
+            l = loss_function(self)
+            if l is None:
+                continue
+            loss = loss + l
+        loss.backward()
+        if torch.is_tensor(lr):
+            with torch.no_grad():
+                for prm in self.object3d.parameters():
+                    if prm.grad is not None:
+                        prm.addcmul_(prm.grad, lr, value=-1.0)
+        else:
             for g in self.optimizer.param_groups:
                 g["lr"] = lr
-            self.optimizer.zero_grad()
-            result = self.object3d()
-            mtx_gu = matrix_batch_44_from_position_quat(p=result["trans"], q=result["quat"])
-            self.renders = self._render(mtx_gu)
-            entry = _LazyResult(mtx_gu.detach(), self._render_cpu)  # (copied to the host when read)
-            self.optimization_results.append(entry)
-            loss = torch.zeros(1, device=mtx_gu.device)
-            for loss_function in self.loss_functions:
-                l = loss_function(self)
-                if l is None:
-                    continue
-                loss = loss + l
-            loss.backward()
             self.optimizer.step()
+        return mtx_gu
+
+    def _run_autograd(self, graph=False):
+        hp = self.cfg.hyperparameters
+        self.optimizer = torch.optim.SGD(self.object3d.parameters(), lr=hp.learning_rate_base)
+        lrs = self.lr_schedule()
+        n_it = len(lrs)
+        if not graph or n_it <= 2:
+            for lr in lrs:
+                mtx_gu = self._iteration(lr)
+                self.optimization_results.append(_LazyResult(mtx_gu.detach(), self._render_cpu))  # (copied to the host when read)
+            return
+        # ---- two eager iterations (the allocator, the lazily built tables and the autograd nodes of the parameters settle) ON THE
+        # STREAM THE CAPTURE WILL USE -- an AccumulateGrad node made on another stream would synchronise with it inside the capture --,
+        # then the rest of the schedule as replays of ONE captured iteration
+        n_eager = 2
+        dev = self.object3d.qx.device
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        self.renders = None  # (an earlier run's autograd graph, made on another stream, goes with it)
+        self._log_shapes = {}
+        with torch.cuda.stream(side):
+            try:
+                for lr in lrs[:n_eager]:
+                    mtx_gu = self._iteration(lr)
+                    self.optimization_results.append(_LazyResult(mtx_gu.detach(), self._render_cpu))
+            finally:
+                shapes, self._log_shapes = self._log_shapes, None
+            # everything that outlives an iteration is allocated HERE, outside the capture: a tensor created inside it may be given
+            # the memory of a temporary freed earlier in the iteration, which every replay then scribbles over
+            cap = dict(n_it=n_it, it=torch.full((1,), n_eager, dtype=torch.long, device=dev),
+                       logs={k: torch.zeros((n_it,) + shp, dtype=dt, device=dev) for k, (shp, dt) in shapes.items()})
+            lr_table = torch.tensor(lrs, dtype=torch.float32, device=dev)
+            mtx_log = torch.zeros((n_it,) + tuple(mtx_gu.shape), dtype=mtx_gu.dtype, device=dev)
+            del mtx_gu
+            self.renders = None  # (the last autograd graph goes with it)
+        g = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)  # (the gradients become tensors of the graph's own pool)
+        self._capture = cap
+        try:
+            with torch.cuda.graph(g, stream=side):
+                mtx_gu = self._iteration(lr_table.index_select(0, cap["it"]))
+                mtx_log.index_copy_(0, cap["it"], mtx_gu.detach()[None])
+                cap["it"].add_(1)
+        finally:
+            self._capture = None
+        torch.cuda.current_stream().wait_stream(side)
+        # (nothing ran during the capture: the counter still names the first iteration to replay)
+        for _ in range(n_eager, n_it):
+            g.replay()
+        # The graph lives for this call only.  Results leave its buffers as copies, the last rendering (self.renders: tensors of the
+        # graph's pool) and the gradients go with it: a replay of a kept graph AFTER the caller had read the logs faulted on a device
+        # address in three of four orders of host-side operations tried (cfg2, 8 and 64 hypotheses; the same operations captured by
+        # hand in tools/bench_opbyop.py do not), and that is not understood -- so nothing is replayed once this call has returned.
+        torch.cuda.current_stream().synchronize()
+        mtx_rows = mtx_log[n_eager:].clone()
+        for i in range(n_it - n_eager):
+            self.optimization_results.append(_LazyResult(mtx_rows[i], self._render_cpu))
+        if not isinstance(self.losses_values, _LossLog):
+            log_, self.losses_values = self.losses_values, _LossLog()
+            self.losses_values.update(log_)
+        for key, buf in cap["logs"].items():
+            rows = buf[n_eager:].clone()
+            for i in range(n_it - n_eager):
+                self.losses_values.add(key, rows[i])
+        self.renders = None
+        self.optimizer.zero_grad(set_to_none=True)
+        del g
+        with torch.no_grad():  # (the reference leaves the last iteration's images in self.renders: rendered again, outside the graph)
+            self.renders = self._render(mtx_rows[-1])
 
     def cuda(self):
         self.object3d.cuda()

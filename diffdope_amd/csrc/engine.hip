@@ -759,15 +759,13 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
         q[i] = ldd4<PERS>(P + (size_t)(ov[i] >= 0 ? ov[i] : vi[i]) * 4);
         ps[i][0] = pos[(size_t)vi[i] * 3 + 0]; ps[i][1] = pos[(size_t)vi[i] * 3 + 1]; ps[i][2] = pos[(size_t)vi[i] * 3 + 2];
     }
-#ifdef DDX_EXP_AA_ONE_LEVEL
     // (every component of the six vertices is wanted HERE: left alone the compiler narrows the 16-byte loads -- w first, for the
-    // eye-plane test, x y z behind it, the opposite vertices behind that -- into three dependent round trips)
+    // eye-plane test, x y z behind it, the opposite vertices behind that -- into three dependent round trips; cfg2 38.25 -> 37.83 us)
     asm volatile("" : "+v"(p[0].x), "+v"(p[0].y), "+v"(p[0].z), "+v"(p[0].w), "+v"(p[1].x), "+v"(p[1].y), "+v"(p[1].z), "+v"(p[1].w),
                       "+v"(p[2].x), "+v"(p[2].y), "+v"(p[2].z), "+v"(p[2].w));
     asm volatile("" : "+v"(q[0].x), "+v"(q[0].y), "+v"(q[0].z), "+v"(q[0].w), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[1].z), "+v"(q[1].w),
                       "+v"(q[2].x), "+v"(q[2].y), "+v"(q[2].z), "+v"(q[2].w));
     asm volatile("" : "+v"(ps[0][0]), "+v"(ps[0][1]), "+v"(ps[0][2]), "+v"(ps[1][0]), "+v"(ps[1][1]), "+v"(ps[1][2]), "+v"(ps[2][0]), "+v"(ps[2][1]), "+v"(ps[2][2]));
-#endif
     float x[3], y[3], ox[3], oy[3], iw[3];
     bool behind[3];
 #pragma unroll
@@ -986,13 +984,6 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         const size_t pix = (size_t)py * W + px;
         if (px < W && py < H) { s0 = E.b.gt_seg[pix * 3 + 0]; s1 = E.b.gt_seg[pix * 3 + 1]; s2 = E.b.gt_seg[pix * 3 + 2]; }
-#ifdef DDX_EXP_GT_EARLY
-        float gte[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ROLE == 0 && px < W && py < H) {
-            if (d.use_rgb) { gte[0] = E.b.gt_rgb[pix * 3 + 0]; gte[1] = E.b.gt_rgb[pix * 3 + 1]; gte[2] = E.b.gt_rgb[pix * 3 + 2]; }
-            if (d.use_depth) gte[3] = E.b.gt_depth[pix];
-        }
-#endif
         int id;
         if (ROLE == 0) {
             // the colour / depth role only needs its own pixel: one zbuf entry per lane, no LDS staging
@@ -1079,11 +1070,9 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 }
                 if (d.use_rgb) {
                     const float k = d.w_rgb * lrb * inv_b / (3.0f * (float)H * (float)W);
-#ifdef DDX_EXP_GT_EARLY
-                    const float gt[3] = {gte[0], gte[1], gte[2]}, sg[3] = {s0, s1, s2};
-#else
+                    // (requested here, behind the texel record: asked for with the zbuf entry -- one dependent level less -- the three
+                    // values live across the whole chain and the role spills 14 registers instead of 10: 38.2 -> 39.0 us, measured)
                     const float gt[3] = {E.b.gt_rgb[pix * 3 + 0], E.b.gt_rgb[pix * 3 + 1], E.b.gt_rgb[pix * 3 + 2]}, sg[3] = {s0, s1, s2};
-#endif
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float diff = (col[c] - gt[c]) * sg[c];
@@ -1126,11 +1115,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 zc = __fmaf_rn(m22, gbz, zc);
                 zc = __fmaf_rn(m23, 1.0f, zc);
                 const float depth = -zc, dbg = -m23;
-#ifdef DDX_EXP_GT_EARLY
-                const float gtd = gte[3];
-#else
                 const float gtd = E.b.gt_depth[pix];
-#endif
                 const float diff = (depth - gtd) * s0, dbase = (dbg - gtd) * s0;
                 A.L[1] += fabsf(diff) - fabsf(dbase);
                 const float g = k * sgnf(diff) * s0;  // d loss / d depth

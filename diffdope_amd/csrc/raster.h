@@ -5,6 +5,11 @@
 
 #define RASTER_SMALL_PX 64    // bbox of at most this many pixel centres => resolved in scatter_kernel (16 / 32 / 64: midpoly 4.7k / 7.5k / 7.6k it/s, lowpoly 10.7k / 9.8k / 11.2k, cfg2 unchanged)
 #define RASTER_BIG_GRID 1024  // workgroups of the large-triangle pass
+// The row-restricted materialising path: the emit (raster.hip) writes the rows of a hypothesis' active tiles and EMIT_ROW_MARGIN
+// rows either side; an antialias workgroup (renderops.hip) that survives the row test reads its own AA_ROWS rows and the one above.
+#define AA_ROWS 4
+#define EMIT_ROW_MARGIN 8
+static_assert(EMIT_ROW_MARGIN >= AA_ROWS + 1, "the antialias blocks next to the active rows read rows the restricted emit must have written");
 
 struct RasterScratch {
     int* counters;            // [16]: 3 + parity = "a large triangle exists in this pass" (plain stores of 1)

@@ -211,7 +211,6 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------
 // emit nvdiffrast-style rast [B,H,W,4]
-#define EMIT_ROW_MARGIN 8  // rows emitted beyond the hypothesis' active rows in the restricted form (the antialias kernels read AA_ROWS + 1 rows per block)
 __global__ __launch_bounds__(256) void emit_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
                                                    int B, int H, int W, RasterScratch L, float* __restrict__ rast, int restrict_rows)
 {
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const float* __restrict__ pos
     if (restrict_rows) {  // (the fused materialising path: rows far from the hypothesis' active tiles are never read by its consumers)
         const int lo = (L.row_range[b * 2] - EMIT_ROW_MARGIN) * W, hi = (L.row_range[b * 2 + 1] + EMIT_ROW_MARGIN + 1) * W;
         const int p0 = blockIdx.x * 1024;
-        if (p0 + 1024 <= lo || p0 >= hi) return;  // (workgroup-uniform; lo > hi for a hypothesis that draws nothing)
+        if (p0 + 1024 <= lo || p0 >= hi) return;  // (workgroup-uniform; a hypothesis that draws nothing has the range (1, 0): rows 0 .. EMIT_ROW_MARGIN are emitted, as background)
     }
     unsigned long long keys[4];
 #pragma unroll

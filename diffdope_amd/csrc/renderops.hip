@@ -234,7 +234,6 @@ static __device__ __forceinline__ float coverage_of(const float4& r, int T)
     return __fmaf_rn(w2, 1.0f, __fmaf_rn(r.y, 1.0f, r.x * 1.0f));  // == gbuffer_fwd_kernel's cv
 }
 
-#define AA_ROWS 4
 #define AA_QUEUE 4096
 template <bool BWD, bool COVERAGE>
 __global__ __launch_bounds__(256) void antialias_kernel(const float* __restrict__ color, int C,

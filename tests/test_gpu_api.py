@@ -283,3 +283,46 @@ def test_pose_matrix_kernel_matches_the_reference_goldens():
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)
     assert pose._pose_matrix_func is not None
+
+
+def test_captured_iteration_of_the_op_by_op_path_equals_the_eager_loop():
+    """run_optimization(fused=False, graph=True): two eager iterations, then ONE captured iteration replayed for the rest of the
+    schedule (learning rate, loss rows and pose log indexed by a device-side counter inside the graph) -- against the eager loop
+    (diffdope/diffdope.py:1656-1714 as the reference runs it): losses per iteration, poses per iteration, final parameters, the
+    selected hypothesis and the images left in `renders`; with a user loss function in the list (capture-safe by declaration:
+    graph=True); and the same object again, after its logs have been read and host memory has churned."""
+    import diffdope_amd as dd
+
+    sc = make_scene(16, 20, 60, 80, B=1, dist=1.8)
+    B, nb = 4, 9
+
+    def my_loss(ddope):  # a user loss: silhouette area against the observed one
+        v = (ddope.renders["mask"].mean((1, 2, 3)) - ddope.gt_tensors["segmentation"].mean((1, 2, 3))).abs()
+        ddope.add_loss_value("area", v.detach())
+        return (v * ddope.learning_rates).mean() * 0.3
+
+    runs = {}
+    for graph in (False, True):
+        d = _ddope(sc, ("rgb", "depth", "mask"), B, nb=nb)
+        d.loss_functions.append(my_loss)
+        d.run_optimization(fused=False, graph=graph)
+        runs[graph] = d
+    a, b = runs[False], runs[True]
+    assert set(a.losses_values) == set(b.losses_values) == {"rgb", "depth", "mask_selection", "area"}
+    for k in a.losses_values:
+        assert tuple(b.losses_values[k].shape) == (nb + 1, B)
+        np.testing.assert_allclose(a.losses_values[k].numpy(), b.losses_values[k].numpy(), rtol=1e-5, atol=1e-7)
+    assert len(b.optimization_results) == nb + 1
+    for ra, rb in zip(a.optimization_results, b.optimization_results):
+        np.testing.assert_allclose(ra["mtx"].numpy(), rb["mtx"].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a.object3d.params_tensor().cpu().numpy(), b.object3d.params_tensor().cpu().numpy(), rtol=0, atol=1e-6)
+    assert int(a.get_argmin()) == int(b.get_argmin())
+    np.testing.assert_allclose(a.renders["rgb"].detach().cpu().numpy(), b.renders["rgb"].detach().cpu().numpy(), atol=1e-5)
+    # the same object again from its start pose (its logs have been read, host memory has churned): the same numbers
+    first = {k: v.clone() for k, v in b.losses_values.items()}
+    junk = [np.zeros(n) for n in (10, 1000, 100000)]
+    b.object3d.load_params_tensor(_ddope(sc, ("rgb",), B).object3d.params_tensor())
+    b.run_optimization(fused=False, graph=True)
+    assert len(b.optimization_results) == nb + 1 and len(junk) == 3
+    for k in first:
+        np.testing.assert_allclose(first[k].numpy(), b.losses_values[k].numpy(), rtol=1e-5, atol=1e-7)

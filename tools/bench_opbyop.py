@@ -96,9 +96,13 @@ if '--api' in sys.argv:
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
         print(f'{cfg}: DiffDope.run_optimization(fused=True), 100 iterations: {dt*1e3:.2f} ms per call')
         sys.exit(0)
-    d.run_optimization(fused=False)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    d.run_optimization(fused=False)
-    best = int(d.get_argmin())  # (reads the logs: the deferred host copies happen here)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (nb + 1)
-    print(f'{cfg}: DiffDope.run_optimization(fused=False) {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s (arg-min hypothesis {best})')
+    nb = int(os.environ.get('DDX_API_NB', nb))
+    d.cfg.hyperparameters.nb_iterations = nb
+    for label, kw_ in (('eager', dict(graph=False)), ('captured iteration', dict(graph=True))):
+        d.run_optimization(fused=False, **kw_)
+        for rep in ('second call', 'third call'):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            d.run_optimization(fused=False, **kw_)
+            best = int(d.get_argmin())  # (reads the logs: the deferred host copies happen here)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (nb + 1)
+            print(f'{cfg}: DiffDope.run_optimization(fused=False), {label}, {nb + 1} iterations, {rep}: {dt*1e3:.2f} ms/iteration = {1/dt:.0f} it/s (arg-min hypothesis {best})')
