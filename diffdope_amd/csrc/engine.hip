@@ -41,6 +41,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 #include <cstdio>
@@ -246,10 +247,8 @@ struct ddx_engine {
     int two_streams = 1;     // DDX_TWO_STREAMS: 1 = the iterations of a run after its first as two half-batch chains on two streams, 0 = never
     bool two_min_env = false;
     int two_min_iters = 16;  // ... for runs of at least this many iterations (DDX_TWO_MIN)
-    hipStream_t side = nullptr;  // ... the second stream, and the events that fork it from / join it to the caller's
+    hipStream_t side = nullptr;  // ... the second stream for the caller stream of the current run (the process-wide registry's: ensure_side_stream), and the events that fork it from / join it to the caller's
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_p[3] = {nullptr, nullptr, nullptr};       // (timing events of the probe below)
-    std::vector<std::pair<hipStream_t, bool>> side_checked;  // caller streams met so far: do kernels of `side` run beside theirs?
     int probe_outcome = -1;  // ddx_engine_two_chains: the last answer of ensure_side_stream (-1: never asked)
     // the last run that ddx_engine_run_check has not yet seen clean, as it would have to be repeated (kind 0: none)
     struct { int kind = 0, it0 = 0, n = 0, use_graph = 0, sel_lo = 0; float* sel_out = nullptr; } last;
@@ -836,6 +835,8 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     const float gr = -1.0f;
     const float D = yb - ya;
     const float r = __fdiv_rn(xa * yb - ya * xb, D);
+    // (one reciprocal and four multiplications instead of the four divisions: measured in round 5, 38.0 -> 38.1 us -- the role does not
+    // feel its divisions)
     const float g_xa = gr * yb / D, g_xb = gr * (-ya) / D;
     const float g_ya = gr * (r - xb) / D, g_yb = gr * (xa - r) / D;
     const float gX[2] = {d ? g_ya : g_xa, d ? g_yb : g_xb};
@@ -988,6 +989,9 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
         if (ROLE == 0) {
             // the colour / depth role only needs its own pixel: one zbuf entry per lane, no LDS staging
             id = -1;
+            // (requesting the NEXT tile's entry while this one is shaded -- one dependent level less per tile -- measured in round 5:
+            // cfg2 shade 18.2 -> 19.0 us, 4.7 % coverage 38.3 -> 40.0: 13 spilled registers instead of 10, and the other waves of the SIMD
+            // already cover the round trip)
             if (px < W && py < H) {
                 const unsigned long long key = ldd<PERS>(zb + zaddr(px, py, L.zwb));
                 id = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
@@ -1042,7 +1046,11 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     TexelSetup ts;
                     tex_setup(tu, tv, d.Th, d.Tw, ts);
                     // one 64-byte record = the whole 2x2 footprint (texq): (x0,y0) (x1,y0) (x0,y1) (x1,y1), rgb each
+#ifdef DDX_EXP_NO_TEXEL  // (leave-out measurement: every sample reads the SAME record -- an L1 hit -- instead of its own)
+                    const float4* Q = E.texq + ((size_t)(ts.y0 & 0) * d.Tw + (ts.x0 & 1)) * 4;
+#else
                     const float4* Q = E.texq + ((size_t)ts.y0 * d.Tw + ts.x0) * 4;
+#endif
                     const float4 q0 = Q[0], q1 = Q[1], q2 = Q[2];
                     const float t00[3] = {q0.x, q0.y, q0.z}, t10[3] = {q0.w, q1.x, q1.y}, t01[3] = {q1.z, q1.w, q2.x}, t11[3] = {q2.y, q2.z, q2.w};
                     const float ux = (a0x - a2x) * (float)d.Tw, uy = (a0y - a2y) * (float)d.Th;  // d(texel x, y) / du
@@ -3227,23 +3235,32 @@ static int two_streams_min_iters(const ddx_engine* e)
 // Nothing in the API tells; so: one 30-us single-wave kernel on each, started together, timed with events -- side by side they
 // end 38-41 us after the fork (the second stream starts 8-10 us late: its event wait), in turn after 70-85.  Synchronises both
 // streams (set-up time).
-static int side_runs_beside(ddx_engine* e, hipStream_t s, hipStream_t cand, bool* ok)
+// THE REGISTRY (round 5): the answer belongs to the pair (device, caller stream), not to an engine -- bop.refine_frame builds its
+// engines anew for every frame, and each used to create up to six streams and time three pairs of spin kernels at its set-up.
+// One entry per pair for the life of the process: the stream that was found to run beside the caller's (or none), handed to every
+// engine that meets that caller stream; engines on different caller streams (one object per stream) keep different second streams.
+struct SideEntry { int device; hipStream_t caller, side; bool ok; };
+static std::mutex g_side_mu;
+static std::vector<SideEntry> g_side;
+static hipEvent_t g_side_ev[3] = {nullptr, nullptr, nullptr};  // (timing events of the probe; used under g_side_mu)
+
+static int side_runs_beside(hipStream_t s, hipStream_t cand, bool* ok)
 {
-    if (!e->ev_p[0])
-        for (int i = 0; i < 3; ++i) DDX_HIP(hipEventCreate(&e->ev_p[i]));
+    if (!g_side_ev[0])
+        for (int i = 0; i < 3; ++i) DDX_HIP(hipEventCreate(&g_side_ev[i]));
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
-        DDX_HIP(hipEventRecord(e->ev_p[0], s));
-        DDX_HIP(hipStreamWaitEvent(cand, e->ev_p[0], 0));
+        DDX_HIP(hipEventRecord(g_side_ev[0], s));
+        DDX_HIP(hipStreamWaitEvent(cand, g_side_ev[0], 0));
         side_spin_kernel<<<1, 64, 0, s>>>(3000u);
         side_spin_kernel<<<1, 64, 0, cand>>>(3000u);
-        DDX_HIP(hipEventRecord(e->ev_p[1], s));
-        DDX_HIP(hipEventRecord(e->ev_p[2], cand));
-        DDX_HIP(hipEventSynchronize(e->ev_p[1]));
-        DDX_HIP(hipEventSynchronize(e->ev_p[2]));
+        DDX_HIP(hipEventRecord(g_side_ev[1], s));
+        DDX_HIP(hipEventRecord(g_side_ev[2], cand));
+        DDX_HIP(hipEventSynchronize(g_side_ev[1]));
+        DDX_HIP(hipEventSynchronize(g_side_ev[2]));
         float t1 = 0.f, t2 = 0.f;
-        DDX_HIP(hipEventElapsedTime(&t1, e->ev_p[0], e->ev_p[1]));
-        DDX_HIP(hipEventElapsedTime(&t2, e->ev_p[0], e->ev_p[2]));
+        DDX_HIP(hipEventElapsedTime(&t1, g_side_ev[0], g_side_ev[1]));
+        DDX_HIP(hipEventElapsedTime(&t2, g_side_ev[0], g_side_ev[2]));
         best = std::min(best, std::max(t1, t2));  // (the best of three: an unrelated launch in between must not fail a good pair)
     }
     *ok = best < 0.050f;  // ms
@@ -3251,18 +3268,23 @@ static int side_runs_beside(ddx_engine* e, hipStream_t s, hipStream_t cand, bool
     return 0;
 }
 
-// the engine's stream for caller stream `s`: created at the first call (up to 6 candidates until one runs beside `s`; none: this
-// engine keeps one chain), checked once against every other caller stream it meets
+// the second stream for caller stream `s`: looked up in the registry; searched for at the first call for that pair (up to 6
+// candidates until one runs beside `s`; none: runs on `s` keep one chain)
 static int ensure_side_stream(ddx_engine* e, hipStream_t s, bool* usable)
 {
     *usable = false;
-    for (const auto& pr : e->side_checked)
-        if (pr.first == s) { *usable = pr.second; return 0; }
-    bool ok = false;
-    if (!e->side) {
-        if (e->two_streams <= 0) return 0;
+    if (e->two_streams <= 0) return 0;
+    int dev = 0;
+    DDX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    const SideEntry* hit = nullptr;
+    for (const auto& en : g_side)
+        if (en.device == dev && en.caller == s) { hit = &en; break; }
+    if (!hit) {
+        SideEntry en{dev, s, nullptr, false};
         std::vector<hipStream_t> rejected;
         int err = 0;
+        bool ok = false;
         for (int attempt = 0; attempt < 6 && !ok && !err; ++attempt) {
             hipStream_t cand = nullptr;
             const hipError_t ce = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
@@ -3271,25 +3293,24 @@ static int ensure_side_stream(ddx_engine* e, hipStream_t s, bool* usable)
                 err = (int)ce;
                 break;
             }
-            err = side_runs_beside(e, s, cand, &ok);
-            if (!err && ok) e->side = cand;
+            err = side_runs_beside(s, cand, &ok);
+            if (!err && ok) en.side = cand;
             else rejected.push_back(cand);  // (kept until the search is over: a destroyed stream's queue slot would be handed out again)
         }
         for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
         if (err) return err;
-        if (!e->side) {
-            e->two_streams = 0;  // (no stream of this process runs beside the caller's: one chain)
-            e->probe_outcome = 0;
-            return 0;
-        }
+        en.ok = en.side != nullptr;
+        g_side.push_back(en);
+        hit = &g_side.back();
+    }
+    e->probe_outcome = hit->ok ? 1 : 0;
+    if (!hit->ok) return 0;
+    e->side = hit->side;  // (the registry's: never destroyed by an engine)
+    if (!e->ev_fork) {
         DDX_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         DDX_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-    } else {
-        if (int err = side_runs_beside(e, s, e->side, &ok)) return err;
     }
-    e->side_checked.push_back(std::make_pair(s, ok));
-    e->probe_outcome = ok ? 1 : 0;
-    *usable = ok;
+    *usable = true;
     return 0;
 }
 
@@ -3990,11 +4011,8 @@ extern "C" void ddx_engine_destroy(ddx_engine* e)
     if (e->dev.trace) (void)hipFree(e->dev.trace);
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
-    if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    for (int i = 0; i < 3; ++i)
-        if (e->ev_p[i]) (void)hipEventDestroy(e->ev_p[i]);
     delete e;
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
-# final measurement session of the round: everything profiles/r4c_* is made of (r4b: the same before the two-stream runs)
+# final measurement session of the round: everything profiles/r5c_* is made of (run on the GPU box through gpurun)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-T=r4c
+T=${1:-r5c}
 O=gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/${T}_pytest_gpu.log 2>&1; tail -3 $O/${T}_pytest_gpu.log
@@ -15,11 +15,12 @@ timeout 900 bash tools/pmc_passes.sh $T cfg2_d3.75 --distance 3.75 > $O/${T}_pmc
 timeout 900 bash tools/pmc_passes.sh $T cfg3_d7.5 --config cfg3 > $O/${T}_pmc_cfg3.log 2>&1
 timeout 900 bash tools/pmc_passes.sh $T cfg4_gb512 --config cfg4 --global-batch 512 > $O/${T}_pmc_cfg4sat.log 2>&1
 for k in cfg2_d7.5 cfg2_d3.75 cfg3_d7.5 cfg4_gb512; do python profiles/summarize_sq.py $T $k > $O/${T}_pmc_sq_$k.json 2>>$O/${T}_summ.err; done
-python - <<'PY'
-import json
+T=$T python - <<'PY'
+import json, os
+T = os.environ["T"]
 for k in ("cfg2_d7.5", "cfg2_d3.75", "cfg3_d7.5", "cfg4_gb512"):
     try:
-        d = json.load(open(f"gpurun_out/r4c_pmc_sq_{k}.json"))
+        d = json.load(open(f"gpurun_out/{T}_pmc_sq_{k}.json"))
         for n, v in d["kernels"].items():
             print(k, n[:40], {x: (round(v[x], 3) if isinstance(v.get(x), float) else v.get(x)) for x in ("avg_ns_unprofiled", "valu_issue_frac", "hbm_bytes_per_launch", "hbm_frac_of_peak", "l2_hit_rate", "SQ_WAVES")},
                   "wait", round(v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1), 3), "ldsconf", round(v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3))
@@ -27,16 +28,13 @@ for k in ("cfg2_d7.5", "cfg2_d3.75", "cfg3_d7.5", "cfg4_gb512"):
         print(k, "ERR", e)
 PY
 timeout 600 bash tools/mfma_pass.sh $T > $O/${T}_mfma_util.json 2>$O/${T}_mfma.err
-timeout 60 tools/ubench/_build/store_rate > $O/${T}_ubench_store_rate.jsonl
 timeout 120 python tools/launch_sync_cost.py 2>/dev/null | tail -6 > $O/${T}_launch_sync_cost.txt; cat $O/${T}_launch_sync_cost.txt
 timeout 120 python tools/fixed_cost.py 2>/dev/null | tail -9 > $O/${T}_fixed_cost.txt; cat $O/${T}_fixed_cost.txt
-timeout 200 python tools/ramp_probe.py cfg2 2>&1 | grep "^cfg" > $O/${T}_ramp_probe.log; timeout 200 python tools/ramp_probe.py cfg4 2>&1 | grep "^cfg" >> $O/${T}_ramp_probe.log; cat $O/${T}_ramp_probe.log
-for c in cfg2 cfg4 cfg5 cfg50k64; do timeout 200 python tools/two_stream_threshold.py $c 2>&1 | grep "^cfg"; done > $O/${T}_two_stream_threshold.log; cat $O/${T}_two_stream_threshold.log
-DDX_LIB=/root/repo/diffdope_amd/libddx_exp.so timeout 600 python tools/experiments/exp_stagger.py cfg2 > $O/${T}_exp_stagger_cfg2.log 2>&1; cat $O/${T}_exp_stagger_cfg2.log
-timeout 120 tools/experiments/_build/scratch_probe > $O/${T}_scratch_probe.log 2>&1; tail -3 $O/${T}_scratch_probe.log
-DDX_TRACE=1 timeout 120 python tools/trace_kernels.py > $O/${T}_trace_cfg2.log 2>&1; cat $O/${T}_trace_cfg2.log
+DDX_TRACE=1 DDX_TWO_STREAMS=0 timeout 120 python tools/trace_kernels.py > $O/${T}_trace_cfg2.log 2>&1; cat $O/${T}_trace_cfg2.log
 timeout 300 python tools/large_batch.py > $O/${T}_large_batch.log 2>&1; cat $O/${T}_large_batch.log
 timeout 300 python tools/multi_object_streams.py cfg5 > $O/${T}_multi_object_cfg5.log 2>&1; cat $O/${T}_multi_object_cfg5.log
-timeout 300 python tools/multi_object_streams.py cfg2 > $O/${T}_multi_object_cfg2.log 2>&1; cat $O/${T}_multi_object_cfg2.log
-timeout 300 python tools/bench_opbyop.py cfg2 --api --graph > $O/${T}_opbyop.txt 2>&1; cat $O/${T}_opbyop.txt
+timeout 600 python tools/run_kernel_check.py --configs cfg2,cfg4,cfg50k64 --iters 20 > $O/${T}_run_kernel_check.log 2>&1; cat $O/${T}_run_kernel_check.log | cut -c1-200,560-900
+DDX_API_NB=100 timeout 300 python tools/bench_opbyop.py cfg2 --api --graph > $O/${T}_opbyop.txt 2>&1; cat $O/${T}_opbyop.txt
+timeout 900 python tools/cull_sweep.py 1000 0 > $O/${T}_cull_sweep.json 2>$O/${T}_cull_sweep.err; cat $O/${T}_cull_sweep.json
+timeout 2400 bash tools/final_fuzz.sh $T 30 > /dev/null 2>&1; cat $O/${T}_fuzz_final.log
 echo FINAL DONE
