@@ -740,19 +740,23 @@ class DiffDope:
         mesh_t = [r["pos"], r["pos_idx"], self.camera.cam_proj] + list(tex.values())
         sig = (tuple(_buffer_key(t) for t in mesh_t), tuple(self.resolution), self.batchsize, tuple(sorted(weights.items())), optimizer,
                global_batch, len(self.lr_schedule()), tuple(sorted((k, tuple(v.shape)) for k, v in gt.items())), shade_slices, edge_slices,
-               bool(self.cfg.hyperparameters.get("cull_backfaces", True)), self.cfg.hyperparameters.get("compat"), bool(separate_big_pass))
+               bool(self.cfg.hyperparameters.get("cull_backfaces", False)), self.cfg.hyperparameters.get("compat"), bool(separate_big_pass))
         cached = getattr(self, "_engine_cache", None)
         if cached is not None and cached[0] == sig and getattr(self, "_pending", None) is None:
             eng = cached[1]
             eng.new_observation(gt=gt, params=params, lr_mult=self.learning_rates, lr_sched=self.lr_schedule())
             params = eng.params
         else:
-            # cfg.hyperparameters.cull_backfaces (default True: deviation D5, invisible in exact arithmetic) and .compat (default None;
-            # "nvdiffrast": deviation D2 switched to nvdiffrast's rule) reach the engine from the config
+            # cfg.hyperparameters.cull_backfaces and .compat reach the engine from the config.  THIS API draws both faces of every
+            # triangle unless asked, as dr.rasterize does (diffdope.py:198-200): skipping the back faces of a closed mesh (deviation
+            # D5, RefineEngine's own default: +9 % on cfg2) is invisible in exact arithmetic, but in float32 a back-facing sliver on
+            # the silhouette can win a pixel -- tools/cull_sweep.py: 1 351 of 8 000 random hypotheses differ in some bit of their
+            # losses or gradient between the two rules (profiles/r5c_cull_sweep.json).  .compat default None; "nvdiffrast": deviation
+            # D2 switched to nvdiffrast's rule
             hp = self.cfg.hyperparameters
             eng = RefineEngine(r["pos"][0], r["pos_idx"][0], self.camera.cam_proj[0], self.resolution, gt, params, self.learning_rates,
                                self.lr_schedule(), weights, optimizer=optimizer, global_batch=global_batch, shade_slices=shade_slices,
-                               edge_slices=edge_slices, cull_backfaces=bool(hp.get("cull_backfaces", True)), compat=hp.get("compat"),
+                               edge_slices=edge_slices, cull_backfaces=bool(hp.get("cull_backfaces", False)), compat=hp.get("compat"),
                                separate_big_pass=separate_big_pass, **tex)
             self._engine_cache = (sig, eng, mesh_t)  # (mesh_t: keeps the keyed buffers alive, see render._buffer_key)
         return eng, params, weights

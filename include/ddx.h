@@ -235,11 +235,12 @@ typedef struct ddx_engine_desc {
     /* 0 (default): ddx_engine_run / ddx_engine_run_select may issue a run of 16 or more iterations (48 or more for larger step
      * launches; never above 7 000 meshlet-hypothesis pairs, where one launch fills the chip; no graph replay, no capture in
      * progress, tile pass inside the shading launch, B a multiple of 16) as two chains of half-batch launches: one on the
-     * caller's stream, one on a stream the engine owns, forked from the caller's stream after the first iteration and joined to
+     * caller's stream, one on a second stream of the library, forked from the caller's stream after the first iteration and joined to
      * it before the run's last kernel -- so everything the call enqueues is still ordered on `stream` as far as the caller can
-     * see, and the results are the same bit for bit.  The set-up checks with two 30-us kernels that the engine's stream really
-     * runs beside the caller's (streams that share a hardware queue take turns) and keeps one chain if no such stream can be
-     * had; a caller stream the engine meets later is checked at its first long run (synchronises it once).  1: one chain on the
+     * see, and the results are the same bit for bit.  The second stream comes from a process-wide registry keyed by (device,
+     * caller stream): the first engine that needs one for a caller stream checks with two 30-us kernels that a candidate really
+     * runs beside it (streams that share a hardware queue take turns), tries up to six, and records the answer -- one chain if
+     * none can be had -- for every later engine on that stream (synchronises the caller's stream, once per process and stream).  1: one chain on the
      * caller's stream only.  Environment DDX_TWO_STREAMS=0
      * has the same effect for every engine of the process; DDX_TWO_MIN=n forks every eligible run of n or more iterations. */
     int32_t single_stream;

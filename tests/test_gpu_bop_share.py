@@ -126,7 +126,7 @@ def test_config5_share_four_objects_64_hypotheses_1280x720(tmp_path, H, W, rows,
         wts = dict(rgb=lw.weight_rgb if lw.l1_rgb_with_mask else None, depth=lw.weight_depth if lw.l1_depth_with_mask else None,
                    mask=lw.weight_mask if lw.l1_mask else None, edge=lw.get("weight_edge", 1.0) if lw.get("l1_edge", False) else None)
         R = orc.RenderOracle(npy(r["pos"][0]), npy(r["pos_idx"][0]), npy(seq.camera.cam_proj[0]), H, W, {k: npy(v[0]) for k, v in seq.gt_tensors.items()},
-                             wts, dtype=np.float32, cull_backfaces=True, uv=npy(r["uv"][0]), tex=npy(r["tex"][0]))
+                             wts, dtype=np.float32, cull_backfaces=not e.desc.no_backface_cull, uv=npy(r["uv"][0]), tex=npy(r["tex"][0]))
         pn, ln = npy(p), npy(lrm)
         for b in (0, B // 2):
             total, logs, g_ref, _ = R.loss_and_grad(pn[:, b:b + 1], ln[b:b + 1], global_B=B)

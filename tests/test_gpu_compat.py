@@ -102,7 +102,8 @@ def test_engine_and_gbuffer_with_compat_match_the_oracle_with_compat(nvdiffrast_
 
 
 def test_diffdope_cfg_reaches_the_culling_and_compat_switches():
-    """cfg.hyperparameters.cull_backfaces / .compat (D5 / D2 from the config)."""
+    """cfg.hyperparameters.cull_backfaces / .compat (D5 / D2 from the config).  The DiffDope API draws both faces by default, like
+    dr.rasterize (round 5); culling is RefineEngine's own default and an option here."""
     import diffdope_amd as dd
     from diffdope_amd import synthetic as syn
 
@@ -112,7 +113,7 @@ def test_diffdope_cfg_reaches_the_culling_and_compat_switches():
     cam = dd.Camera(**syn.camera_intrinsics(W, H))
     seg = torch.zeros(H, W, 3)
     seg[20:40, 30:50] = 1.0
-    for hp_extra, want_cull, want_compat in ((dict(), True, 0), (dict(cull_backfaces=False), False, 0), (dict(compat="nvdiffrast"), True, 1)):
+    for hp_extra, want_cull, want_compat in ((dict(), False, 0), (dict(cull_backfaces=True), True, 0), (dict(compat="nvdiffrast"), False, 1)):
         cfg = dict(losses=dict(l1_rgb_with_mask=False, weight_rgb=0.7, l1_depth_with_mask=False, weight_depth=1.0, l1_mask=True, weight_mask=1.0),
                    hyperparameters=dict(nb_iterations=2, batchsize=2, base_lr=0.1, learning_rates_bound=[0.5, 3.0], learning_rate_base=1,
                                         lr_decay=0.1, seed=2, **hp_extra))
