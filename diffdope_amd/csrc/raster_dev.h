@@ -86,9 +86,17 @@ __device__ __forceinline__ scatter_mask_t small_mask(const int2& a, const int2& 
 __device__ __forceinline__ void walk_mask(scatter_mask_t mask, int px0, int py0, int nxp, const float4& p0, const float4& p1, const float4& p2,
                                           int t, const ScatterTarget& S)
 {
-    const float rn = __frcp_rn((float)nxp);
+    // (k + 0.5) / nxp lies at least 0.5 / nxp >= 2^-7 away from every integer and is below 64: the hardware reciprocal (1 ulp) and
+    // one rounded product cannot carry it across one -- the same j as with the correctly rounded reciprocal, eleven instructions less
+    // per triangle; k from the two 32-bit halves: (float) of a 64-bit bit index was a six-instruction u64 -> f32 conversion)
+    const float rn = __builtin_amdgcn_rcpf((float)nxp);
     while (mask) {
-        const int k = RASTER_SMALL_PX > 32 ? __ffsll((long long)mask) - 1 : __ffs((unsigned)mask) - 1;
+#if RASTER_SMALL_PX > 32
+        const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+        const int k = mlo ? __ffs(mlo) - 1 : 31 + __ffs(mhi);
+#else
+        const int k = __ffs((unsigned)mask) - 1;
+#endif
         mask &= mask - 1;
         const int j = (int)(((float)k + 0.5f) * rn), i = k - __mul24(j, nxp);  // k = j * nxp + i, exact for k < 64
         float zw;
@@ -347,7 +355,7 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
                     const int kb = select_bit(s_mask[wv][Lo], f - s_pref[wv][Lo]);
                     const float4 p0 = s_rec[wv][Lo][0], p1 = s_rec[wv][Lo][1], p2 = s_rec[wv][Lo][2], q = s_rec[wv][Lo][3];
                     const int px0 = __float_as_int(q.x), py0 = __float_as_int(q.y), nxp = __float_as_int(q.z), tid_ = __float_as_int(q.w);
-                    const int j = (int)(((float)kb + 0.5f) * __frcp_rn((float)nxp)), i = kb - __mul24(j, nxp);  // kb = j * nxp + i, exact for kb < 64
+                    const int j = (int)(((float)kb + 0.5f) * __builtin_amdgcn_rcpf((float)nxp)), i = kb - __mul24(j, nxp);  // kb = j * nxp + i, exact for kb < 64 (walk_mask)
                     float zw;
                     const float fx = __fmaf_rn((float)(px0 + i), S.ndc.xs, S.ndc.xo), fy = __fmaf_rn((float)(py0 + j), S.ndc.ys, S.ndc.yo);
                     if (pixel_depth(p0, p1, p2, fx, fy, zw))
