@@ -110,10 +110,16 @@ __device__ __forceinline__ void walk_mask(scatter_mask_t mask, int px0, int py0,
 // bbox need not be covered).  (The usual trip count is 1 x 1: keep the compiler from unrolling / vectorising these loops.)
 __device__ __forceinline__ void flag_tiles(unsigned char* flag, int ntx, int tx0, int ty0, int tx1, int ty1)
 {
+    // (the usual range is ONE tile: its store goes out without loop bookkeeping -- the two nested loops cost the wave a dozen scalar
+    // instructions for a single trip --, and the loops run only for a lane whose range is larger; a second store of the first tile is
+    // the same byte)
+    flag[__mul24(ty0, ntx) + tx0] = 1;  // plain store, no atomics
+    if (tx1 > tx0 || ty1 > ty0) {
 #pragma clang loop unroll(disable) vectorize(disable)
-    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int ty = ty0; ty <= ty1; ++ty)
 #pragma clang loop unroll(disable) vectorize(disable)
-        for (int tx = tx0; tx <= tx1; ++tx) flag[__mul24(ty, ntx) + tx] = 1;  // plain store, no atomics
+            for (int tx = tx0; tx <= tx1; ++tx) flag[__mul24(ty, ntx) + tx] = 1;
+    }
 }
 
 // WALK: the lane resolves its covered centres itself, right here (the plain variant of the kernel; kept inside this function,
@@ -131,57 +137,59 @@ __device__ __forceinline__ unsigned scatter_one(const ScatterTarget& S, int H, i
 {
     cv.mask = 0; cv.px0 = 0; cv.py0 = 0; cv.nxp = 1; cv.clipped = 0;
     unsigned range = ~0u;  // packed tile range of a LARGE triangle
-    if (a.x != INT_MIN && bq.x != INT_MIN && c.x != INT_MIN) {
-        const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
-        const int ymin = min(a.y, min(bq.y, c.y)), ymax = max(a.y, max(bq.y, c.y));
-        int px0 = (xmin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, px1 = (xmax - DDX_SUBPIX / 2) >> 8;
-        int py0 = (ymin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, py1 = (ymax - DDX_SUBPIX / 2) >> 8;
-        px0 = max(px0, 0); py0 = max(py0, 0);
-        px1 = min(px1, W - 1); py1 = min(py1, H - 1);
-        if (px0 <= px1 && py0 <= py1) {
-            const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
-            const bool small = __mul24(nxp, nyp) <= RASTER_SMALL_PX && (xmax - xmin) < 8192 && (ymax - ymin) < 8192;
-            bool alive = false;
-            if (small) {
-                // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly
-                const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
-                if (DEFER) {
-                    if (area != 0 && !(cull != 0 && (area < 0) == (cull < 0))) cv.clipped = 2;
-                } else
-                if (area != 0 && !(cull != 0 && (area < 0) == (cull < 0))) {  // (non-degenerate and not a culled back face)
-                    // pass 1: coverage of the <= RASTER_SMALL_PX bbox centres as a bit mask -- integer only
-                    scatter_mask_t mask = small_mask(a, bq, c, area, px0, py0, nxp, nyp);
-                    alive = mask != 0;  // a small triangle that covers no centre draws nothing: no tile to flag
-                    bool walk = WALK == 1;
-                    if (WALK == 2) {
-                        const int cnt = RASTER_SMALL_PX > 32 ? __popcll(mask) : __popc((unsigned)mask);
-                        walk = __ballot(cnt > SCATTER_DIRECT_MAX) == 0ull;  // (over the lanes active here)
-                    }
-                    if (walk) {
-                        if (mask) {
-                            const float4 p0 = ld4(S.P + (size_t)i0 * 4), p1 = ld4(S.P + (size_t)i1 * 4), p2 = ld4(S.P + (size_t)i2 * 4);
-                            walk_mask(mask, px0, py0, nxp, p0, p1, p2, t, S);
-                        }
-                    } else {
-                        cv.mask = mask; cv.px0 = px0; cv.py0 = py0; cv.nxp = nxp;
-                    }
-                }
-            } else {
-                const long long area = (long long)(bq.x - a.x) * (long long)(c.y - a.y) - (long long)(c.x - a.x) * (long long)(bq.y - a.y);
-                alive = area != 0 && !(cull != 0 && (area < 0) == (cull < 0));
+    // ONE level of branching for the common case (round 5).  The tests a triangle has to pass -- every vertex in front of the eye
+    // plane, a bounding box that holds a pixel centre, small, not degenerate, not a culled back face -- used to be five nested ifs:
+    // each costs the wave a handful of scalar instructions for its exec mask whether or not a lane takes it, and the scalar count of
+    // this part equalled its vector count.  The predicates are evaluated side by side (on garbage for a vertex at w <= 0: unsigned
+    // arithmetic, nothing is read from memory) and combined; the rare cases -- a large triangle, a vertex behind the eye plane -- keep
+    // their own branches behind the common one.  Same stores, same atomics.
+    const bool inside = a.x != INT_MIN && bq.x != INT_MIN && c.x != INT_MIN;
+    const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
+    const int ymin = min(a.y, min(bq.y, c.y)), ymax = max(a.y, max(bq.y, c.y));
+    int px0 = (int)((unsigned)xmin + (unsigned)(DDX_SUBPIX - 1 - DDX_SUBPIX / 2)) >> 8, px1 = (int)((unsigned)xmax - (unsigned)(DDX_SUBPIX / 2)) >> 8;
+    int py0 = (int)((unsigned)ymin + (unsigned)(DDX_SUBPIX - 1 - DDX_SUBPIX / 2)) >> 8, py1 = (int)((unsigned)ymax - (unsigned)(DDX_SUBPIX / 2)) >> 8;
+    px0 = max(px0, 0); py0 = max(py0, 0);
+    px1 = min(px1, W - 1); py1 = min(py1, H - 1);
+    const bool cand = inside && px0 <= px1 && py0 <= py1;
+    const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
+    const bool small = __mul24(nxp, nyp) <= RASTER_SMALL_PX && ((unsigned)xmax - (unsigned)xmin) < 8192u && ((unsigned)ymax - (unsigned)ymin) < 8192u;
+    // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly (only looked at for a small triangle)
+    const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
+    const bool front = area != 0 && !(cull != 0 && (area < 0) == (cull < 0));  // (non-degenerate and not a culled back face)
+    if (cand && small && front) {
+        if (DEFER) {
+            cv.clipped = 2;
+        } else {
+            // pass 1: coverage of the <= RASTER_SMALL_PX bbox centres as a bit mask -- integer only
+            scatter_mask_t mask = small_mask(a, bq, c, area, px0, py0, nxp, nyp);
+            bool walk = WALK == 1;
+            if (WALK == 2) {
+                const int cnt = RASTER_SMALL_PX > 32 ? __popcll(mask) : __popc((unsigned)mask);
+                walk = __ballot(cnt > SCATTER_DIRECT_MAX) == 0ull;  // (over the lanes active here)
             }
-            if (alive) {
-                const int tx0 = max(px0 - 1, 0) / DDX_TILE, tx1 = min(px1 + 1, W - 1) / DDX_TILE;
-                const int ty0 = max(py0 - 1, 0) / DDX_TILE, ty1 = min(py1 + 1, H - 1) / DDX_TILE;
-                flag_tiles(S.flag, S.ntx, tx0, ty0, tx1, ty1);
-                if (!small) {
-                    flag_tiles(S.big, S.ntx, tx0, ty0, tx1, ty1);
-                    range = (unsigned)tx0 | ((unsigned)ty0 << 8) | ((unsigned)(tx1 - tx0) << 16) | ((unsigned)(ty1 - ty0) << 24);
-                    *S.anybig = 1;  // plain store: "the batch has a large triangle"
+            if (mask != 0) {  // a small triangle that covers no centre draws nothing: no tile to flag
+                flag_tiles(S.flag, S.ntx, max(px0 - 1, 0) / DDX_TILE, max(py0 - 1, 0) / DDX_TILE, min(px1 + 1, W - 1) / DDX_TILE, min(py1 + 1, H - 1) / DDX_TILE);
+                if (walk) {
+                    const float4 p0 = ld4(S.P + (size_t)i0 * 4), p1 = ld4(S.P + (size_t)i1 * 4), p2 = ld4(S.P + (size_t)i2 * 4);
+                    walk_mask(mask, px0, py0, nxp, p0, p1, p2, t, S);
+                } else {
+                    cv.mask = mask; cv.px0 = px0; cv.py0 = py0; cv.nxp = nxp;
                 }
             }
         }
-    } else {
+    }
+    if (cand && !small) {  // a LARGE triangle: listed for the tile pass
+        const long long area64 = (long long)(bq.x - a.x) * (long long)(c.y - a.y) - (long long)(c.x - a.x) * (long long)(bq.y - a.y);
+        if (area64 != 0 && !(cull != 0 && (area64 < 0) == (cull < 0))) {
+            const int tx0 = max(px0 - 1, 0) / DDX_TILE, tx1 = min(px1 + 1, W - 1) / DDX_TILE;
+            const int ty0 = max(py0 - 1, 0) / DDX_TILE, ty1 = min(py1 + 1, H - 1) / DDX_TILE;
+            flag_tiles(S.flag, S.ntx, tx0, ty0, tx1, ty1);
+            flag_tiles(S.big, S.ntx, tx0, ty0, tx1, ty1);
+            range = (unsigned)tx0 | ((unsigned)ty0 << 8) | ((unsigned)(tx1 - tx0) << 16) | ((unsigned)(ty1 - ty0) << 24);
+            *S.anybig = 1;  // plain store: "the batch has a large triangle"
+        }
+    }
+    if (!inside) {
         // a vertex at w <= 0 (rare: a hypothesis that dives through the camera).  If any corner lies in front of the near plane the
         // triangle is a straddler: the tile pass clips it (clip_near) and draws the visible part.  Where that part lands cannot
         // be bounded from the snapped corners, so it is listed for the whole frame.  (Kept to a few instructions on purpose:
