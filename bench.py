@@ -449,6 +449,8 @@ def main():
             "avg_launch_ms": kms[dom], "counters_source": pmc_src, "counters_stale": stale, "csrc_sha16": csrc_sha16(),
             "valu": {"achieved": valu_ach, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": (valu_ach / VALU_PEAK_GINST) if valu_ach else None,
                      "valu_wave_insts_per_launch": valu_insts,
+                     "salu_wave_insts_per_launch": (kp.get("SQ_INSTS_SALU") if kp else None),  # (round 4: 7.23 M VALU + 3.59 M SALU on cfg2)
+                     "wait_frac_of_wave_cycles": ((kp["SQ_WAIT_ANY"] / kp["SQ_WAVE_CYCLES"]) if (kp and kp.get("SQ_WAVE_CYCLES") and not stale) else None),
                      # the same pipe seen by SQ_ACTIVE_INST_VALU (quad-cycles waves spent executing VALU instructions, summed over the
                      # chip) x 4 / (1024 SIMDs x 2.4 GHz x duration): ~4 cycles per instruction on these integer-heavy kernels, so
                      # about twice `frac`; the larger of the two is the honest "how busy is the VALU" (0.72 at saturation)
