@@ -135,9 +135,20 @@ def check(code, what):
         raise RuntimeError(f"{what} failed (code {code}): {msg}")
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as a void pointer.  (torch.cuda.current_stream().cuda_stream builds a Stream
+    object through several Python layers -- 14 us per call, seven calls per iteration of the op-by-op path, which is bound by its
+    host side; the raw getter is what the object wraps.)"""
+    global _raw_stream
     import torch
 
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
