@@ -154,7 +154,9 @@ __device__ __forceinline__ unsigned scatter_one(const ScatterTarget& S, int H, i
     const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
     const bool small = __mul24(nxp, nyp) <= RASTER_SMALL_PX && ((unsigned)xmax - (unsigned)xmin) < 8192u && ((unsigned)ymax - (unsigned)ymin) < 8192u;
     // extents < 2^13 sub-pixels: the area and the edge functions fit 32 bits exactly (only looked at for a small triangle)
-    const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
+    // (differences in unsigned arithmetic: a vertex at w <= 0 carries INT_MIN, and this line is no longer behind the test for it)
+    const int area = __mul24((int)((unsigned)bq.x - (unsigned)a.x), (int)((unsigned)c.y - (unsigned)a.y)) -
+                     __mul24((int)((unsigned)c.x - (unsigned)a.x), (int)((unsigned)bq.y - (unsigned)a.y));
     const bool front = area != 0 && !(cull != 0 && (area < 0) == (cull < 0));  // (non-degenerate and not a culled back face)
     if (cand && small && front) {
         if (DEFER) {
