@@ -73,6 +73,11 @@ _SIGNATURES = {
     "ddx_silhouette_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "ddx_masked_l1_fwd": (_I, [_P, _P, _P, _I, _I, _LL, _P, _P, _P]),
     "ddx_masked_l1_bwd": (_I, [_P, _P, _P, _I, _P, _I, _LL, _P, _P]),
+    "ddx_masked_l1_bc3_fwd": (_I, [_P, _P, _P, _I, _LL, _P, _P, _P]),
+    "ddx_masked_l1_bc3_bwd": (_I, [_P, _P, _P, _P, _I, _LL, _P, _P]),
+    "ddx_gbuffer_fwd_rows_c": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "ddx_silhouette_fwd_rows_c": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "ddx_silhouette_bwd_rows_c": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "ddx_engine_scratch_bytes": (_SZ, [ctypes.POINTER(EngineDesc)]),
     "ddx_engine_create": (_I, [ctypes.POINTER(EngineDesc), ctypes.POINTER(EngineBuffers), ctypes.POINTER(_P)]),
     "ddx_engine_run": (_I, [_P, _I, _I, _I, _P]),

@@ -603,11 +603,20 @@ class DiffDope:
         self.losses_values.add(key, values.detach().clone())
 
     # ---- rendering -------------------------------------------------------------------------------
-    def _render(self, mtx):
+    def _render(self, mtx, outputs=None):
         r = self.object3d.mesh()
         kw = dict(uv=r["uv"], uv_idx=r["uv_idx"], tex=r["tex"]) if self.object3d.mesh.has_textured_map else dict(vtx_color=r["vtx_color"])
         return render_texture_batch(glctx=self.glctx, proj_cam=self.camera.cam_proj, mtx=mtx, pos=r["pos"], pos_idx=r["pos_idx"],
-                                    resolution=self.resolution, **kw)
+                                    resolution=self.resolution, outputs=outputs, **kw)
+
+    def _loop_outputs(self):
+        """What the loss functions of this run read from self.renders: known for the built-in ones (None = everything: a user
+        function may read anything).  Without a colour loss the loop's renders carry no "rgb" (render_texture_batch(outputs=...));
+        the complete images of the last iteration are rendered once more when the loop is done, as the reference leaves them."""
+        if not self.loss_functions or not all(f in _BUILTIN_LOSSES for f in self.loss_functions):
+            return None
+        need = {_BUILTIN_LOSSES[f] for f in self.loss_functions}
+        return None if need & {"rgb", "edge"} else tuple(sorted(need))
 
     def _render_cpu(self, mtx_cpu):
         with torch.no_grad():
@@ -786,7 +795,7 @@ class DiffDope:
         self.optimizer.zero_grad()
         result = self.object3d()
         mtx_gu = matrix_batch_44_from_position_quat(p=result["trans"], q=result["quat"])
-        self.renders = self._render(mtx_gu)
+        self.renders = self._render(mtx_gu, outputs=self._loop_outputs())
         loss = torch.zeros(1, device=mtx_gu.device)
         for loss_function in self.loss_functions:
             l = loss_function(self)
@@ -814,6 +823,9 @@ class DiffDope:
             for lr in lrs:
                 mtx_gu = self._iteration(lr)
                 self.optimization_results.append(_LazyResult(mtx_gu.detach(), self._render_cpu))  # (copied to the host when read)
+            if n_it and self._loop_outputs() is not None:
+                with torch.no_grad():  # (the loop's renders were partial: the last iteration's images once more, complete)
+                    self.renders = self._render(mtx_gu.detach())
             return
         # ---- two eager iterations (the allocator, the lazily built tables and the autograd nodes of the parameters settle) ON THE
         # STREAM THE CAPTURE WILL USE -- an AccumulateGrad node made on another stream would synchronise with it inside the capture --,

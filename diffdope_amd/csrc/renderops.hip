@@ -381,10 +381,18 @@ extern "C" int ddx_silhouette_fwd(const float* rast, const float* pos, const int
 extern "C" int ddx_silhouette_fwd_rows(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
                                        int H, int W, const int32_t* row_range, float* mask, void* stream)
 {
+    return ddx_silhouette_fwd_rows_c(rast, pos, tri, opp, B, V, T, H, W, row_range, mask, 3, stream);
+}
+
+// ... on an image of `channels` equal channels (1: the single copy ddx_gbuffer_fwd_rows_c keeps; 3: the reference's layout)
+extern "C" int ddx_silhouette_fwd_rows_c(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
+                                         int H, int W, const int32_t* row_range, float* mask, int channels, void* stream)
+{
     DDX_REQUIRE(rast && pos && tri && opp && mask, DDX_E_NULL, "silhouette_fwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "silhouette_fwd: bad shape");
+    DDX_REQUIRE(channels == 1 || channels == 3, DDX_E_SHAPE, "silhouette_fwd: channels=%d (1 or 3)", channels);
     DDX_REQUIRE_FRAME(B, H, W, "silhouette_fwd");
-    antialias_kernel<false, true><<<aa_grid(H, B), 256, 0, (hipStream_t)stream>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, nullptr, mask, nullptr, row_range);
+    antialias_kernel<false, true><<<aa_grid(H, B), 256, 0, (hipStream_t)stream>>>(nullptr, channels, rast, pos, tri, opp, V, T, H, W, nullptr, mask, nullptr, row_range);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -398,12 +406,20 @@ extern "C" int ddx_silhouette_bwd(const float* rast, const float* pos, const int
 extern "C" int ddx_silhouette_bwd_rows(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
                                        int H, int W, const int32_t* row_range, const float* dmask, float* dpos, void* stream)
 {
+    return ddx_silhouette_bwd_rows_c(rast, pos, tri, opp, B, V, T, H, W, row_range, dmask, 3, dpos, stream);
+}
+
+// ... dmask [B,H,W,channels]; with one channel it is the sum of the reference's three
+extern "C" int ddx_silhouette_bwd_rows_c(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T,
+                                         int H, int W, const int32_t* row_range, const float* dmask, int channels, float* dpos, void* stream)
+{
     DDX_REQUIRE(rast && pos && tri && opp && dmask && dpos, DDX_E_NULL, "silhouette_bwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "silhouette_bwd: bad shape");
+    DDX_REQUIRE(channels == 1 || channels == 3, DDX_E_SHAPE, "silhouette_bwd: channels=%d (1 or 3)", channels);
     DDX_REQUIRE_FRAME(B, H, W, "silhouette_bwd");
     hipStream_t s = (hipStream_t)stream;
     DDX_HIP(hipMemsetAsync(dpos, 0, (size_t)B * V * 4 * sizeof(float), s));
-    antialias_kernel<true, true><<<aa_grid(H, B), 256, 0, s>>>(nullptr, 3, rast, pos, tri, opp, V, T, H, W, dmask, nullptr, dpos, row_range);
+    antialias_kernel<true, true><<<aa_grid(H, B), 256, 0, s>>>(nullptr, channels, rast, pos, tri, opp, V, T, H, W, dmask, nullptr, dpos, row_range);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -536,6 +552,102 @@ __global__ __launch_bounds__(256) void masked_l1_bwd4_kernel(const float* __rest
     }
 }
 
+// x with ONE channel against an observed image of three (l1_mask, diffdope.py:583-613: the rendered silhouette's three channels are
+// one number, kept once -- ddx_gbuffer_fwd_rows_c --, the observed segmentation's are not): out[b] = mean over (i, c) of
+// |(x[b,i] - y[i,c]) * m[i,c]|, d x[b,i] = the sum over c.  Four pixels per lane when P % 4 == 0 and the operands are 16-byte
+// aligned (VEC), one otherwise; per pixel (|d0| + |d1|) + |d2|, the pixels of a group added pairwise: a fixed order.
+template <bool VEC>
+__global__ __launch_bounds__(256) void masked_l1_bc3_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                    const float* __restrict__ m, long long P, float* __restrict__ partial)
+{
+    const int b = blockIdx.y, c = blockIdx.x;
+    const long long G = VEC ? P >> 2 : P, per = (G + ML1_CHUNKS - 1) / ML1_CHUNKS;
+    const long long i0 = (long long)c * per, i1 = i0 + per < G ? i0 + per : G;
+    const float* xb = x + (size_t)b * P;
+    auto px = [&](float xv, const float* yy, const float* mm) {
+        const float m0 = m ? mm[0] : 1.f, m1 = m ? mm[1] : 1.f, m2 = m ? mm[2] : 1.f;
+        return (fabsf((xv - yy[0]) * m0) + fabsf((xv - yy[1]) * m1)) + fabsf((xv - yy[2]) * m2);
+    };
+    float acc = 0.f;
+#pragma unroll 2
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        if (VEC) {
+            float yy[12], mm[12];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 v = ld4(y + i * 12 + k * 4);
+                yy[k * 4] = v.x; yy[k * 4 + 1] = v.y; yy[k * 4 + 2] = v.z; yy[k * 4 + 3] = v.w;
+                const float4 w = m ? ld4(m + i * 12 + k * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                mm[k * 4] = w.x; mm[k * 4 + 1] = w.y; mm[k * 4 + 2] = w.z; mm[k * 4 + 3] = w.w;
+            }
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) any |= mm[k] != 0.f;
+            if (any) {  // (as masked_l1_partial_kernel: x is only read where the mask lets something through)
+                const float4 xv = ld4(xb + i * 4);
+                acc += (px(xv.x, yy, mm) + px(xv.y, yy + 3, mm + 3)) + (px(xv.z, yy + 6, mm + 6) + px(xv.w, yy + 9, mm + 9));
+            }
+        } else {
+            const float* mm = m ? m + i * 3 : nullptr;
+            if (!m || mm[0] != 0.f || mm[1] != 0.f || mm[2] != 0.f) acc += px(xb[i], y + i * 3, mm);
+        }
+    }
+    acc = wave_sum(acc);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * ML1_CHUNKS + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void masked_l1_bc3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ m, const float* __restrict__ gout, long long P,
+                                                                float* __restrict__ dx)
+{
+    const int b = blockIdx.y;
+    const float scale = gout[b] / (float)(P * 3);
+    const float* xb = x + (size_t)b * P;
+    float* db = dx + (size_t)b * P;
+    const long long G = VEC ? P >> 2 : P;
+    auto px = [&](float xv, const float* yy, const float* mm) {
+        float g = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float mk = m ? mm[c] : 1.f;
+            const float d = (xv - yy[c]) * mk;
+            g += (float)((d > 0.f) - (d < 0.f)) * mk * scale;  // (a zero mask adds +-0)
+        }
+        return g;
+    };
+#pragma unroll
+    for (int k = 0; k < PIX_ROUNDS; ++k) {
+        const long long i = (long long)blockIdx.x * PIX_PER_WG + k * 256 + threadIdx.x;
+        if (i >= G) continue;
+        if (VEC) {
+            float yy[12], mm[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4 v = ld4(y + i * 12 + q * 4);
+                yy[q * 4] = v.x; yy[q * 4 + 1] = v.y; yy[q * 4 + 2] = v.z; yy[q * 4 + 3] = v.w;
+                const float4 w = m ? ld4(m + i * 12 + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                mm[q * 4] = w.x; mm[q * 4 + 1] = w.y; mm[q * 4 + 2] = w.z; mm[q * 4 + 3] = w.w;
+            }
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) any |= mm[q] != 0.f;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (any) {
+                const float4 xv = ld4(xb + i * 4);
+                g = make_float4(px(xv.x, yy, mm), px(xv.y, yy + 3, mm + 3), px(xv.z, yy + 6, mm + 6), px(xv.w, yy + 9, mm + 9));
+            }
+            *reinterpret_cast<float4*>(db + i * 4) = g;
+        } else {
+            const float* mm = m ? m + i * 3 : nullptr;
+            db[i] = (!m || mm[0] != 0.f || mm[1] != 0.f || mm[2] != 0.f) ? px(xb[i], y + i * 3, mm) : 0.f;
+        }
+    }
+}
+
 static inline bool ml1_vec_ok(const void* x, const void* y, const void* m, int m_stride, const void* dx, long long N)
 {
     auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
@@ -572,6 +684,30 @@ extern "C" int ddx_masked_l1_bwd(const float* x, const float* y, const float* m,
     return 0;
 }
 
+// ... x [B,P] with one channel against y, m [P,3] (see masked_l1_bc3_partial_kernel); out[b] = the mean over the 3 P terms
+extern "C" int ddx_masked_l1_bc3_fwd(const float* x, const float* y, const float* m, int B, long long P, float* partial, float* out,
+                                     void* stream)
+{
+    DDX_REQUIRE(x && y && partial && out, DDX_E_NULL, "masked_l1_bc3_fwd: NULL pointer");
+    DDX_REQUIRE(B >= 1 && B <= 65535 && P >= 1 && P < (1ll << 38), DDX_E_SHAPE, "masked_l1_bc3_fwd: bad shape B=%d P=%lld", B, P);
+    if (ml1_vec_ok(x, y, m, 1, nullptr, P)) masked_l1_bc3_partial_kernel<true><<<dim3(ML1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(x, y, m, P, partial);
+    else masked_l1_bc3_partial_kernel<false><<<dim3(ML1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(x, y, m, P, partial);
+    masked_l1_final_kernel<<<B, ML1_CHUNKS, 0, (hipStream_t)stream>>>(partial, P * 3, out);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_masked_l1_bc3_bwd(const float* x, const float* y, const float* m, const float* gout, int B, long long P, float* dx,
+                                     void* stream)
+{
+    DDX_REQUIRE(x && y && gout && dx, DDX_E_NULL, "masked_l1_bc3_bwd: NULL pointer");
+    DDX_REQUIRE(B >= 1 && B <= 65535 && P >= 1 && P < (1ll << 38), DDX_E_SHAPE, "masked_l1_bc3_bwd: bad shape B=%d P=%lld", B, P);
+    if (ml1_vec_ok(x, y, m, 1, dx, P)) masked_l1_bc3_bwd_kernel<true><<<pix_grid2(P >> 2, B), 256, 0, (hipStream_t)stream>>>(x, y, m, gout, P, dx);
+    else masked_l1_bc3_bwd_kernel<false><<<pix_grid2(P, B), 256, 0, (hipStream_t)stream>>>(x, y, m, gout, P, dx);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // gbuffer: the per-pixel middle of render_texture_batch (diffdope/diffdope.py:203-231) as ONE forward and ONE backward pass
 // over the frame -- interpolate(pos) -> pose transform -> depth; interpolate(uv) -> texture(linear) (or interpolate(vertex
@@ -587,7 +723,7 @@ __global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restric
                                                           const float* __restrict__ uv, const float* __restrict__ tex, int Th, int Tw,
                                                           const float* __restrict__ vcol, int V, int T, int HW,
                                                           float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ cover,
-                                                          const int* __restrict__ row_range, int W)
+                                                          const int* __restrict__ row_range, int W, int cover_c)
 {
     const int b = blockIdx.y;
     const float* M = mtx + (size_t)b * 16;
@@ -626,7 +762,7 @@ __global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restric
                     const float bq = __fmaf_rn(s.fx, t11[c] - t01[c], t01[c]);
                     col[c] = __fmaf_rn(s.fy, bq - a, a);
                 }
-            } else {
+            } else if (rgb) {  // (rgb == NULL: the caller asked for depth and coverage only)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     col[c] = __fmaf_rn(w2, vcol[(size_t)i2 * 3 + c], __fmaf_rn(v, vcol[(size_t)i1 * 3 + c], u * vcol[(size_t)i0 * 3 + c]));
@@ -639,8 +775,10 @@ __global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restric
         zc = __fmaf_rn(M[11], 1.0f, zc);
         depth[i] = -zc;
         const float k = r.w < 0.f ? 0.f : (r.w > 1.f ? 1.f : r.w);  // clamp(rast[..., -1:], 0, 1) (diffdope.py:228,231)
-        rgb[i * 3 + 0] = col[0] * k; rgb[i * 3 + 1] = col[1] * k; rgb[i * 3 + 2] = col[2] * k;
-        cover[i * 3 + 0] = cv; cover[i * 3 + 1] = cv; cover[i * 3 + 2] = cv;
+        if (rgb) { rgb[i * 3 + 0] = col[0] * k; rgb[i * 3 + 1] = col[1] * k; rgb[i * 3 + 2] = col[2] * k; }
+        // (the three channels of interpolate(ones) are one number: cover_c == 1 keeps one copy of it, see ddx_gbuffer_fwd_rows_c)
+        if (cover_c == 1) cover[i] = cv;
+        else { cover[i * 3 + 0] = cv; cover[i * 3 + 1] = cv; cover[i * 3 + 2] = cv; }
     }
 }
 
@@ -776,14 +914,23 @@ extern "C" int ddx_gbuffer_fwd_rows(const float* rast, const float* mtx, const f
                                     const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
                                     const int32_t* row_range, float* rgb, float* depth, float* cover, void* stream)
 {
-    DDX_REQUIRE(rast && mtx && pos && tri && rgb && depth && cover, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
-    DDX_REQUIRE((uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_fwd: needs (uv, tex) or vtx_color");
+    DDX_REQUIRE(rgb, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
+    return ddx_gbuffer_fwd_rows_c(rast, mtx, pos, tri, uv, tex, Th, Tw, vtx_color, B, V, T, H, W, row_range, rgb, depth, cover, 3, stream);
+}
+
+extern "C" int ddx_gbuffer_fwd_rows_c(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv,
+                                      const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
+                                      const int32_t* row_range, float* rgb, float* depth, float* cover, int cover_channels, void* stream)
+{
+    DDX_REQUIRE(rast && mtx && pos && tri && depth && cover, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
+    DDX_REQUIRE(!rgb || (uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_fwd: needs (uv, tex) or vtx_color");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "gbuffer_fwd: bad shape");
+    DDX_REQUIRE(cover_channels == 1 || cover_channels == 3, DDX_E_SHAPE, "gbuffer_fwd: cover_channels=%d (1 or 3)", cover_channels);
     DDX_REQUIRE(((uintptr_t)rast & 15) == 0, DDX_E_ALIGN, "gbuffer_fwd: rast must be 16-byte aligned");
     DDX_REQUIRE_FRAME(B, H, W, "gbuffer_fwd");
     hipStream_t s = (hipStream_t)stream;
-    if (uv && tex) gbuffer_fwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H * W, rgb, depth, cover, row_range, W);
-    else gbuffer_fwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H * W, rgb, depth, cover, row_range, W);
+    if (rgb && uv && tex) gbuffer_fwd_kernel<true><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, uv, tex, Th, Tw, nullptr, V, T, H * W, rgb, depth, cover, row_range, W, cover_channels);
+    else gbuffer_fwd_kernel<false><<<pix_grid2((long long)H * W, B), 256, 0, s>>>(rast, mtx, pos, tri, nullptr, nullptr, 0, 0, vtx_color, V, T, H * W, rgb, depth, cover, row_range, W, cover_channels);
     DDX_LAUNCH_CHECK();
     return 0;
 }

@@ -362,8 +362,9 @@ class _silhouette_func(torch.autograd.Function):
         rast, pos, tri = _f32c(rast, "rast"), _f32c(pos, "pos"), _i32c(tri, "tri")
         B, H, W = rast.shape[:3]
         V, T = pos.shape[1], tri.shape[0]
-        _lib.check(_lib.load().ddx_silhouette_fwd_rows(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(rows),
-                                                       _lib.ptr(cover), _lib.stream_ptr()), "ddx_silhouette_fwd_rows")
+        _lib.check(_lib.load().ddx_silhouette_fwd_rows_c(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(rows),
+                                                         _lib.ptr(cover), int(cover.shape[-1]), _lib.stream_ptr()), "ddx_silhouette_fwd_rows_c")
+        ctx.channels = int(cover.shape[-1])
         ctx.mark_dirty(cover)
         ctx.save_for_backward(rast, pos, tri, opp, rows)
         return cover
@@ -375,8 +376,8 @@ class _silhouette_func(torch.autograd.Function):
         V, T = pos.shape[1], tri.shape[0]
         dmask = _f32c(dmask, "dmask")
         dpos = torch.empty_like(pos)
-        _lib.check(_lib.load().ddx_silhouette_bwd_rows(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(rows),
-                                                       _lib.ptr(dmask), _lib.ptr(dpos), _lib.stream_ptr()), "ddx_silhouette_bwd_rows")
+        _lib.check(_lib.load().ddx_silhouette_bwd_rows_c(_lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(opp), B, V, T, H, W, _lib.ptr(rows),
+                                                         _lib.ptr(dmask), ctx.channels, _lib.ptr(dpos), _lib.stream_ptr()), "ddx_silhouette_bwd_rows_c")
         return None, None, dpos, None, None, None
 
 
@@ -410,6 +411,44 @@ class _masked_l1_func(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _masked_l1_bc3_func(torch.autograd.Function):
+    """x [B,...,1] (one stored channel) against y, m [...,3]: ddx_masked_l1_bc3_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, y, m):
+        B = x.shape[0]
+        P = x[0].numel()
+        out = torch.empty((B,), dtype=torch.float32, device=x.device)
+        partial = torch.empty((B, 128), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().ddx_masked_l1_bc3_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(m) if m is not None else None, B, P, _lib.ptr(partial),
+                                                     _lib.ptr(out), _lib.stream_ptr()), "ddx_masked_l1_bc3_fwd")
+        ctx.save_for_backward(x, y, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, m = ctx.saved_tensors
+        B = x.shape[0]
+        P = x[0].numel()
+        gout = _f32c(gout, "gout")
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().ddx_masked_l1_bc3_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(m) if m is not None else None, _lib.ptr(gout), B, P,
+                                                     _lib.ptr(dx), _lib.stream_ptr()), "ddx_masked_l1_bc3_bwd")
+        return dx, None, None
+
+
+def _one_channel_base(x):
+    """x is `base.expand(..., 3)` of a contiguous base [..., 1] (render_texture_batch's mask): the base, else None.  Handing the
+    BASE to the loss kernel keeps autograd off the expanded view (whose backward would materialise and sum the three channels)."""
+    if x.dim() < 2 or x.shape[-1] != 3 or x.stride(-1) != 0 or not x._is_view():
+        return None
+    b = x._base
+    if (b is None or b.dim() != x.dim() or b.shape[-1] != 1 or tuple(b.shape[:-1]) != tuple(x.shape[:-1]) or not b.is_contiguous()
+            or b.data_ptr() != x.data_ptr() or tuple(b.stride()[:-1]) != tuple(x.stride()[:-1])):
+        return None
+    return b
+
+
 def masked_l1_mean(x, y, mask=None, mask_channel0=False):
     """mean over all but the batch axis of |(x - y) * mask| -> [B]: the image-space part of the reference's built-in losses
     (diffdope.py:547-613) as ONE forward and ONE backward kernel for ROCm tensors.  x [B,...]; y and mask describe ONE observed
@@ -424,6 +463,10 @@ def masked_l1_mean(x, y, mask=None, mask_channel0=False):
         return t
     y1, m1 = one(y, x.dim()), one(mask, x.dim() + 1 if mask_channel0 else x.dim())
     tail = tuple(x.shape[1:])
+    xb = _one_channel_base(x) if (x.is_cuda and x.dtype == torch.float32 and not mask_channel0) else None
+    if (xb is not None and tuple(y1.shape) == tail and y1.dtype == torch.float32
+            and (m1 is None or (m1.dtype == torch.float32 and tuple(m1.shape) == tail))):
+        return _masked_l1_bc3_func.apply(xb, y1.contiguous(), None if m1 is None else m1.contiguous())
     fusable = (x.is_cuda and x.dtype == torch.float32 and tuple(y1.shape) == tail and y1.dtype == torch.float32
                and (m1 is None or (m1.dtype == torch.float32 and tuple(m1.shape) == (tail + (3,) if mask_channel0 else tail))))
     if not fusable:
@@ -437,19 +480,19 @@ class _gbuffer_func(torch.autograd.Function):
     frame each way).  pos / uv / tex / vtx_color are ONE copy each ([V,3], [V,2], [Th,Tw,3], [V,3]); they get no gradient."""
 
     @staticmethod
-    def forward(ctx, clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows=None):
+    def forward(ctx, clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows=None, cover_channels=3, want_rgb=True):
         lib = _lib.load()
         clip, mtx, rast = _f32c(clip, "clip"), _f32c(mtx, "mtx"), _f32c(rast, "rast")
         B, H, W = rast.shape[:3]
         V, T = pos.shape[0], tri.shape[0]
         Th, Tw = (tex.shape[0], tex.shape[1]) if tex is not None else (0, 0)
         dev = rast.device
-        rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) if want_rgb else None
         depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-        cover = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
-        _lib.check(lib.ddx_gbuffer_fwd_rows(_lib.ptr(rast), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv), _lib.ptr(tex), Th, Tw,
-                                            _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(cover),
-                                            _lib.stream_ptr()), "ddx_gbuffer_fwd_rows")
+        cover = torch.empty((B, H, W, int(cover_channels)), dtype=torch.float32, device=dev)
+        _lib.check(lib.ddx_gbuffer_fwd_rows_c(_lib.ptr(rast), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv), _lib.ptr(tex), Th, Tw,
+                                              _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(rgb) if want_rgb else None, _lib.ptr(depth),
+                                              _lib.ptr(cover), int(cover_channels), _lib.stream_ptr()), "ddx_gbuffer_fwd_rows_c")
         ctx.save_for_backward(clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows)
         ctx.set_materialize_grads(False)  # (an unused output arrives as None instead of a zero-filled 80-240 MB tensor)
         ctx.mark_non_differentiable(cover)  # (the interpolation of a tensor of ones does not depend on the barycentrics)
@@ -459,7 +502,7 @@ class _gbuffer_func(torch.autograd.Function):
     def backward(ctx, drgb, ddepth, _dcover):
         clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows = ctx.saved_tensors
         if drgb is None and ddepth is None:
-            return (None,) * 9
+            return (None,) * 11
         B, H, W = rast.shape[:3]
         V, T = pos.shape[0], tri.shape[0]
         Th, Tw = (tex.shape[0], tex.shape[1]) if tex is not None else (0, 0)
@@ -470,7 +513,7 @@ class _gbuffer_func(torch.autograd.Function):
         _lib.check(_lib.load().ddx_gbuffer_bwd_rows(_lib.ptr(rast), _lib.ptr(clip), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv),
                                                     _lib.ptr(tex), Th, Tw, _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(drgb),
                                                     _lib.ptr(ddepth), _lib.ptr(dclip), _lib.ptr(dmtx), _lib.stream_ptr()), "ddx_gbuffer_bwd_rows")
-        return dclip, dmtx, None, None, None, None, None, None, None
+        return dclip, dmtx, None, None, None, None, None, None, None, None, None
 
 
 _same_index_cache = {}
@@ -505,7 +548,7 @@ def _one_copy(t):
 
 
 def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None, uv_idx=None, tex=None, vtx_color=None,
-                         return_rast_out=False, fused=None, restrict_rows=True):
+                         return_rast_out=False, fused=None, restrict_rows=True, compact_mask=True, outputs=None):
     """The materialising render of diffdope.py:156-234 (same signature and outputs), for user loss functions that read
     ddope.renders; the built-in losses take the fused engine (diffdope_amd.engine) instead.
 
@@ -520,6 +563,13 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
     restrict_rows (fused path; round 4): the passes only visit the pixel rows each hypothesis draws into (the rows of its active
     tiles, from the rasteriser): outside them a pixel is background by construction, so nothing is read there -- the same
     images and gradients, bit for bit, at a fraction of the traffic (an object at 1.2 % of the frame spans a fifth of the rows).
+    compact_mask (fused path; round 5): the three channels of `mask` are one number per pixel (the reference interpolates a tensor
+    of ones, :212), so ONE is stored and `mask` is its expand(..., 3): the same shape and values, a zero stride on the last axis
+    (an in-place write into it needs a .clone() first).  masked_l1_mean recognises the view and works on the stored channel; any
+    other consumer sees an ordinary [B,H,W,3] tensor whose gradient autograd sums over the channels.  compact_mask=False: three
+    stored copies.
+    outputs (fused path): None = all; a collection of names from ("rgb", "depth", "mask") = what the caller will read -- without
+    "rgb" the colour pass (texture fetches, 12 bytes per pixel written) is left out and the entry is None.
     """
     H, W = (resolution if isinstance(resolution, (list, tuple)) else (resolution, resolution))
     faces = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
@@ -545,10 +595,14 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
         p1 = _f32c(_one_copy(pos), "pos")
         kw = dict(uv=_f32c(_one_copy(uv), "uv"), tex=_f32c(_one_copy(tex), "tex"), vtx_color=None) if textured else \
             dict(uv=None, tex=None, vtx_color=_f32c(_one_copy(vtx_color), "vtx_color"))
-        rgb, depth, cover = _gbuffer_func.apply(clip, mtx, rast.detach(), p1, _i32c(faces, "pos_idx"), kw["uv"], kw["tex"], kw["vtx_color"], rows)
+        want_rgb = outputs is None or "rgb" in outputs
+        rgb, depth, cover = _gbuffer_func.apply(clip, mtx, rast.detach(), p1, _i32c(faces, "pos_idx"), kw["uv"], kw["tex"], kw["vtx_color"], rows,
+                                                1 if compact_mask else 3, want_rgb)
         # the silhouette: antialias blends added in place onto the coverage image (rast detached: antialias has no gradient for
         # it, and an attached one would still make autograd run rasterize's backward on zeros)
         mask = _silhouette_func.apply(cover, rast.detach(), clip, _i32c(faces, "pos_idx"), build_topology(faces), rows)
+        if compact_mask:
+            mask = mask.expand(*mask.shape[:-1], 3)
         return {"rgb": rgb, "depth": depth, "rast_out": rast if return_rast_out else None, "mask": mask}
     rast, _ = rasterize(glctx, clip, faces, resolution=[H, W])
     covered = rast[..., 3:].clamp(0, 1)

@@ -179,6 +179,18 @@ int ddx_silhouette_fwd_rows(const float* rast, const float* pos, const int32_t* 
                             const int32_t* row_range, float* mask, void* stream);
 int ddx_silhouette_bwd_rows(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
                             const int32_t* row_range, const float* dmask, float* dpos, void* stream);
+/* ... with the silhouette kept as ONE channel.  The three channels the reference carries (interpolate of a [T,3] tensor of ones,
+ * diffdope.py:212) are one number per pixel; at 64 x 640x480 the two extra copies are 157 MB written by the g-buffer pass and read and
+ * written again by every consumer.  `channels` = 1 or 3 (3: the functions above).  ddx_gbuffer_fwd_rows_c: cover [B,H,W,cover_channels];
+ * rgb may be NULL there (depth and coverage only: neither the texture nor the vertex colours are read).  ddx_silhouette_bwd_rows_c
+ * with one channel takes d mask [B,H,W,1] = the sum of the three channel gradients. */
+int ddx_gbuffer_fwd_rows_c(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv, const float* tex,
+                           int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, const int32_t* row_range, float* rgb,
+                           float* depth, float* cover, int cover_channels, void* stream);
+int ddx_silhouette_fwd_rows_c(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
+                              const int32_t* row_range, float* mask, int channels, void* stream);
+int ddx_silhouette_bwd_rows_c(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int V, int T, int H, int W,
+                              const int32_t* row_range, const float* dmask, int channels, float* dpos, void* stream);
 
 /* Image-space part of the built-in losses for the op-by-op path (diffdope.py:547-613: l1_rgb_with_mask :547-562,
  * l1_depth_with_mask :565-580, l1_mask :583-613): out[b] = mean_i |(x[b,i] - y[i]) * m[i * m_stride]|, with the observed image y [N]
@@ -188,6 +200,11 @@ int ddx_masked_l1_fwd(const float* x, const float* y, const float* m, int m_stri
                       void* stream);
 int ddx_masked_l1_bwd(const float* x, const float* y, const float* m, int m_stride, const float* gout, int B, long long N, float* dx,
                       void* stream);
+/* ... for an x of ONE channel against an observed image and mask of three (l1_mask, diffdope.py:583-613, on the single copy of the
+ * silhouette that ddx_gbuffer_fwd_rows_c / ddx_silhouette_*_rows_c keep): x [B,P], y and m [P,3] (m NULL = no mask);
+ * out[b] = mean over the 3 P terms |(x[b,i] - y[i,c]) * m[i,c]|; dx[b,i] = sum over c of sign(.) * m[i,c] * gout[b] / (3 P). */
+int ddx_masked_l1_bc3_fwd(const float* x, const float* y, const float* m, int B, long long P, float* partial, float* out, void* stream);
+int ddx_masked_l1_bc3_bwd(const float* x, const float* y, const float* m, const float* gout, int B, long long P, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused refinement engine: the body of DiffDope.run_optimization (diffdope.py:1656-1714) for the

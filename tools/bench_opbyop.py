@@ -21,10 +21,13 @@ wt = w['weights']
 from diffdope_amd.render import masked_l1_mean
 FUSED_LOSS = '--torch-losses' not in sys.argv  # the built-in loss functions use render.masked_l1_mean; --torch-losses: the plain expressions
 
+# (what the loss terms read: without a colour term the colour image is not rendered -- as DiffDope._loop_outputs decides for the built-in losses)
+OUTPUTS = None if wt.get('rgb') is not None or '--all-outputs' in sys.argv else tuple(k for k in ('depth', 'mask') if wt.get(k) is not None)
+
 def step():
     q = params[:4].T / torch.norm(params[:4].T, dim=1, keepdim=True)
     mtx = dd.matrix_batch_44_from_position_quat(q=q, p=params[4:].T)
-    r = render_texture_batch(ctx, ex(w['proj']), mtx, ex(w['pos']), ex(w['tri']), [H, W], **kw)
+    r = render_texture_batch(ctx, ex(w['proj']), mtx, ex(w['pos']), ex(w['tri']), [H, W], outputs=OUTPUTS, **kw)
     loss = 0
     if FUSED_LOSS:
         if wt.get('rgb') is not None:
