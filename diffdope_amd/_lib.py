@@ -52,6 +52,8 @@ _SIGNATURES = {
     "ddx_xfm_bwd_full": (_I, [_P, _LL, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "ddx_pose_matrix_fwd": (_I, [_P, _P, _I, _P, _P]),
     "ddx_pose_matrix_bwd": (_I, [_P, _P, _I, _P, _P, _P]),
+    "ddx_pose_pack_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "ddx_pose_pack_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "ddx_rasterize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
     "ddx_rasterize_fwd_rows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _I, _P]),

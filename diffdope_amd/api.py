@@ -11,6 +11,7 @@ What differs on purpose ("Logging semantics"):
   * `optimization_results[i]` always holds "mtx"; "rgb"/"depth"/"mask" are rendered on first access from
     the stored pose instead of being copied to the host every iteration (diffdope.py:1698-1703).
 """
+import os
 import logging
 import math
 import random
@@ -23,7 +24,7 @@ import torch
 from . import io_img, io_ply
 from . import ops as dd_ops
 from .engine import RefineEngine
-from .pose import matrix_batch_44_from_position_quat
+from .pose import matrix_batch_44_from_position_quat, quat_trans_from_parameters
 from .render import RasterizeGLContext, masked_l1_mean, render_texture_batch
 
 log = logging.getLogger(__name__)
@@ -359,10 +360,8 @@ class Object3D(torch.nn.Module):
     def forward(self):
         """The mesh dictionary plus the pose of every hypothesis: `quat` [B,4] (x, y, z, w, normalised here -- the seven parameters
         are free, so the optimiser may leave the unit sphere) and `trans` [B,3] (semantics of diffdope.py:1085-1098)."""
-        raw_q = torch.stack((self.qx, self.qy, self.qz, self.qw), dim=1)
         out = dict(self.mesh())
-        out["quat"] = raw_q / raw_q.norm(dim=1, keepdim=True)
-        out["trans"] = torch.stack((self.x, self.y, self.z), dim=1)
+        out["quat"], out["trans"] = quat_trans_from_parameters(self.qx, self.qy, self.qz, self.qw, self.x, self.y, self.z)
         return out
 
 
@@ -804,10 +803,15 @@ class DiffDope:
             loss = loss + l
         loss.backward()
         if torch.is_tensor(lr):
-            with torch.no_grad():
-                for prm in self.object3d.parameters():
-                    if prm.grad is not None:
-                        prm.addcmul_(prm.grad, lr, value=-1.0)
+            with torch.no_grad():  # (two launches for the seven parameters; p + (-1) (g lr), the rounding of the eager step)
+                prms = [prm for prm in self.object3d.parameters() if prm.grad is not None]
+                lr_b = self._capture["lr_b"]
+                lr_b.copy_(lr.expand_as(lr_b))
+                if os.environ.get("DDX_API_SGD") == "loop":
+                    for prm in prms:
+                        prm.addcmul_(prm.grad, lr_b, value=-1.0)
+                else:
+                    torch._foreach_addcmul_(prms, [prm.grad for prm in prms], [lr_b] * len(prms), value=-1.0)
         else:
             for g in self.optimizer.param_groups:
                 g["lr"] = lr
@@ -847,6 +851,7 @@ class DiffDope:
             # the memory of a temporary freed earlier in the iteration, which every replay then scribbles over
             cap = dict(n_it=n_it, it=torch.full((1,), n_eager, dtype=torch.long, device=dev),
                        logs={k: torch.zeros((n_it,) + shp, dtype=dt, device=dev) for k, (shp, dt) in shapes.items()})
+            cap["lr_b"] = torch.zeros_like(self.object3d.qx)  # (this iteration's learning rate, one copy per hypothesis)
             lr_table = torch.tensor(lrs, dtype=torch.float32, device=dev)
             mtx_log = torch.zeros((n_it,) + tuple(mtx_gu.shape), dtype=mtx_gu.dtype, device=dev)
             del mtx_gu

@@ -94,6 +94,63 @@ __global__ void pose_matrix_bwd_kernel(const float* __restrict__ q, const float*
     dp[b * 3 + 0] = G[3]; dp[b * 3 + 1] = G[7]; dp[b * 3 + 2] = G[11];
 }
 
+// Object3D.forward's pose head (diffdope/diffdope.py:1085-1098): the seven per-hypothesis parameters, each its own [B] tensor, to
+// quat = (qx, qy, qz, qw) / |.| [B,4] and trans [B,3] -- stack, norm, divide, stack in the reference (and ~20 framework kernels in
+// the backward of those) as one kernel each way.  |q| = sqrt(((x x + y y) + z z) + w w), the components divided by it; the
+// backward is d q = (g - qn (qn . g)) / |q| written into rows 0-3 of d params [7,B], d trans into rows 4-6.
+__global__ void pose_pack_fwd_kernel(const float* __restrict__ qx, const float* __restrict__ qy, const float* __restrict__ qz,
+                                     const float* __restrict__ qw, const float* __restrict__ x, const float* __restrict__ y,
+                                     const float* __restrict__ z, int B, float* __restrict__ quat, float* __restrict__ trans)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float a = qx[b], bq = qy[b], c = qz[b], d = qw[b];
+    const float n = sqrtf(((a * a + bq * bq) + c * c) + d * d);
+    quat[b * 4 + 0] = a / n; quat[b * 4 + 1] = bq / n; quat[b * 4 + 2] = c / n; quat[b * 4 + 3] = d / n;
+    trans[b * 3 + 0] = x[b]; trans[b * 3 + 1] = y[b]; trans[b * 3 + 2] = z[b];
+}
+
+__global__ void pose_pack_bwd_kernel(const float* __restrict__ qx, const float* __restrict__ qy, const float* __restrict__ qz,
+                                     const float* __restrict__ qw, const float* __restrict__ dquat, const float* __restrict__ dtrans,
+                                     int B, float* __restrict__ dparams)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float a = qx[b], bq = qy[b], c = qz[b], d = qw[b];
+    const float n = sqrtf(((a * a + bq * bq) + c * c) + d * d);
+    const float u0 = a / n, u1 = bq / n, u2 = c / n, u3 = d / n;
+    const float g0 = dquat ? dquat[b * 4 + 0] : 0.f, g1 = dquat ? dquat[b * 4 + 1] : 0.f, g2 = dquat ? dquat[b * 4 + 2] : 0.f,
+                g3 = dquat ? dquat[b * 4 + 3] : 0.f;
+    const float dot = ((u0 * g0 + u1 * g1) + u2 * g2) + u3 * g3;
+    dparams[0 * (size_t)B + b] = (g0 - u0 * dot) / n;
+    dparams[1 * (size_t)B + b] = (g1 - u1 * dot) / n;
+    dparams[2 * (size_t)B + b] = (g2 - u2 * dot) / n;
+    dparams[3 * (size_t)B + b] = (g3 - u3 * dot) / n;
+    dparams[4 * (size_t)B + b] = dtrans ? dtrans[b * 3 + 0] : 0.f;
+    dparams[5 * (size_t)B + b] = dtrans ? dtrans[b * 3 + 1] : 0.f;
+    dparams[6 * (size_t)B + b] = dtrans ? dtrans[b * 3 + 2] : 0.f;
+}
+
+extern "C" int ddx_pose_pack_fwd(const float* qx, const float* qy, const float* qz, const float* qw, const float* x, const float* y,
+                                 const float* z, int B, float* quat, float* trans, void* stream)
+{
+    DDX_REQUIRE(qx && qy && qz && qw && x && y && z && quat && trans, DDX_E_NULL, "pose_pack_fwd: NULL pointer");
+    DDX_REQUIRE(B >= 1, DDX_E_SHAPE, "pose_pack_fwd: B=%d", B);
+    pose_pack_fwd_kernel<<<ddx_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(qx, qy, qz, qw, x, y, z, B, quat, trans);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_pose_pack_bwd(const float* qx, const float* qy, const float* qz, const float* qw, const float* dquat,
+                                 const float* dtrans, int B, float* dparams, void* stream)
+{
+    DDX_REQUIRE(qx && qy && qz && qw && dparams, DDX_E_NULL, "pose_pack_bwd: NULL pointer");
+    DDX_REQUIRE(B >= 1, DDX_E_SHAPE, "pose_pack_bwd: B=%d", B);
+    pose_pack_bwd_kernel<<<ddx_cdiv(B, 256), 256, 0, (hipStream_t)stream>>>(qx, qy, qz, qw, dquat, dtrans, B, dparams);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ddx_pose_matrix_fwd(const float* q, const float* p, int B, float* mtx, void* stream)
 {
     DDX_REQUIRE(q && p && mtx, DDX_E_NULL, "pose_matrix_fwd: NULL pointer");

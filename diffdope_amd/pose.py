@@ -29,6 +29,48 @@ class _pose_matrix_func(torch.autograd.Function):
         return dq, dp
 
 
+class _pose_pack_func(torch.autograd.Function):
+    """ddx_pose_pack_fwd / _bwd: (qx, qy, qz, qw, x, y, z), each [B] -> (quat [B,4] normalised, trans [B,3])."""
+
+    @staticmethod
+    def forward(ctx, qx, qy, qz, qw, x, y, z):
+        from . import _lib
+
+        prm = [t.contiguous() for t in (qx, qy, qz, qw, x, y, z)]
+        B = prm[0].shape[0]
+        quat = torch.empty((B, 4), dtype=torch.float32, device=prm[0].device)
+        trans = torch.empty((B, 3), dtype=torch.float32, device=prm[0].device)
+        _lib.check(_lib.load().ddx_pose_pack_fwd(*[_lib.ptr(t) for t in prm], B, _lib.ptr(quat), _lib.ptr(trans), _lib.stream_ptr()), "ddx_pose_pack_fwd")
+        ctx.save_for_backward(*prm[:4])
+        ctx.set_materialize_grads(False)
+        return quat, trans
+
+    @staticmethod
+    def backward(ctx, dquat, dtrans):
+        from . import _lib
+
+        q = ctx.saved_tensors
+        B = q[0].shape[0]
+        if dquat is None and dtrans is None:
+            return (None,) * 7
+        dquat = None if dquat is None else dquat.contiguous()
+        dtrans = None if dtrans is None else dtrans.contiguous()
+        d = torch.empty((7, B), dtype=torch.float32, device=q[0].device)
+        _lib.check(_lib.load().ddx_pose_pack_bwd(*[_lib.ptr(t) for t in q], _lib.ptr(dquat) if dquat is not None else None,
+                                                 _lib.ptr(dtrans) if dtrans is not None else None, B, _lib.ptr(d), _lib.stream_ptr()), "ddx_pose_pack_bwd")
+        return tuple(d.unbind(0))
+
+
+def quat_trans_from_parameters(qx, qy, qz, qw, x, y, z):
+    """Object3D.forward's pose head (diffdope.py:1085-1098): quat = stack(qx, qy, qz, qw) / its norm [B,4], trans = stack(x, y, z)
+    [B,3].  ROCm float32 [B] tensors take one kernel each way; anything else the torch expressions."""
+    prm = (qx, qy, qz, qw, x, y, z)
+    if all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 1 and t.shape == qx.shape for t in prm):
+        return _pose_pack_func.apply(*prm)
+    raw_q = torch.stack((qx, qy, qz, qw), dim=1)
+    return raw_q / raw_q.norm(dim=1, keepdim=True), torch.stack((x, y, z), dim=1)
+
+
 def matrix_batch_44_from_position_quat(q, p):
     """(batch,4) xyzw quaternion + (batch,3) translation -> (batch,4,4), differentiable.  Same row formulas as
     diffdope.py:57-80.  ROCm float32 tensors take one kernel each way (the reference's ~30 small ops, ~60 more in the

@@ -76,6 +76,13 @@ int ddx_xfm_bwd_full(const float* points, long long points_bstride, const float*
  * caller normalises, diffdope.py:1091), p [B,3] -> mtx [B,4,4] row-major; dmtx [B,4,4] -> dq [B,4], dp [B,3], fully written. */
 int ddx_pose_matrix_fwd(const float* q, const float* p, int B, float* mtx, void* stream);
 int ddx_pose_matrix_bwd(const float* q, const float* dmtx, int B, float* dq, float* dp, void* stream);
+/* Object3D.forward's pose head (diffdope.py:1085-1098): the seven parameters, each a [B] array of its own, to quat [B,4] = (qx, qy,
+ * qz, qw) / |.| and trans [B,3], one kernel each way; the backward writes d params [7,B] (rows qx qy qz qw x y z; dquat or dtrans
+ * NULL = zeros). */
+int ddx_pose_pack_fwd(const float* qx, const float* qy, const float* qz, const float* qw, const float* x, const float* y, const float* z,
+                      int B, float* quat, float* trans, void* stream);
+int ddx_pose_pack_bwd(const float* qx, const float* qy, const float* qz, const float* qw, const float* dquat, const float* dtrans, int B,
+                      float* dparams, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rasterize: replaces dr.rasterize(glctx, pos, tri, resolution) at diffdope.py:198-200 and its
