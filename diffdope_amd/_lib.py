@@ -77,6 +77,8 @@ _SIGNATURES = {
     "ddx_masked_l1_bwd": (_I, [_P, _P, _P, _I, _P, _I, _LL, _P, _P]),
     "ddx_masked_l1_bc3_fwd": (_I, [_P, _P, _P, _I, _LL, _P, _P, _P]),
     "ddx_masked_l1_bc3_bwd": (_I, [_P, _P, _P, _P, _I, _LL, _P, _P]),
+    "ddx_masked_l1_fwd_sum": (_I, [_P, _P, _P, _I, _I, _I, _LL, _P, _P, _P, _P, _P]),
+    "ddx_masked_l1_bwd_sum": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _LL, _P, _P]),
     "ddx_gbuffer_fwd_rows_c": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "ddx_silhouette_fwd_rows_c": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "ddx_silhouette_bwd_rows_c": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),

@@ -108,25 +108,43 @@ def dist_batch_lr(tensor, learning_rates, channels=[1, 2, 3]):
     return torch.mean(tensor, channels) * learning_rates
 
 
+def _lr_weights(ddope, weight):
+    """learning_rates * weight / B: with it, (v * learning_rates).mean() * weight (dist_batch_lr and the term's weight, diffdope.py:
+    534-544) is one weighted sum of v, which masked_l1_mean folds into its own launches.  Cached per (learning_rates, weight)."""
+    lr = ddope.learning_rates
+    tag = (lr.data_ptr(), lr._version, tuple(lr.shape), lr.device)
+    cache = getattr(ddope, "_lr_weights_cache", None)
+    if cache is None or cache[0] != tag:
+        cache = (tag, {})
+        ddope._lr_weights_cache = cache
+    if float(weight) not in cache[1]:
+        cache[1][float(weight)] = (lr.detach().float() * (float(weight) / lr.shape[0])).contiguous()
+    return cache[1][float(weight)]
+
+
 def l1_rgb_with_mask(ddope):
-    """diffdope.py:547-562 (image-space part fused for ROCm tensors: render.masked_l1_mean)."""
-    v = masked_l1_mean(ddope.renders["rgb"], ddope.gt_tensors["rgb"], ddope.gt_tensors["segmentation"])
-    ddope.add_loss_value("rgb", v.detach() * ddope.cfg.losses.weight_rgb)
-    return (v * ddope.learning_rates).mean() * ddope.cfg.losses.weight_rgb
+    """diffdope.py:547-562 (image-space part and the weighting by the learning rates fused for ROCm tensors: render.masked_l1_mean)."""
+    w = ddope.cfg.losses.weight_rgb
+    v, term = masked_l1_mean(ddope.renders["rgb"], ddope.gt_tensors["rgb"], ddope.gt_tensors["segmentation"], batch_weights=_lr_weights(ddope, w))
+    ddope.add_loss_value("rgb", v.detach() * w)
+    return term
 
 
 def l1_depth_with_mask(ddope):
     """diffdope.py:565-580."""
-    v = masked_l1_mean(ddope.renders["depth"], ddope.gt_tensors["depth"], ddope.gt_tensors["segmentation"], mask_channel0=True)
-    ddope.add_loss_value("depth", v.detach() * ddope.cfg.losses.weight_depth)
-    return (v * ddope.learning_rates).mean() * ddope.cfg.losses.weight_depth
+    w = ddope.cfg.losses.weight_depth
+    v, term = masked_l1_mean(ddope.renders["depth"], ddope.gt_tensors["depth"], ddope.gt_tensors["segmentation"], mask_channel0=True,
+                             batch_weights=_lr_weights(ddope, w))
+    ddope.add_loss_value("depth", v.detach() * w)
+    return term
 
 
 def l1_mask(ddope):
     """diffdope.py:583-613."""
-    v = masked_l1_mean(ddope.renders["mask"], ddope.gt_tensors["segmentation"])
-    ddope.add_loss_value("mask_selection", v.detach() * ddope.cfg.losses.weight_mask)
-    return (v * ddope.learning_rates).mean() * ddope.cfg.losses.weight_mask
+    w = ddope.cfg.losses.weight_mask
+    v, term = masked_l1_mean(ddope.renders["mask"], ddope.gt_tensors["segmentation"], batch_weights=_lr_weights(ddope, w))
+    ddope.add_loss_value("mask_selection", v.detach() * w)
+    return term
 
 
 _SOBEL = None
@@ -795,13 +813,14 @@ class DiffDope:
         result = self.object3d()
         mtx_gu = matrix_batch_44_from_position_quat(p=result["trans"], q=result["quat"])
         self.renders = self._render(mtx_gu, outputs=self._loop_outputs())
-        loss = torch.zeros(1, device=mtx_gu.device)
+        loss = None  # (the reference starts from torch.zeros(1): a fill, an addition and a reshaping in the backward for nothing)
         for loss_function in self.loss_functions:
             l = loss_function(self)
             if l is None:
                 continue
-            loss = loss + l
-        loss.backward()
+            loss = l if loss is None else loss + l
+        if loss is not None:
+            loss.backward()
         if torch.is_tensor(lr):
             with torch.no_grad():  # (two launches for the seven parameters; p + (-1) (g lr), the rounding of the eager step)
                 prms = [prm for prm in self.object3d.parameters() if prm.grad is not None]

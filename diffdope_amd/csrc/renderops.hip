@@ -465,12 +465,43 @@ __global__ __launch_bounds__(ML1_CHUNKS) void masked_l1_final_kernel(const float
     if (threadIdx.x == 0) out[b] = __fdiv_rn(red[0] + red[1], (float)N);
 }
 
+// ... and the batch-weighted sum of the rows in the same launch (ddx_masked_l1_fwd_sum): sum_out[0] = sum_b out[b] * bw[b], the
+// built-in losses' (v * learning_rates).mean() * weight (diffdope.py:534-544, :562, :580, :613) with bw = learning_rates * weight /
+// B.  One workgroup; wave w takes rows w, w + 4, ... in order, the four wave sums are added pairwise: a fixed order.
+__global__ __launch_bounds__(256) void masked_l1_final_sum_kernel(const float* __restrict__ partial, long long N, const float* __restrict__ bw,
+                                                                  int B, float* __restrict__ out, float* __restrict__ sum_out)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        // (the row sum in masked_l1_final_kernel's order: lanes 0-63 and 64-127 of its workgroup, then the two halves)
+        const float lo = wave_sum(partial[(size_t)b * ML1_CHUNKS + lane]), hi = wave_sum(partial[(size_t)b * ML1_CHUNKS + 64 + lane]);
+        const float v = __fdiv_rn(lo + hi, (float)N);
+        if (lane == 0) out[b] = v;
+        acc += v * bw[b];
+    }
+    __shared__ float red[4];
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sum_out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the factor of row b in a backward pass: d out[b] (gout, may be NULL) plus d sum * bw[b] (gsum, may be NULL), over the row's N terms
+static __device__ __forceinline__ float ml1_row_scale(const float* __restrict__ gout, const float* __restrict__ gsum,
+                                                      const float* __restrict__ bw, int b, float n)
+{
+    float g = gout ? gout[b] : 0.f;
+    if (gsum) g = gout ? g + gsum[0] * bw[b] : gsum[0] * bw[b];
+    return g / n;
+}
+
 __global__ __launch_bounds__(256) void masked_l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ m, int m_stride, const float* __restrict__ gout,
-                                                            long long N, float* __restrict__ dx)
+                                                            long long N, float* __restrict__ dx, const float* __restrict__ gsum = nullptr,
+                                                            const float* __restrict__ bw = nullptr)
 {
     const int b = blockIdx.y;
-    const float scale = gout[b] / (float)N;
+    const float scale = ml1_row_scale(gout, gsum, bw, b, (float)N);
     const float* xb = x + (size_t)b * N;
     float* db = dx + (size_t)b * N;
 #pragma unroll
@@ -526,10 +557,11 @@ __global__ __launch_bounds__(256) void masked_l1_partial4_kernel(const float* __
 template <bool STRIDE1>
 __global__ __launch_bounds__(256) void masked_l1_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ m, int m_stride, const float* __restrict__ gout,
-                                                             long long N, float* __restrict__ dx)
+                                                             long long N, float* __restrict__ dx, const float* __restrict__ gsum = nullptr,
+                                                             const float* __restrict__ bw = nullptr)
 {
     const int b = blockIdx.y;
-    const float scale = gout[b] / (float)N;
+    const float scale = ml1_row_scale(gout, gsum, bw, b, (float)N);
     const float* xb = x + (size_t)b * N;
     float* db = dx + (size_t)b * N;
     const long long N4 = N >> 2;
@@ -602,10 +634,11 @@ __global__ __launch_bounds__(256) void masked_l1_bc3_partial_kernel(const float*
 template <bool VEC>
 __global__ __launch_bounds__(256) void masked_l1_bc3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                 const float* __restrict__ m, const float* __restrict__ gout, long long P,
-                                                                float* __restrict__ dx)
+                                                                float* __restrict__ dx, const float* __restrict__ gsum = nullptr,
+                                                                const float* __restrict__ bw = nullptr)
 {
     const int b = blockIdx.y;
-    const float scale = gout[b] / (float)(P * 3);
+    const float scale = ml1_row_scale(gout, gsum, bw, b, (float)(P * 3));
     const float* xb = x + (size_t)b * P;
     float* db = dx + (size_t)b * P;
     const long long G = VEC ? P >> 2 : P;
@@ -704,6 +737,46 @@ extern "C" int ddx_masked_l1_bc3_bwd(const float* x, const float* y, const float
     DDX_REQUIRE(B >= 1 && B <= 65535 && P >= 1 && P < (1ll << 38), DDX_E_SHAPE, "masked_l1_bc3_bwd: bad shape B=%d P=%lld", B, P);
     if (ml1_vec_ok(x, y, m, 1, dx, P)) masked_l1_bc3_bwd_kernel<true><<<pix_grid2(P >> 2, B), 256, 0, (hipStream_t)stream>>>(x, y, m, gout, P, dx);
     else masked_l1_bc3_bwd_kernel<false><<<pix_grid2(P, B), 256, 0, (hipStream_t)stream>>>(x, y, m, gout, P, dx);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+// The loss term of a built-in loss in two launches each way (see masked_l1_final_sum_kernel): out [B] as ddx_masked_l1_fwd (bc3 == 0: x
+// [B,N], y [N], m with m_stride) or ddx_masked_l1_bc3_fwd (bc3 != 0: x [B,N], y and m [N,3]) -- the same bits --, and sum_out[0] =
+// sum_b out[b] * bw[b].  Backward: d x from d out (gout [B] or NULL) and d sum (gsum [1] or NULL; then bw [B]) in ONE launch.
+extern "C" int ddx_masked_l1_fwd_sum(const float* x, const float* y, const float* m, int m_stride, int bc3, int B, long long N, const float* bw,
+                                     float* partial, float* out, float* sum_out, void* stream)
+{
+    DDX_REQUIRE(x && y && partial && out && bw && sum_out, DDX_E_NULL, "masked_l1_fwd_sum: NULL pointer");
+    DDX_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && N < (1ll << 38) && m_stride >= 1, DDX_E_SHAPE, "masked_l1_fwd_sum: bad shape B=%d N=%lld stride=%d", B, N, m_stride);
+    hipStream_t s = (hipStream_t)stream;
+    if (bc3) {
+        if (ml1_vec_ok(x, y, m, 1, nullptr, N)) masked_l1_bc3_partial_kernel<true><<<dim3(ML1_CHUNKS, B), 256, 0, s>>>(x, y, m, N, partial);
+        else masked_l1_bc3_partial_kernel<false><<<dim3(ML1_CHUNKS, B), 256, 0, s>>>(x, y, m, N, partial);
+    } else if (ml1_vec_ok(x, y, m, m_stride, nullptr, N)) {
+        if (!m || m_stride == 1) masked_l1_partial4_kernel<true><<<dim3(ML1_CHUNKS, B), 256, 0, s>>>(x, y, m, m_stride, N, partial);
+        else masked_l1_partial4_kernel<false><<<dim3(ML1_CHUNKS, B), 256, 0, s>>>(x, y, m, m_stride, N, partial);
+    } else
+        masked_l1_partial_kernel<<<dim3(ML1_CHUNKS, B), 256, 0, s>>>(x, y, m, m_stride, N, partial);
+    masked_l1_final_sum_kernel<<<1, 256, 0, s>>>(partial, bc3 ? N * 3 : N, bw, B, out, sum_out);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ddx_masked_l1_bwd_sum(const float* x, const float* y, const float* m, int m_stride, int bc3, const float* gout, const float* gsum,
+                                     const float* bw, int B, long long N, float* dx, void* stream)
+{
+    DDX_REQUIRE(x && y && dx && (gout || gsum) && (!gsum || bw), DDX_E_NULL, "masked_l1_bwd_sum: NULL pointer");
+    DDX_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && N < (1ll << 38) && m_stride >= 1, DDX_E_SHAPE, "masked_l1_bwd_sum: bad shape B=%d N=%lld", B, N);
+    hipStream_t s = (hipStream_t)stream;
+    if (bc3) {
+        if (ml1_vec_ok(x, y, m, 1, dx, N)) masked_l1_bc3_bwd_kernel<true><<<pix_grid2(N >> 2, B), 256, 0, s>>>(x, y, m, gout, N, dx, gsum, bw);
+        else masked_l1_bc3_bwd_kernel<false><<<pix_grid2(N, B), 256, 0, s>>>(x, y, m, gout, N, dx, gsum, bw);
+    } else if (ml1_vec_ok(x, y, m, m_stride, dx, N)) {
+        if (!m || m_stride == 1) masked_l1_bwd4_kernel<true><<<pix_grid2(N >> 2, B), 256, 0, s>>>(x, y, m, m_stride, gout, N, dx, gsum, bw);
+        else masked_l1_bwd4_kernel<false><<<pix_grid2(N >> 2, B), 256, 0, s>>>(x, y, m, m_stride, gout, N, dx, gsum, bw);
+    } else
+        masked_l1_bwd_kernel<<<pix_grid2(N, B), 256, 0, s>>>(x, y, m, m_stride, gout, N, dx, gsum, bw);
     DDX_LAUNCH_CHECK();
     return 0;
 }

@@ -437,6 +437,40 @@ class _masked_l1_bc3_func(torch.autograd.Function):
         return dx, None, None
 
 
+class _masked_l1_sum_func(torch.autograd.Function):
+    """(out [B], sum_b out[b] bw[b]) of ddx_masked_l1_fwd_sum / _bwd_sum: x [B,...] (bc3: its one stored channel), y, m as the two
+    functions above take them."""
+
+    @staticmethod
+    def forward(ctx, x, y, m, m_stride, bc3, bw):
+        B = x.shape[0]
+        N = x[0].numel()
+        out = torch.empty((B,), dtype=torch.float32, device=x.device)
+        tot = torch.empty((), dtype=torch.float32, device=x.device)
+        partial = torch.empty((B, 128), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().ddx_masked_l1_fwd_sum(_lib.ptr(x), _lib.ptr(y), _lib.ptr(m) if m is not None else None, int(m_stride), int(bc3), B, N,
+                                                     _lib.ptr(bw), _lib.ptr(partial), _lib.ptr(out), _lib.ptr(tot), _lib.stream_ptr()), "ddx_masked_l1_fwd_sum")
+        ctx.save_for_backward(x, y, m, bw)
+        ctx.m_stride, ctx.bc3 = int(m_stride), int(bc3)
+        ctx.set_materialize_grads(False)
+        return out, tot
+
+    @staticmethod
+    def backward(ctx, gout, gtot):
+        x, y, m, bw = ctx.saved_tensors
+        if gout is None and gtot is None:
+            return (None,) * 6
+        B = x.shape[0]
+        N = x[0].numel()
+        gout = None if gout is None else _f32c(gout, "gout")
+        gtot = None if gtot is None else _f32c(gtot, "gtot")
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().ddx_masked_l1_bwd_sum(_lib.ptr(x), _lib.ptr(y), _lib.ptr(m) if m is not None else None, ctx.m_stride, ctx.bc3,
+                                                     _lib.ptr(gout) if gout is not None else None, _lib.ptr(gtot) if gtot is not None else None,
+                                                     _lib.ptr(bw), B, N, _lib.ptr(dx), _lib.stream_ptr()), "ddx_masked_l1_bwd_sum")
+        return dx, None, None, None, None, None
+
+
 def _one_channel_base(x):
     """x is `base.expand(..., 3)` of a contiguous base [..., 1] (render_texture_batch's mask): the base, else None.  Handing the
     BASE to the loss kernel keeps autograd off the expanded view (whose backward would materialise and sum the three channels)."""
@@ -449,11 +483,14 @@ def _one_channel_base(x):
     return b
 
 
-def masked_l1_mean(x, y, mask=None, mask_channel0=False):
+def masked_l1_mean(x, y, mask=None, mask_channel0=False, batch_weights=None):
     """mean over all but the batch axis of |(x - y) * mask| -> [B]: the image-space part of the reference's built-in losses
     (diffdope.py:547-613) as ONE forward and ONE backward kernel for ROCm tensors.  x [B,...]; y and mask describe ONE observed
     image (shape x.shape[1:], or batched views of it with batch stride 0, or a batch of size 1); mask_channel0: mask is [...,3] and
-    its channel 0 masks an x without channel axis (l1_depth_with_mask).  Other inputs take the torch expression."""
+    its channel 0 masks an x without channel axis (l1_depth_with_mask).  Other inputs take the torch expression.
+    batch_weights [B] (float32, no gradient): returns (v, (v * batch_weights).sum()) -- with batch_weights = learning_rates * weight
+    / B the second is what a built-in loss returns, (v * learning_rates).mean() * weight (diffdope.py:534-544, :562) -- from the
+    same two launches, and its backward is ONE launch instead of the four small ones of that expression plus the loss kernel."""
     def one(t, rank):
         # strip a broadcast batch axis: `rank` is the rank the tensor has WITH a batch axis
         if t is None:
@@ -464,15 +501,25 @@ def masked_l1_mean(x, y, mask=None, mask_channel0=False):
     y1, m1 = one(y, x.dim()), one(mask, x.dim() + 1 if mask_channel0 else x.dim())
     tail = tuple(x.shape[1:])
     xb = _one_channel_base(x) if (x.is_cuda and x.dtype == torch.float32 and not mask_channel0) else None
+    bw = None
+    if batch_weights is not None and x.is_cuda and batch_weights.dtype == torch.float32 and tuple(batch_weights.shape) == (x.shape[0],):
+        bw = batch_weights.detach().contiguous()
     if (xb is not None and tuple(y1.shape) == tail and y1.dtype == torch.float32
             and (m1 is None or (m1.dtype == torch.float32 and tuple(m1.shape) == tail))):
-        return _masked_l1_bc3_func.apply(xb, y1.contiguous(), None if m1 is None else m1.contiguous())
+        if bw is not None:
+            return _masked_l1_sum_func.apply(xb, y1.contiguous(), None if m1 is None else m1.contiguous(), 1, 1, bw)
+        v = _masked_l1_bc3_func.apply(xb, y1.contiguous(), None if m1 is None else m1.contiguous())
+        return v if batch_weights is None else (v, (v * batch_weights).sum())
     fusable = (x.is_cuda and x.dtype == torch.float32 and tuple(y1.shape) == tail and y1.dtype == torch.float32
                and (m1 is None or (m1.dtype == torch.float32 and tuple(m1.shape) == (tail + (3,) if mask_channel0 else tail))))
     if not fusable:
         mk = 1.0 if mask is None else (mask[..., 0] if mask_channel0 else mask)
-        return torch.mean(torch.abs((x - y) * mk), tuple(range(1, x.dim())))
-    return _masked_l1_func.apply(x.contiguous(), y1.contiguous(), None if m1 is None else m1.contiguous(), 3 if mask_channel0 else 1)
+        v = torch.mean(torch.abs((x - y) * mk), tuple(range(1, x.dim())))
+    elif bw is not None:
+        return _masked_l1_sum_func.apply(x.contiguous(), y1.contiguous(), None if m1 is None else m1.contiguous(), 3 if mask_channel0 else 1, 0, bw)
+    else:
+        v = _masked_l1_func.apply(x.contiguous(), y1.contiguous(), None if m1 is None else m1.contiguous(), 3 if mask_channel0 else 1)
+    return v if batch_weights is None else (v, (v * batch_weights).sum())
 
 
 class _gbuffer_func(torch.autograd.Function):
@@ -574,7 +621,9 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
     H, W = (resolution if isinstance(resolution, (list, tuple)) else (resolution, resolution))
     faces = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
     # clip-space vertices and visibility (:195-200)
-    clip = dd_ops.xfm_points(pos.contiguous(), torch.matmul(proj_cam, mtx))
+    # (a batch-shared mesh -- one copy behind a stride-0 batch axis -- goes in as [1,V,3]: no B copies of it are made first)
+    pos_1 = _one_copy(pos) if not pos.requires_grad else None
+    clip = dd_ops.xfm_points(pos_1[None].contiguous() if pos_1 is not None else pos.contiguous(), torch.matmul(proj_cam, mtx))
     textured = vtx_color is None
     attrs = (pos, uv, tex) if textured else (pos, vtx_color)
     uv_faces = None if not textured else (uv_idx[0] if uv_idx.dim() == 3 else uv_idx)

@@ -212,6 +212,14 @@ int ddx_masked_l1_bwd(const float* x, const float* y, const float* m, int m_stri
  * out[b] = mean over the 3 P terms |(x[b,i] - y[i,c]) * m[i,c]|; dx[b,i] = sum over c of sign(.) * m[i,c] * gout[b] / (3 P). */
 int ddx_masked_l1_bc3_fwd(const float* x, const float* y, const float* m, int B, long long P, float* partial, float* out, void* stream);
 int ddx_masked_l1_bc3_bwd(const float* x, const float* y, const float* m, const float* gout, int B, long long P, float* dx, void* stream);
+/* ... and the batch-weighted sum of the rows in the same launches: what a built-in loss returns, (out * learning_rates).mean() * weight
+ * (diffdope.py:534-544 dist_batch_lr, :562, :580, :613), is sum_b out[b] * bw[b] with bw = learning_rates * weight / B.  bc3 = 0: the
+ * operands of ddx_masked_l1_fwd; bc3 != 0: those of ddx_masked_l1_bc3_fwd (N = P).  out [B]: the same bits as those calls;
+ * sum_out [1].  Backward: gout [B] (d out) or NULL, gsum [1] (d sum) or NULL -- not both NULL --, one launch. */
+int ddx_masked_l1_fwd_sum(const float* x, const float* y, const float* m, int m_stride, int bc3, int B, long long N, const float* bw,
+                          float* partial, float* out, float* sum_out, void* stream);
+int ddx_masked_l1_bwd_sum(const float* x, const float* y, const float* m, int m_stride, int bc3, const float* gout, const float* gsum,
+                          const float* bw, int B, long long N, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused refinement engine: the body of DiffDope.run_optimization (diffdope.py:1656-1714) for the

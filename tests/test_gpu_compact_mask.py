@@ -145,3 +145,41 @@ def test_the_api_loop_renders_what_its_losses_read():
     np.testing.assert_allclose(a.object3d.params_tensor().cpu().numpy(), b.object3d.params_tensor().cpu().numpy(), rtol=0, atol=1e-5)
     c = _ddope(sc, ("rgb", "mask"), B)
     assert c._loop_outputs() is None  # (a colour term: everything)
+
+
+@pytest.mark.parametrize("H,W", [(37, 53), (36, 52)])
+def test_batch_weighted_sum_of_masked_l1(H, W):
+    """masked_l1_mean(..., batch_weights=bw) -> (v, sum_b v[b] bw[b]) (ddx_masked_l1_fwd_sum / _bwd_sum): v has the bits of the call
+    without weights; the sum and the gradient -- through the sum alone, as the built-in losses use it, and through both outputs --
+    match the reference's expression (v * learning_rates).mean() * weight (diffdope.py:534-544, :562, :580, :613); for the
+    colour-shaped, the depth-shaped (channel-0 mask) and the one-stored-channel operands."""
+    from diffdope_amd.render import masked_l1_mean
+
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, weight = 6, 0.7
+    lr = torch.rand(B, device="cuda", generator=g) + 0.5
+    bw = lr * (weight / B)
+    seg = (torch.rand(1, H, W, 3, device="cuda", generator=g) > 0.4).float()
+    extra = torch.rand(B, device="cuda", generator=g)
+    cases = []
+    x = torch.randn((B, H, W, 3), device="cuda", generator=g, requires_grad=True)
+    cases.append((x, x, torch.randn((1, H, W, 3), device="cuda", generator=g).expand(B, H, W, 3), seg.expand(B, H, W, 3), False))
+    x = torch.randn((B, H, W), device="cuda", generator=g, requires_grad=True)
+    cases.append((x, x, torch.randn((1, H, W), device="cuda", generator=g).expand(B, H, W), seg.expand(B, H, W, 3), True))
+    base = torch.rand((B, H, W, 1), device="cuda", generator=g, requires_grad=True)
+    cases.append((base, base.expand(B, H, W, 3), seg.expand(B, H, W, 3), None, False))
+    for leaf, xin, y, m, ch0 in cases:
+        v0 = masked_l1_mean(xin, y, m, mask_channel0=ch0)
+        v, s = masked_l1_mean(xin, y, m, mask_channel0=ch0, batch_weights=bw)
+        assert torch.equal(v0.detach(), v.detach()) and s.dim() == 0
+        mk = 1.0 if m is None else (m[..., 0] if ch0 else m)
+        ref_v = torch.mean(torch.abs((xin - y) * mk), tuple(range(1, xin.dim())))
+        ref_s = (ref_v * lr).mean() * weight
+        np.testing.assert_allclose(float(s), float(ref_s), rtol=3e-6)
+        (g_ref,) = torch.autograd.grad(ref_s, leaf, retain_graph=True)
+        (g_out,) = torch.autograd.grad(s, leaf, retain_graph=True)
+        tol = dict(rtol=3e-6, atol=1e-6 * float(g_ref.abs().max()))
+        np.testing.assert_allclose(g_out.cpu().numpy(), g_ref.cpu().numpy(), **tol)
+        (g_ref2,) = torch.autograd.grad(ref_s + (ref_v * extra).sum(), leaf)
+        (g_out2,) = torch.autograd.grad(s + (v * extra).sum(), leaf)
+        np.testing.assert_allclose(g_out2.cpu().numpy(), g_ref2.cpu().numpy(), rtol=3e-6, atol=1e-6 * float(g_ref2.abs().max()))
