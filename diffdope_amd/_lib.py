@@ -57,6 +57,7 @@ _SIGNATURES = {
     "ddx_rasterize_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "ddx_rasterize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
     "ddx_rasterize_fwd_rows": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _I, _P]),
+    "ddx_rasterize_fwd_rows_clean": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _I, _I, _P]),
     "ddx_rasterize_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ddx_interpolate_fwd": (_I, [_P, _LL, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "ddx_interpolate_bwd": (_I, [_P, _LL, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -628,12 +628,12 @@ class DiffDope:
 
     def _loop_outputs(self):
         """What the loss functions of this run read from self.renders: known for the built-in ones (None = everything: a user
-        function may read anything).  Without a colour loss the loop's renders carry no "rgb" (render_texture_batch(outputs=...));
+        function may read anything).  An image no term reads is not rendered in the loop (render_texture_batch(outputs=...));
         the complete images of the last iteration are rendered once more when the loop is done, as the reference leaves them."""
         if not self.loss_functions or not all(f in _BUILTIN_LOSSES for f in self.loss_functions):
             return None
-        need = {_BUILTIN_LOSSES[f] for f in self.loss_functions}
-        return None if need & {"rgb", "edge"} else tuple(sorted(need))
+        need = {"rgb" if _BUILTIN_LOSSES[f] == "edge" else _BUILTIN_LOSSES[f] for f in self.loss_functions}
+        return None if need == {"rgb", "depth", "mask"} else tuple(sorted(need))
 
     def _render_cpu(self, mtx_cpu):
         with torch.no_grad():

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void compact_big_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // emit nvdiffrast-style rast [B,H,W,4]
 __global__ __launch_bounds__(256) void emit_kernel(const float* __restrict__ pos, const int* __restrict__ tri, int V,
-                                                   int B, int H, int W, RasterScratch L, float* __restrict__ rast, int restrict_rows)
+                                                   int B, int H, int W, RasterScratch L, float* __restrict__ rast, int restrict_rows,
+                                                   int restore)
 {
     // blockIdx.y = hypothesis, 1024 consecutive pixels of it per workgroup: 32-bit pixel arithmetic (H, W <= 4096)
     const int b = blockIdx.y, HW = H * W;
@@ -227,6 +228,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const float* __restrict__ pos
         const int p = blockIdx.x * 1024 + k * 256 + threadIdx.x;
         const int py = p / W, px = p - py * W;
         keys[k] = p < HW ? L.zbuf[(size_t)b * L.zper + zaddr(px, py, L.zwb)] : ~0ull;
+        // (restore: every entry a triangle won is put back to "empty" once read -- a few per cent of the frame --, so the next call on
+        // this scratch needs no 8-bytes-per-pixel clear of the whole buffer: ddx_rasterize_fwd_rows_clean)
+        if (restore && keys[k] != ~0ull) L.zbuf[(size_t)b * L.zper + zaddr(px, py, L.zwb)] = ~0ull;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -283,6 +287,16 @@ extern "C" int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, in
 extern "C" int ddx_rasterize_fwd_rows(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W, void* scratch,
                                       size_t scratch_bytes, float* rast, int32_t* row_range, int emit_all, void* stream)
 {
+    return ddx_rasterize_fwd_rows_clean(pos, tri, B, V, T, H, W, scratch, scratch_bytes, rast, row_range, emit_all, 0, stream);
+}
+
+// ... for a caller that keeps its scratch from call to call (a loop over iterations): zbuf_clean != 0 says that the depth buffer inside
+// `scratch` is all-empty -- as THIS function leaves it: the pass that reads it puts every entry it finds back --, and the clear of
+// 8 bytes per pixel and hypothesis (157 MB at 64 x 640x480, 27 us) is left out.  The first call on a scratch, a call after one of the
+// other entry points, after a change of (B, V, T, H, W) or after an error passes 0.  The same rast and row_range either way.
+extern "C" int ddx_rasterize_fwd_rows_clean(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W, void* scratch,
+                                            size_t scratch_bytes, float* rast, int32_t* row_range, int emit_all, int zbuf_clean, void* stream)
+{
     DDX_REQUIRE(pos && tri && scratch && rast, DDX_E_NULL, "rasterize_fwd: NULL pointer");
     DDX_REQUIRE(B >= 1 && B <= 65535 && V >= 1 && T >= 1 && H >= 1 && W >= 1 && H <= 4096 && W <= 4096, DDX_E_SHAPE,
                 "rasterize_fwd: bad shape B=%d V=%d T=%d H=%d W=%d", B, V, T, H, W);
@@ -293,9 +307,10 @@ extern "C" int ddx_rasterize_fwd_rows(const float* pos, const int32_t* tri, int 
     DDX_REQUIRE(scratch_bytes >= need, DDX_E_SCRATCH, "rasterize_fwd: scratch %zu < required %zu bytes", scratch_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     if (int e = raster_snap(pos, B, V, H, W, L, s)) return e;
-    if (int e = raster_run(pos, tri, B, V, T, H, W, L, s, true, nullptr)) return e;
+    if (zbuf_clean) DDX_HIP(hipMemsetAsync(L.counters, 0, L.zero_bytes, s));
+    if (int e = raster_run(pos, tri, B, V, T, H, W, L, s, !zbuf_clean, nullptr)) return e;
     const int restrict_rows = (row_range && !emit_all) ? 1 : 0;
-    emit_kernel<<<dim3((unsigned)((H * W + 1023) / 1024), (unsigned)B), 256, 0, s>>>(pos, tri, V, B, H, W, L, rast, restrict_rows);
+    emit_kernel<<<dim3((unsigned)((H * W + 1023) / 1024), (unsigned)B), 256, 0, s>>>(pos, tri, V, B, H, W, L, rast, restrict_rows, 1);
     DDX_LAUNCH_CHECK();
     // the rows a hypothesis draws into, for the consumers of `rast` (the scratch is overwritten by the next call: the caller keeps a copy)
     if (row_range) DDX_HIP(hipMemcpyAsync(row_range, L.row_range, (size_t)B * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));

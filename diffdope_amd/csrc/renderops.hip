@@ -842,11 +842,13 @@ __global__ __launch_bounds__(256) void gbuffer_fwd_kernel(const float* __restric
             }
         }
         // depth = -(mtx . [gb; 1])_z, the k-ordered fma chain of xfm_points (a background pixel interpolates to the origin: -mtx[2][3])
-        float zc = __fmaf_rn(M[8], gb[0], 0.f);
-        zc = __fmaf_rn(M[9], gb[1], zc);
-        zc = __fmaf_rn(M[10], gb[2], zc);
-        zc = __fmaf_rn(M[11], 1.0f, zc);
-        depth[i] = -zc;
+        if (depth) {
+            float zc = __fmaf_rn(M[8], gb[0], 0.f);
+            zc = __fmaf_rn(M[9], gb[1], zc);
+            zc = __fmaf_rn(M[10], gb[2], zc);
+            zc = __fmaf_rn(M[11], 1.0f, zc);
+            depth[i] = -zc;
+        }
         const float k = r.w < 0.f ? 0.f : (r.w > 1.f ? 1.f : r.w);  // clamp(rast[..., -1:], 0, 1) (diffdope.py:228,231)
         if (rgb) { rgb[i * 3 + 0] = col[0] * k; rgb[i * 3 + 1] = col[1] * k; rgb[i * 3 + 2] = col[2] * k; }
         // (the three channels of interpolate(ones) are one number: cover_c == 1 keeps one copy of it, see ddx_gbuffer_fwd_rows_c)
@@ -987,7 +989,7 @@ extern "C" int ddx_gbuffer_fwd_rows(const float* rast, const float* mtx, const f
                                     const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
                                     const int32_t* row_range, float* rgb, float* depth, float* cover, void* stream)
 {
-    DDX_REQUIRE(rgb, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
+    DDX_REQUIRE(rgb && depth, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
     return ddx_gbuffer_fwd_rows_c(rast, mtx, pos, tri, uv, tex, Th, Tw, vtx_color, B, V, T, H, W, row_range, rgb, depth, cover, 3, stream);
 }
 
@@ -995,7 +997,7 @@ extern "C" int ddx_gbuffer_fwd_rows_c(const float* rast, const float* mtx, const
                                       const float* tex, int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W,
                                       const int32_t* row_range, float* rgb, float* depth, float* cover, int cover_channels, void* stream)
 {
-    DDX_REQUIRE(rast && mtx && pos && tri && depth && cover, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
+    DDX_REQUIRE(rast && mtx && pos && tri && cover, DDX_E_NULL, "gbuffer_fwd: NULL pointer");
     DDX_REQUIRE(!rgb || (uv && tex && Th >= 1 && Tw >= 1) || vtx_color, DDX_E_NULL, "gbuffer_fwd: needs (uv, tex) or vtx_color");
     DDX_REQUIRE(B >= 1 && V >= 1 && T >= 1 && H >= 1 && W >= 1, DDX_E_SHAPE, "gbuffer_fwd: bad shape");
     DDX_REQUIRE(cover_channels == 1 || cover_channels == 3, DDX_E_SHAPE, "gbuffer_fwd: cover_channels=%d (1 or 3)", cover_channels);

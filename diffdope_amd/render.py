@@ -95,6 +95,7 @@ class RasterizeContext:
         self.device = device
         self._scratch = None
         self._key = None
+        self._zbuf_clean = False  # (the depth buffer inside the scratch is all-empty: left so by ddx_rasterize_fwd_rows_clean)
 
     def scratch(self, B, V, T, H, W, device):
         key = (B, V, T, H, W, str(device))
@@ -104,6 +105,7 @@ class RasterizeContext:
                 raise RuntimeError(f"rasterize: unsupported shape B={B} V={V} T={T} H={H} W={W} (H,W <= 4096)")
             self._scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
             self._key = key
+            self._zbuf_clean = False
         off = (-self._scratch.data_ptr()) % 256
         return self._scratch[off:], self._scratch.numel() - off
 
@@ -123,6 +125,7 @@ class _rasterize_func(torch.autograd.Function):
         lib = glctx.lib
         rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device)
         scratch, nbytes = glctx.scratch(B, V, T, H, W, pos.device)
+        glctx._zbuf_clean = False
         _lib.check(lib.ddx_rasterize_fwd(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes,
                                          _lib.ptr(rast), _lib.stream_ptr()), "ddx_rasterize_fwd")
         ctx.save_for_backward(pos, tri, rast)
@@ -151,8 +154,12 @@ def _rasterize_rows(glctx, pos, tri, resolution, emit_all):
     rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device)
     rows = torch.empty((B, 2), dtype=torch.int32, device=pos.device)  # (a copy: the scratch is overwritten by the context's next call)
     scratch, nbytes = glctx.scratch(B, V, T, H, W, pos.device)
-    _lib.check(glctx.lib.ddx_rasterize_fwd_rows(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes, _lib.ptr(rast),
-                                                _lib.ptr(rows), int(bool(emit_all)), _lib.stream_ptr()), "ddx_rasterize_fwd_rows")
+    # (the context keeps its scratch from call to call: after the first one the depth buffer in it needs no clear, the pass that reads
+    # it puts back what it finds -- 27 us of an iteration of 64 x 640x480; an error leaves the flag down)
+    clean, glctx._zbuf_clean = glctx._zbuf_clean, False
+    _lib.check(glctx.lib.ddx_rasterize_fwd_rows_clean(_lib.ptr(pos), _lib.ptr(tri), B, V, T, H, W, _lib.ptr(scratch), nbytes, _lib.ptr(rast),
+                                                      _lib.ptr(rows), int(bool(emit_all)), int(clean), _lib.stream_ptr()), "ddx_rasterize_fwd_rows_clean")
+    glctx._zbuf_clean = True
     return rast, rows
 
 
@@ -527,7 +534,7 @@ class _gbuffer_func(torch.autograd.Function):
     frame each way).  pos / uv / tex / vtx_color are ONE copy each ([V,3], [V,2], [Th,Tw,3], [V,3]); they get no gradient."""
 
     @staticmethod
-    def forward(ctx, clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows=None, cover_channels=3, want_rgb=True):
+    def forward(ctx, clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows=None, cover_channels=3, want_rgb=True, want_depth=True):
         lib = _lib.load()
         clip, mtx, rast = _f32c(clip, "clip"), _f32c(mtx, "mtx"), _f32c(rast, "rast")
         B, H, W = rast.shape[:3]
@@ -535,10 +542,10 @@ class _gbuffer_func(torch.autograd.Function):
         Th, Tw = (tex.shape[0], tex.shape[1]) if tex is not None else (0, 0)
         dev = rast.device
         rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) if want_rgb else None
-        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_depth else None
         cover = torch.empty((B, H, W, int(cover_channels)), dtype=torch.float32, device=dev)
         _lib.check(lib.ddx_gbuffer_fwd_rows_c(_lib.ptr(rast), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv), _lib.ptr(tex), Th, Tw,
-                                              _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(rgb) if want_rgb else None, _lib.ptr(depth),
+                                              _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(rgb) if want_rgb else None, _lib.ptr(depth) if want_depth else None,
                                               _lib.ptr(cover), int(cover_channels), _lib.stream_ptr()), "ddx_gbuffer_fwd_rows_c")
         ctx.save_for_backward(clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows)
         ctx.set_materialize_grads(False)  # (an unused output arrives as None instead of a zero-filled 80-240 MB tensor)
@@ -549,7 +556,7 @@ class _gbuffer_func(torch.autograd.Function):
     def backward(ctx, drgb, ddepth, _dcover):
         clip, mtx, rast, pos, tri, uv, tex, vtx_color, rows = ctx.saved_tensors
         if drgb is None and ddepth is None:
-            return (None,) * 11
+            return (None,) * 12
         B, H, W = rast.shape[:3]
         V, T = pos.shape[0], tri.shape[0]
         Th, Tw = (tex.shape[0], tex.shape[1]) if tex is not None else (0, 0)
@@ -560,7 +567,7 @@ class _gbuffer_func(torch.autograd.Function):
         _lib.check(_lib.load().ddx_gbuffer_bwd_rows(_lib.ptr(rast), _lib.ptr(clip), _lib.ptr(mtx), _lib.ptr(pos), _lib.ptr(tri), _lib.ptr(uv),
                                                     _lib.ptr(tex), Th, Tw, _lib.ptr(vtx_color), B, V, T, H, W, _lib.ptr(rows), _lib.ptr(drgb),
                                                     _lib.ptr(ddepth), _lib.ptr(dclip), _lib.ptr(dmtx), _lib.stream_ptr()), "ddx_gbuffer_bwd_rows")
-        return dclip, dmtx, None, None, None, None, None, None, None, None, None
+        return dclip, dmtx, None, None, None, None, None, None, None, None, None, None
 
 
 _same_index_cache = {}
@@ -616,7 +623,7 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
     other consumer sees an ordinary [B,H,W,3] tensor whose gradient autograd sums over the channels.  compact_mask=False: three
     stored copies.
     outputs (fused path): None = all; a collection of names from ("rgb", "depth", "mask") = what the caller will read -- without
-    "rgb" the colour pass (texture fetches, 12 bytes per pixel written) is left out and the entry is None.
+    "rgb" the colour pass (texture fetches, 12 bytes per pixel written) is left out and the entry is None; likewise "depth", and "mask" with its antialias pass.
     """
     H, W = (resolution if isinstance(resolution, (list, tuple)) else (resolution, resolution))
     faces = pos_idx[0] if pos_idx.dim() == 3 else pos_idx
@@ -646,12 +653,15 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
             dict(uv=None, tex=None, vtx_color=_f32c(_one_copy(vtx_color), "vtx_color"))
         want_rgb = outputs is None or "rgb" in outputs
         rgb, depth, cover = _gbuffer_func.apply(clip, mtx, rast.detach(), p1, _i32c(faces, "pos_idx"), kw["uv"], kw["tex"], kw["vtx_color"], rows,
-                                                1 if compact_mask else 3, want_rgb)
+                                                1 if compact_mask else 3, want_rgb, outputs is None or "depth" in outputs)
         # the silhouette: antialias blends added in place onto the coverage image (rast detached: antialias has no gradient for
         # it, and an attached one would still make autograd run rasterize's backward on zeros)
-        mask = _silhouette_func.apply(cover, rast.detach(), clip, _i32c(faces, "pos_idx"), build_topology(faces), rows)
-        if compact_mask:
-            mask = mask.expand(*mask.shape[:-1], 3)
+        if outputs is None or "mask" in outputs:
+            mask = _silhouette_func.apply(cover, rast.detach(), clip, _i32c(faces, "pos_idx"), build_topology(faces), rows)
+            if compact_mask:
+                mask = mask.expand(*mask.shape[:-1], 3)
+        else:
+            mask = None
         return {"rgb": rgb, "depth": depth, "rast_out": rast if return_rast_out else None, "mask": mask}
     rast, _ = rasterize(glctx, clip, faces, resolution=[H, W])
     covered = rast[..., 3:].clamp(0, 1)

@@ -100,6 +100,12 @@ int ddx_rasterize_fwd(const float* pos, const int32_t* tri, int B, int V, int T,
  * not be read by anything but the *_rows passes given the same row_range.  emit_all = 1: the whole frame, as ddx_rasterize_fwd. */
 int ddx_rasterize_fwd_rows(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
                            void* scratch, size_t scratch_bytes, float* rast, int32_t* row_range, int emit_all, void* stream);
+/* ... for a caller that keeps `scratch` from call to call (the iterations of a loop): zbuf_clean != 0 states that the depth buffer
+ * inside it is all-empty, as every call of this library's rasteriser leaves it (the pass that reads it puts back what it finds),
+ * and the clear of 8 bytes per pixel and hypothesis is left out.  Pass 0 on a scratch's first use, after a change of (B, V, T, H, W)
+ * and after a call that returned an error.  Same rast and row_range either way. */
+int ddx_rasterize_fwd_rows_clean(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W, void* scratch,
+                                 size_t scratch_bytes, float* rast, int32_t* row_range, int emit_all, int zbuf_clean, void* stream);
 /* drast [B,H,W,4] (channels 0,1 used) -> dpos [B,V,4], fully written (zeroed then accumulated). */
 int ddx_rasterize_bwd(const float* pos, const int32_t* tri, int B, int V, int T, int H, int W,
                       const float* rast, const float* drast, float* dpos, void* stream);
@@ -189,7 +195,7 @@ int ddx_silhouette_bwd_rows(const float* rast, const float* pos, const int32_t* 
 /* ... with the silhouette kept as ONE channel.  The three channels the reference carries (interpolate of a [T,3] tensor of ones,
  * diffdope.py:212) are one number per pixel; at 64 x 640x480 the two extra copies are 157 MB written by the g-buffer pass and read and
  * written again by every consumer.  `channels` = 1 or 3 (3: the functions above).  ddx_gbuffer_fwd_rows_c: cover [B,H,W,cover_channels];
- * rgb may be NULL there (depth and coverage only: neither the texture nor the vertex colours are read).  ddx_silhouette_bwd_rows_c
+ * rgb and depth may each be NULL there (an output nobody reads: without rgb neither the texture nor the vertex colours are read).  ddx_silhouette_bwd_rows_c
  * with one channel takes d mask [B,H,W,1] = the sum of the three channel gradients. */
 int ddx_gbuffer_fwd_rows_c(const float* rast, const float* mtx, const float* pos, const int32_t* tri, const float* uv, const float* tex,
                            int Th, int Tw, const float* vtx_color, int B, int V, int T, int H, int W, const int32_t* row_range, float* rgb,

@@ -56,16 +56,23 @@ def test_one_stored_channel_equals_three(name):
 
 
 def test_outputs_without_rgb():
-    """outputs=("depth", "mask"): no colour image, depth and mask and their gradient as with it."""
+    """outputs=("depth", "mask"): no colour image, depth and mask and their gradient as with it; outputs=("rgb",): the colour image
+    alone, the same bits."""
     from diffdope_amd.render import RasterizeContext, render_texture_batch
 
     w, ex, kw, mtx0 = _scene("cfg2")
     H, W = w["H"], w["W"]
     outs = []
+    ctx = RasterizeContext()  # (one context for all calls: from the second on its depth buffer is not cleared again)
+    r = render_texture_batch(ctx, ex(w["proj"]), mtx0, ex(w["pos"]), ex(w["tri"]), [H, W], outputs=("rgb",), **kw)
+    assert r["depth"] is None and r["mask"] is None and tuple(r["rgb"].shape) == (mtx0.shape[0], H, W, 3)
+    rgb_only = r["rgb"].clone()
     for outputs in (None, ("depth", "mask")):
         mtx = mtx0.clone().requires_grad_(True)
-        r = render_texture_batch(RasterizeContext(), ex(w["proj"]), mtx, ex(w["pos"]), ex(w["tri"]), [H, W], outputs=outputs, **kw)
+        r = render_texture_batch(ctx, ex(w["proj"]), mtx, ex(w["pos"]), ex(w["tri"]), [H, W], outputs=outputs, **kw)
         assert (r["rgb"] is None) == (outputs is not None)
+        if outputs is None:
+            assert torch.equal(r["rgb"], rgb_only)
         g = torch.Generator(device="cpu").manual_seed(5)
         wd, wm = (torch.rand(r[k].shape, generator=g).to(mtx.device) for k in ("depth", "mask"))
         (grad,) = torch.autograd.grad((r["depth"] * wd).sum() + (r["mask"] * wm).sum(), mtx)
@@ -143,8 +150,12 @@ def test_the_api_loop_renders_what_its_losses_read():
     for k in a.losses_values:
         np.testing.assert_allclose(a.losses_values[k].numpy(), b.losses_values[k].numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(a.object3d.params_tensor().cpu().numpy(), b.object3d.params_tensor().cpu().numpy(), rtol=0, atol=1e-5)
-    c = _ddope(sc, ("rgb", "mask"), B)
-    assert c._loop_outputs() is None  # (a colour term: everything)
+    assert _ddope(sc, ("rgb", "mask"), B)._loop_outputs() == ("mask", "rgb")
+    assert _ddope(sc, ("rgb", "depth", "mask"), B)._loop_outputs() is None
+    c = _ddope(sc, ("rgb",), B)
+    assert c._loop_outputs() == ("rgb",)
+    c.run_optimization(fused=False)  # (no silhouette pass in the loop; all three images afterwards)
+    assert all(c.renders[k] is not None for k in ("rgb", "depth", "mask"))
 
 
 @pytest.mark.parametrize("H,W", [(37, 53), (36, 52)])
@@ -183,3 +194,33 @@ def test_batch_weighted_sum_of_masked_l1(H, W):
         (g_ref2,) = torch.autograd.grad(ref_s + (ref_v * extra).sum(), leaf)
         (g_out2,) = torch.autograd.grad(s + (v * extra).sum(), leaf)
         np.testing.assert_allclose(g_out2.cpu().numpy(), g_ref2.cpu().numpy(), rtol=3e-6, atol=1e-6 * float(g_ref2.abs().max()))
+
+
+def test_a_kept_context_needs_no_clear_of_its_depth_buffer():
+    """ddx_rasterize_fwd_rows_clean: the pass that reads the depth buffer puts back what it finds, so a context's second and later
+    calls skip the clear -- the same rast, bit for bit, as a fresh context gives, for a sequence of different poses (each leaves
+    its own pixels behind if the restore misses one), through both the row-restricted and the whole-frame emit."""
+    import diffdope_amd as dd
+    from diffdope_amd import render
+    from diffdope_amd.render import RasterizeContext
+
+    w, ex, kw, mtx0 = _scene("cfg2")
+    B, H, W = mtx0.shape[0], w["H"], w["W"]
+    kept = RasterizeContext()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for it in range(6):
+        mtx = mtx0.clone()
+        mtx[:, :3, 3] += (torch.rand((B, 3), device="cuda", generator=g) - 0.5) * torch.tensor([1.5, 1.5, 3.0], device="cuda")
+        clip = dd.xfm_points(ex(w["pos"]).contiguous(), torch.matmul(ex(w["proj"]), mtx))
+        emit_all = it % 2 == 1
+        a, ra = render._rasterize_rows(kept, clip, w["tri"], [H, W], emit_all=emit_all)
+        b, rb = render._rasterize_rows(RasterizeContext(), clip, w["tri"], [H, W], emit_all=True)
+        assert kept._zbuf_clean and torch.equal(ra, rb)
+        if emit_all:
+            assert torch.equal(a, b)
+        else:  # (only the rows of the active tiles are defined)
+            for h in range(B):
+                lo, hi = int(ra[h, 0]), int(ra[h, 1])
+                if lo <= hi:
+                    assert torch.equal(a[h, lo:hi + 1], b[h, lo:hi + 1])
+        assert float(b[..., 3].max()) > 0
