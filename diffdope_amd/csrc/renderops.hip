@@ -473,12 +473,25 @@ __global__ __launch_bounds__(256) void masked_l1_final_sum_kernel(const float* _
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float acc = 0.f;
-    for (int b = wave; b < B; b += 4) {
-        // (the row sum in masked_l1_final_kernel's order: lanes 0-63 and 64-127 of its workgroup, then the two halves)
-        const float lo = wave_sum(partial[(size_t)b * ML1_CHUNKS + lane]), hi = wave_sum(partial[(size_t)b * ML1_CHUNKS + 64 + lane]);
-        const float v = __fdiv_rn(lo + hi, (float)N);
-        if (lane == 0) out[b] = v;
-        acc += v * bw[b];
+    for (int b0 = wave; b0 < B; b0 += 4 * 8) {  // (eight rows' loads in flight at a time: the rows are one memory level, not sixteen)
+        float lo[8], hi[8], wgt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * 4;
+            const bool in = b < B;
+            lo[k] = in ? partial[(size_t)b * ML1_CHUNKS + lane] : 0.f;
+            hi[k] = in ? partial[(size_t)b * ML1_CHUNKS + 64 + lane] : 0.f;
+            wgt[k] = in ? bw[b] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + k * 4;
+            if (b >= B) break;
+            // (the row sum in masked_l1_final_kernel's order: lanes 0-63 and 64-127 of its workgroup, then the two halves)
+            const float v = __fdiv_rn(wave_sum(lo[k]) + wave_sum(hi[k]), (float)N);
+            if (lane == 0) out[b] = v;
+            acc += v * wgt[k];
+        }
     }
     __shared__ float red[4];
     if (lane == 0) red[wave] = acc;

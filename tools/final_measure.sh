@@ -5,16 +5,17 @@ T=${1:-r5c}
 O=gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/${T}_pytest_gpu.log 2>&1; tail -3 $O/${T}_pytest_gpu.log
-timeout 900 python bench.py > $O/${T}_bench.json 2>$O/${T}_bench.err; tail -c 400 $O/${T}_bench.json
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/${T}_bench_steps20.json 2>/dev/null; tail -c 300 $O/${T}_bench_steps20.json
-timeout 1200 bash tools/sweep.sh $T > $O/${T}_sweep.log 2>&1; cat $O/${T}_sweep.log
-timeout 300 bash tools/ktrace.sh $T > $O/${T}_ktrace_cfg2.log 2>&1; cat $O/${T}_ktrace_cfg2.log; cp $(find $O/trace_$T -name "t_kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
-timeout 300 bash tools/ktrace.sh ${T}cfg3 --config cfg3 > $O/${T}_ktrace_cfg3.log 2>&1; cat $O/${T}_ktrace_cfg3.log; cp $(find $O/trace_${T}cfg3 -name "t_kernel_stats.csv" | head -1) $O/${T}_kernel_stats_cfg3.csv
 timeout 900 bash tools/pmc_passes.sh $T cfg2_d7.5 > $O/${T}_pmc_cfg2.log 2>&1
 timeout 900 bash tools/pmc_passes.sh $T cfg2_d3.75 --distance 3.75 > $O/${T}_pmc_cfg2d.log 2>&1
 timeout 900 bash tools/pmc_passes.sh $T cfg3_d7.5 --config cfg3 > $O/${T}_pmc_cfg3.log 2>&1
 timeout 900 bash tools/pmc_passes.sh $T cfg4_gb512 --config cfg4 --global-batch 512 > $O/${T}_pmc_cfg4sat.log 2>&1
 for k in cfg2_d7.5 cfg2_d3.75 cfg3_d7.5 cfg4_gb512; do python profiles/summarize_sq.py $T $k > $O/${T}_pmc_sq_$k.json 2>>$O/${T}_summ.err; done
+cp $O/${T}_pmc_sq_*.json profiles/  # (bench.py reads its counters from profiles/: those of THIS build, made just above)
+timeout 900 python bench.py > $O/${T}_bench.json 2>$O/${T}_bench.err; tail -c 400 $O/${T}_bench.json
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/${T}_bench_steps20.json 2>/dev/null; tail -c 300 $O/${T}_bench_steps20.json
+timeout 1200 bash tools/sweep.sh $T > $O/${T}_sweep.log 2>&1; cat $O/${T}_sweep.log
+timeout 300 bash tools/ktrace.sh $T > $O/${T}_ktrace_cfg2.log 2>&1; cat $O/${T}_ktrace_cfg2.log; cp $(find $O/trace_$T -name "t_kernel_stats.csv" | head -1) $O/${T}_kernel_stats.csv
+timeout 300 bash tools/ktrace.sh ${T}cfg3 --config cfg3 > $O/${T}_ktrace_cfg3.log 2>&1; cat $O/${T}_ktrace_cfg3.log; cp $(find $O/trace_${T}cfg3 -name "t_kernel_stats.csv" | head -1) $O/${T}_kernel_stats_cfg3.csv
 T=$T python - <<'PY'
 import json, os
 T = os.environ["T"]
