@@ -118,7 +118,7 @@ def _lr_weights(ddope, weight):
         cache = (tag, {})
         ddope._lr_weights_cache = cache
     if float(weight) not in cache[1]:
-        cache[1][float(weight)] = (lr.detach().float() * (float(weight) / lr.shape[0])).contiguous()
+        cache[1][float(weight)] = (lr.detach() * (float(weight) / lr.shape[0])).contiguous()
     return cache[1][float(weight)]
 
 

@@ -314,3 +314,75 @@ def test_obj_reader_and_mesh_class(tmp_path):
     assert c["uv"] is None and c["texture_file"] is None
     mesh2 = dd.Mesh(path_model=str(tmp_path / "c.obj"))
     assert not mesh2.has_textured_map and tuple(mesh2.vtx_color.shape) == (3, 3)
+
+
+def test_builtin_losses_are_the_reference_expressions():
+    """l1_rgb_with_mask / l1_depth_with_mask / l1_mask (diffdope.py:547-613) with the weighting by the learning rates folded
+    into one weighted sum (api._lr_weights; on ROCm tensors inside the loss launches): on any other tensors -- here float64 on
+    the CPU, where the torch expressions run -- value, logged row and gradient are those of
+    (mean |(x - y) m| * learning_rates).mean() * weight, also with the mask view render_texture_batch returns."""
+    from types import SimpleNamespace
+
+    import diffdope_amd as dd
+
+    g = torch.Generator().manual_seed(4)
+    B, h, w = 3, 7, 9
+    seg = (torch.rand((1, h, w, 3), generator=g, dtype=torch.float64) > 0.4).double().expand(B, -1, -1, -1)
+    gt = {"rgb": torch.rand((1, h, w, 3), generator=g, dtype=torch.float64).expand(B, -1, -1, -1),
+          "depth": torch.rand((1, h, w), generator=g, dtype=torch.float64).expand(B, -1, -1), "segmentation": seg}
+    lr = torch.tensor([0.3, 1.0, 2.5], dtype=torch.float64)
+    base = torch.rand((B, h, w, 1), generator=g, dtype=torch.float64, requires_grad=True)
+    ren = {"rgb": torch.rand((B, h, w, 3), generator=g, dtype=torch.float64, requires_grad=True),
+           "depth": torch.rand((B, h, w), generator=g, dtype=torch.float64, requires_grad=True), "mask": base.expand(B, h, w, 3)}
+    cases = [(dd.l1_rgb_with_mask, "rgb", "rgb", 0.7, ren["rgb"], lambda: torch.abs((ren["rgb"] - gt["rgb"]) * seg).mean((1, 2, 3))),
+             (dd.l1_depth_with_mask, "depth", "depth", 1.3, ren["depth"], lambda: torch.abs((ren["depth"] - gt["depth"]) * seg[..., 0]).mean((1, 2))),
+             (dd.l1_mask, "mask", "mask_selection", 0.9, base, lambda: torch.abs(ren["mask"] - seg).mean((1, 2, 3)))]
+    for fn, key, log_key, wgt, leaf, expr in cases:
+        logged = {}
+        dp = SimpleNamespace(renders=ren, gt_tensors=gt, learning_rates=lr, add_loss_value=lambda k, v: logged.setdefault(k, v),
+                             cfg=dd.Cfg(losses=dd.Cfg(**{f"weight_{key}": wgt})))
+        loss = fn(dp)
+        ref_v = expr()
+        ref = (ref_v * lr).mean() * wgt
+        assert set(logged) == {log_key} and torch.allclose(logged[log_key], ref_v.detach() * wgt, rtol=1e-13, atol=0)
+        assert loss.dim() == 0 and torch.allclose(loss, ref, rtol=1e-13, atol=0)
+        (ga,) = torch.autograd.grad(loss, leaf)
+        (gb,) = torch.autograd.grad(ref, leaf)
+        assert torch.allclose(ga, gb, rtol=1e-12, atol=1e-18)
+        # the weights are cached per (learning_rates, weight): a second term with another weight does not evict the first
+        assert dd.api._lr_weights(dp, wgt) is dd.api._lr_weights(dp, wgt)
+        other = dd.api._lr_weights(dp, 2.0)
+        assert dd.api._lr_weights(dp, wgt) is not other and torch.allclose(other, lr * (2.0 / B))
+
+
+def test_pose_head_expressions_match_the_reference_goldens():
+    """pose.quat_trans_from_parameters on CPU tensors (the torch expressions of Object3D.forward, diffdope.py:1085-1098) followed
+    by matrix_batch_44_from_position_quat: matrices and parameter gradients of tests/golden/g2_pose.npz (made from the reference)."""
+    import os
+
+    import diffdope_amd as dd
+    from diffdope_amd import pose
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g2_pose.npz"))
+    params = [torch.tensor(g["params"][i], requires_grad=True) for i in range(7)]
+    q, t = pose.quat_trans_from_parameters(*params)
+    mtx = dd.matrix_batch_44_from_position_quat(p=t, q=q)
+    np.testing.assert_allclose(mtx.detach().numpy(), g["mtx"], rtol=1e-6, atol=1e-6)
+    mtx.backward(torch.tensor(g["dmtx"]))
+    np.testing.assert_allclose(np.stack([p.grad.numpy() for p in params]), g["dparams"], rtol=1e-4, atol=1e-5)
+
+
+def test_loop_outputs_follow_the_loss_set():
+    """DiffDope._loop_outputs: what the op-by-op loop renders -- everything as soon as a function that is not built in is in the
+    list (it may read any image), else the images the terms read (the edge extension reads the colour image)."""
+    import diffdope_amd as dd
+    from diffdope_amd import api
+
+    f = api.DiffDope._loop_outputs
+    from types import SimpleNamespace as NS
+    assert f(NS(loss_functions=[api.l1_depth_with_mask, api.l1_mask])) == ("depth", "mask")
+    assert f(NS(loss_functions=[api.l1_rgb_with_mask])) == ("rgb",)
+    assert f(NS(loss_functions=[api.l1_edge, api.l1_mask])) == ("mask", "rgb")
+    assert f(NS(loss_functions=[api.l1_rgb_with_mask, api.l1_depth_with_mask, api.l1_mask])) is None
+    assert f(NS(loss_functions=[api.l1_mask, lambda d: None])) is None
+    assert f(NS(loss_functions=[])) is None
