@@ -13,7 +13,10 @@ diff-dope discards them or hands them to texture(..., "linear"), which ignores t
 are returned as `PixelDerivativesNotComputed` placeholders of the right shape that can be passed around (to
 interpolate / texture, as the reference does) but raise RuntimeError as soon as any arithmetic, indexing or copy
 consumes them, so a user loss that relies on them fails loudly instead of reading zeros; only filter_mode="linear" /
-boundary wrap is implemented (mip-mapped filtering raises); everything needs ROCm tensors (no CPU fallback).
+boundary wrap is implemented (mip-mapped filtering raises); everything needs ROCm tensors (no CPU fallback);
+render_texture_batch's `mask` is, on its fused path, a [B,H,W,3] VIEW of one stored channel (last stride 0: its three channels are
+one number per pixel in the reference too) -- reading it, reducing it and differentiating through it work as on any tensor,
+writing into it in place needs a .clone() first (compact_mask=False stores the three copies).
 """
 import numpy as np
 import torch
