@@ -11,7 +11,6 @@ What differs on purpose ("Logging semantics"):
   * `optimization_results[i]` always holds "mtx"; "rgb"/"depth"/"mask" are rendered on first access from
     the stored pose instead of being copied to the host every iteration (diffdope.py:1698-1703).
 """
-import os
 import logging
 import math
 import random
@@ -828,11 +827,7 @@ class DiffDope:
                 prms = [prm for prm in self.object3d.parameters() if prm.grad is not None]
                 lr_b = self._capture["lr_b"]
                 lr_b.copy_(lr.expand_as(lr_b))
-                if os.environ.get("DDX_API_SGD") == "loop":
-                    for prm in prms:
-                        prm.addcmul_(prm.grad, lr_b, value=-1.0)
-                else:
-                    torch._foreach_addcmul_(prms, [prm.grad for prm in prms], [lr_b] * len(prms), value=-1.0)
+                torch._foreach_addcmul_(prms, [prm.grad for prm in prms], [lr_b] * len(prms), value=-1.0)
         else:
             for g in self.optimizer.param_groups:
                 g["lr"] = lr
@@ -840,7 +835,7 @@ class DiffDope:
             # (torch/optim/sgd.py _multi_tensor_sgd); issued directly: the optimizer's Python wrapper costs 0.1 ms of an iteration
             # whose GPU work takes 0.6.  Any other optimizer state goes through step().
             g0 = self.optimizer.param_groups[0]
-            plain = (len(self.optimizer.param_groups) == 1 and not g0.get("momentum") and not g0.get("weight_decay") and not g0.get("nesterov")
+            plain = (type(self.optimizer) is torch.optim.SGD and len(self.optimizer.param_groups) == 1 and not g0.get("momentum") and not g0.get("weight_decay") and not g0.get("nesterov")
                      and not g0.get("maximize") and prms and prms[0].is_cuda)
             if plain:
                 with torch.no_grad():

@@ -490,7 +490,16 @@ def _one_channel_base(x):
     if (b is None or b.dim() != x.dim() or b.shape[-1] != 1 or tuple(b.shape[:-1]) != tuple(x.shape[:-1]) or not b.is_contiguous()
             or b.data_ptr() != x.data_ptr() or tuple(b.stride()[:-1]) != tuple(x.stride()[:-1])):
         return None
-    return b
+    # the base must stand where x stands in the autograd graph: a detached view (x.detach(), a view made under no_grad) shares the
+    # base's memory, not its history -- the base is then taken without it; a view with a history must be the expand of the base itself
+    if not x.requires_grad:
+        return b.detach()
+    fn = x.grad_fn
+    if fn is None or not fn.name().startswith("ExpandBackward") or not fn.next_functions:
+        return None
+    nxt = fn.next_functions[0][0]
+    same = (nxt is b.grad_fn) if b.grad_fn is not None else (getattr(nxt, "variable", None) is b)
+    return b if same else None
 
 
 def masked_l1_mean(x, y, mask=None, mask_channel0=False, batch_weights=None):
@@ -512,7 +521,8 @@ def masked_l1_mean(x, y, mask=None, mask_channel0=False, batch_weights=None):
     tail = tuple(x.shape[1:])
     xb = _one_channel_base(x) if (x.is_cuda and x.dtype == torch.float32 and not mask_channel0) else None
     bw = None
-    if batch_weights is not None and x.is_cuda and batch_weights.dtype == torch.float32 and tuple(batch_weights.shape) == (x.shape[0],):
+    if (batch_weights is not None and x.is_cuda and batch_weights.dtype == torch.float32 and tuple(batch_weights.shape) == (x.shape[0],)
+            and not batch_weights.requires_grad):
         bw = batch_weights.detach().contiguous()
     if (xb is not None and tuple(y1.shape) == tail and y1.dtype == torch.float32
             and (m1 is None or (m1.dtype == torch.float32 and tuple(m1.shape) == tail))):

@@ -111,12 +111,20 @@ def test_masked_l1_of_the_one_channel_view_matches_the_torch_expression(H, W, ma
     (g_out,) = torch.autograd.grad((out * lr).mean(), base)
     # (three signed terms per pixel, added in another order than autograd's sum over the expanded axis: they may cancel)
     np.testing.assert_allclose(g_out.cpu().numpy(), g_ref.cpu().numpy(), rtol=2e-6, atol=1e-6 * float(g_ref.abs().max()))
+    # a view without a history (detached, or made under no_grad) gives the same value and no gradient path to the stored channel
+    out_d = masked_l1_mean(base.expand(B, H, W, 3).detach(), y.expand(B, H, W, 3), None if m is None else m.expand(B, H, W, 3))
+    with torch.no_grad():
+        out_n = masked_l1_mean(base.expand(B, H, W, 3), y.expand(B, H, W, 3), None if m is None else m.expand(B, H, W, 3))
+    assert not out_d.requires_grad and not out_n.requires_grad
+    for o in (out_d, out_n):  # (whichever path they take: the stored channel's, or -- torch does not report them as views of it -- the general one)
+        np.testing.assert_allclose(o.cpu().numpy(), out.detach().cpu().numpy(), rtol=2e-6)
+    n_hits = len(hits)
     # a zero-stride view that is NOT the expand of a contiguous [...,1] base takes the general path, with the same value
     odd = torch.rand((B, H, W, 2), device="cuda", generator=g)[..., :1]
     out2 = masked_l1_mean(odd.expand(B, H, W, 3), y.expand(B, H, W, 3), None if m is None else m.expand(B, H, W, 3))
     ref2 = torch.mean(torch.abs((odd.expand(B, H, W, 3) - y) * (1.0 if m is None else m)), (1, 2, 3))
     np.testing.assert_allclose(out2.cpu().numpy(), ref2.cpu().numpy(), rtol=2e-6)
-    assert len(hits) == 1
+    assert len(hits) == n_hits == 1  # (the monkeypatch was removed after the first call)
 
 
 def test_the_api_loop_renders_what_its_losses_read():
