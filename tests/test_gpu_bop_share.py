@@ -3,7 +3,7 @@ GPU, refined through bop.refine_frame (the reference's examples/run_bop_scene.py
 loss sets.  Checked here: the frame as ONE engine group is bit-identical to one stream per object and to four engines run one
 after the other; and every object's engine,
 as refine_frame built it (mesh of 20 480 triangles, 2048-px frame crop semantics of the API, its own mask and loss set), against the
-oracle on two hypotheses (losses rtol 5e-5, pose gradient 3e-3 of its largest component) with duplicated hypotheses bit-identical."""
+oracle on two hypotheses (losses rtol 5e-5, pose gradient 1e-4 of its largest component) with duplicated hypotheses bit-identical."""
 import json
 
 import numpy as np
@@ -135,4 +135,4 @@ def test_config5_share_four_objects_64_hypotheses_1280x720(tmp_path, H, W, rows,
                     np.testing.assert_allclose(lg[j, b], logs[key][0], rtol=5e-5, atol=1e-7, err_msg=f"object {i} hypothesis {b} {key}")
                 else:
                     assert lg[j, b] == 0
-            np.testing.assert_allclose(g[:, b], g_ref[:, 0], rtol=3e-3, atol=3e-3 * np.abs(g_ref).max(), err_msg=f"object {i} hypothesis {b}")
+            np.testing.assert_allclose(g[:, b], g_ref[:, 0], rtol=1e-4, atol=1e-4 * np.abs(g_ref).max(), err_msg=f"object {i} hypothesis {b}")

@@ -152,7 +152,7 @@ def test_render_texture_batch_autograd_matches_oracle():
         assert abs(float(loss) - total) < 1e-5 * max(1, abs(total))
         loss.backward()
         g = np.stack([p.grad.cpu().numpy() for p in params])
-        np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+        np.testing.assert_allclose(g, g_ref, rtol=1e-4, atol=1e-4 * np.abs(g_ref).max())
 
 
 @pytest.mark.parametrize("rows,cols,H,W,B,dist", [(4, 6, 50, 70, 1, 1.2), (6, 8, 120, 160, 3, 1.0), (16, 20, 37, 53, 2, 1.8),
@@ -172,7 +172,7 @@ def test_engine_large_triangles_ragged_sizes_single_hypothesis(rows, cols, H, W,
     if rows <= 6:
         assert st["big_triangles"] == 1  # the tile pass ran
     g = (sc["params"] - params.cpu().numpy()) / 0.25
-    np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    np.testing.assert_allclose(g, g_ref, rtol=1e-4, atol=1e-4 * np.abs(g_ref).max())
     lg = eng.losses()[0].cpu().numpy()
     for i, key in enumerate(KEYS):
         np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
@@ -192,7 +192,7 @@ def test_engine_hypothesis_leaving_the_frame():
     eng.run()
     eng.finish()
     g = (sc["params"] - params.cpu().numpy()) / 0.25
-    np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    np.testing.assert_allclose(g, g_ref, rtol=1e-4, atol=1e-4 * np.abs(g_ref).max())
     assert abs(g[6, 1]) > 0 and np.abs(g[:6, 1]).max() < 1e-9
     lg = eng.losses()[0].cpu().numpy()
     for i, key in enumerate(KEYS):
@@ -261,6 +261,7 @@ def test_engine_full_size_one_hypothesis_against_oracle_and_batch_properties(row
     # one hypothesis against the oracle (global_B keeps the 1/B factor of the batch mean)
     total, logs, g_ref, _ = R.loss_and_grad(params[:, 2:3], lrm[2:3], global_B=16)
     g_gpu = (params[:, 2] - pn[:, 2]) / lr
+    # (the gradient is read back from the parameter update, (p' - p) / lr: the round-off of p' at its own magnitude shows in it -- 3e-4 .. 2e-3 measured)
     np.testing.assert_allclose(g_gpu, g_ref[:, 0], rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
     for i, key in enumerate(KEYS):
         if key in logs:
@@ -370,7 +371,7 @@ def test_mesh_with_more_vertices_than_triangles():
     for i, key in enumerate(KEYS):
         if key in logs:
             np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
-    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-4 * np.abs(g_ref).max())
     R.cull_backfaces = False
     _, _, _, r2 = R.loss_and_grad(sc["params"], sc["lr_mult"])
     B = sc["B"]
@@ -586,7 +587,7 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
     lg = l_far.cpu().numpy()
     for i, key in enumerate(KEYS):
         np.testing.assert_allclose(lg[i], logs[key], rtol=3e-5, atol=1e-7)
-    np.testing.assert_allclose(g_far.cpu().numpy(), g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    np.testing.assert_allclose(g_far.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-4 * np.abs(g_ref).max())
     # (d) two shells: culled when both are outward, not when the second is inside-out (same decision as the oracle's rule)
     n = len(sc["pos"])
     pos2 = np.concatenate([sc["pos"], sc["pos"] * np.float32(0.25) + np.float32(0.02)]).astype(np.float32)
@@ -671,4 +672,4 @@ def test_engine_hypothesis_cut_by_the_camera_plane_is_clipped_like_the_oracle():
     for i, key in enumerate(KEYS):
         if key in logs:
             np.testing.assert_allclose(lg[i], logs[key], rtol=5e-5, atol=1e-7)
-    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-4 * np.abs(g_ref).max())
