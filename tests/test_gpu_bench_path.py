@@ -49,7 +49,7 @@ def test_fused_engine_on_the_bench_workload_against_oracle(name, B, shard):
     """The engine as bench.py builds it (cfg2: 80x128 mesh = 20 480 triangles, 640x480, rgb+mask, distance 7.5, 64 hypotheses;
     cfg1: 77x90 mesh = 13 860 triangles, 160x120, mask only; cfg3: 160x160 mesh = 51 200 triangles, 128 hypotheses, rgb + depth +
     edge; cfg4: 100x150 mesh = 30 000 triangles, vertex colours, depth + mask, hypotheses 192..255 of a global batch of 512):
-    evaluation pass of the whole batch, two hypotheses against the oracle (losses rtol 5e-5, pose gradient 2e-5 of its largest
+    evaluation pass of the whole batch, two hypotheses against the oracle (losses rtol 5e-6, pose gradient 2e-5 of its largest
     component, and against the oracle run in float64 as referee), duplicated hypotheses bit-identical, and the first optimiser iteration (SGD) reproduces params - lr * grad."""
     from diffdope_amd import workloads as wl
 
@@ -80,7 +80,7 @@ def test_fused_engine_on_the_bench_workload_against_oracle(name, B, shard):
         total, logs, g_ref, _ = R.loss_and_grad(pn[:, b:b + 1], ln[b:b + 1], global_B=w["global_B"])
         for i, key in enumerate(KEYS):
             if key in logs:
-                np.testing.assert_allclose(lg[i, b], logs[key][0], rtol=5e-5, atol=1e-7)
+                np.testing.assert_allclose(lg[i, b], logs[key][0], rtol=5e-6, atol=1e-8)  # (passes at 5e-7; round 4: 5e-5)
             else:
                 assert lg[i, b] == 0
         # (cfg1: 13 860 triangles on 160x120 are far below a pixel each, so hardly any silhouette pair antialiases and the mask
