@@ -68,7 +68,7 @@ def test_engine_and_gbuffer_with_compat_match_the_oracle_with_compat(nvdiffrast_
         eng = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [sc["H"], sc["W"]], {k: T(v) for k, v in sc["gt"].items()}, params,
                               T(sc["lr_mult"]), [0.1], w, uv=T(sc["uv"]), tex=T(sc["tex"]), compat="nvdiffrast")
         losses, grad = eng.loss_and_grad()
-        np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=2e-3, atol=2e-4 * np.abs(g_ref).max())
+        np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=2e-4, atol=2e-5 * np.abs(g_ref).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
         eng0 = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [sc["H"], sc["W"]], {k: T(v) for k, v in sc["gt"].items()}, params,
                                T(sc["lr_mult"]), [0.1], w, uv=T(sc["uv"]), tex=T(sc["tex"]))
         _, grad0 = eng0.loss_and_grad()
@@ -97,7 +97,7 @@ def test_engine_and_gbuffer_with_compat_match_the_oracle_with_compat(nvdiffrast_
             assert abs(float(loss.detach()) - total) < 2e-5 * max(1.0, abs(total))
             loss.backward(retain_graph=True)
             g = np.stack([p_.grad.cpu().numpy() for p_ in params])
-            np.testing.assert_allclose(g, g_ref, rtol=3e-3, atol=3e-3 * np.abs(g_ref).max())
+            np.testing.assert_allclose(g, g_ref, rtol=3e-4, atol=3e-4 * np.abs(g_ref).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
             grads.append(g)
 
 

@@ -41,7 +41,7 @@ def test_engine_one_iteration_losses_and_gradients(weights, textured):
     g_gpu = (sc["params"] - params.cpu().numpy()) / lr
     scale = np.abs(g_ref).max()
     assert scale > 0
-    np.testing.assert_allclose(g_gpu, g_ref, rtol=2e-3, atol=2e-3 * scale)
+    np.testing.assert_allclose(g_gpu, g_ref, rtol=2e-4, atol=2e-4 * scale)  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     lg = eng.losses()[0].cpu().numpy()
     for i, key in enumerate(KEYS):
         if key in logs:
@@ -291,7 +291,7 @@ def test_engine_eval_pass_gradient_against_oracle_and_torch_optimizer(weights):
     losses, grad = eng.loss_and_grad()
     torch.cuda.synchronize()
     assert torch.equal(params, before) and eng.it == 0
-    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-3, atol=1e-4 * np.abs(g_ref).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * np.abs(g_ref).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     for i, key in enumerate(KEYS):
         if key in logs:
             np.testing.assert_allclose(losses[i].cpu().numpy(), logs[key], rtol=2e-5, atol=1e-7)
@@ -299,7 +299,7 @@ def test_engine_eval_pass_gradient_against_oracle_and_torch_optimizer(weights):
     val = eng.loss(p)
     assert abs(float(val.detach()) - total) < 1e-5 * max(1.0, abs(total))
     val.backward()
-    np.testing.assert_allclose(p.grad.cpu().numpy(), g_ref, rtol=1e-3, atol=1e-4 * np.abs(g_ref).max())
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * np.abs(g_ref).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     # the evaluation pass leaves the engine usable: a normal run afterwards equals a run on a fresh engine
     eng.run(3)
     eng2, params2 = _engine(sc, weights, [0.1] * 30)
@@ -337,7 +337,7 @@ def test_engine_at_the_large_end(rows, cols, H, W, B, dist):
     lg = losses.cpu().numpy()
     for i, key in enumerate(KEYS):
         np.testing.assert_allclose(lg[i], logs[key], rtol=2e-5, atol=1e-8)
-    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-3, atol=1e-4 * np.abs(g_ref).max())
+    np.testing.assert_allclose(grad.cpu().numpy(), g_ref, rtol=1e-4, atol=1e-5 * np.abs(g_ref).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     eng.run()
     eng.finish()
     st = eng.check()
@@ -446,7 +446,7 @@ def test_engine_result_does_not_depend_on_the_order_of_the_mesh_file():
     l1, g1 = eng2.loss_and_grad()
     torch.cuda.synchronize()
     np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=2e-4, atol=1e-7)
-    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(g0.abs().max()))
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(g0.abs().max()))  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
 
 
 def test_engine_close_up_dense_mesh_scatter_variants_agree(monkeypatch):
@@ -500,7 +500,7 @@ def test_engine_large_batch_not_a_multiple_of_eight():
             if key in logs:
                 np.testing.assert_allclose(lg[i, j], logs[key][0], rtol=5e-5, atol=1e-7)
         g_gpu = (sc["params"][:, j] - pn[:, j]) / lr
-        np.testing.assert_allclose(g_gpu, g_ref[:, 0], rtol=5e-3, atol=5e-3 * np.abs(g_ref).max() + 2e-6)
+        np.testing.assert_allclose(g_gpu, g_ref[:, 0], rtol=5e-4, atol=5e-4 * np.abs(g_ref).max() + 2e-6)  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
 
 
 def test_forward_backward_pair_and_standalone_optimiser_steps():
@@ -572,7 +572,7 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
     Ro = orc.RenderOracle(sc["pos"], sc_open["tri"], sc["proj"], sc["H"], sc["W"], sc["gt"], w, dtype=np.float32, cull_backfaces=True, **kw)
     assert orc.mesh_cull_sign(sc["pos"], sc_open["tri"], sc["proj"]) == 0
     total, logs, g_ref, _ = Ro.loss_and_grad(sc["params"], sc["lr_mult"])
-    np.testing.assert_allclose(g_open.cpu().numpy(), g_ref, rtol=2e-3, atol=2e-3 * np.abs(g_ref).max())
+    np.testing.assert_allclose(g_open.cpu().numpy(), g_ref, rtol=2e-4, atol=2e-4 * np.abs(g_ref).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     # (c) hypothesis 1 straddles the far plane (zfar = 200): its back faces are drawn again; losses still match the oracle
     far = sc["params"].copy()
     far[6, 1] = -200.0

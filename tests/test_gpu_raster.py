@@ -164,7 +164,7 @@ def test_renderer_ops_forward_backward_vs_oracle():
     g = rng.normal(size=ref.shape).astype(np.float32)
     rast.backward(T(g))
     dref = orc.rasterize_bwd(pc, tri, ref, g)
-    np.testing.assert_allclose(pos_t.grad.cpu().numpy(), dref, rtol=2e-3, atol=2e-3 * np.abs(dref).max())
+    np.testing.assert_allclose(pos_t.grad.cpu().numpy(), dref, rtol=2e-4, atol=2e-4 * np.abs(dref).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     rast = rast.detach()
     # interpolate (per-hypothesis attributes and broadcast attributes), with attribute gradients
     for Ba in (1, 2):
@@ -177,7 +177,7 @@ def test_renderer_ops_forward_backward_vs_oracle():
         out.backward(T(go))
         dattr, drast = orc.interpolate_bwd(attr, ref, tri, go, True)
         np.testing.assert_allclose(r_t.grad.cpu().numpy(), drast, rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(a_t.grad.cpu().numpy(), dattr, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(a_t.grad.cpu().numpy(), dattr, rtol=1e-4, atol=1e-4)  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     # texture
     uvimg = rng.uniform(-1.5, 2.5, size=(2, H, W, 2)).astype(np.float32)
     for Bt in (1, 2):
@@ -189,8 +189,8 @@ def test_renderer_ops_forward_backward_vs_oracle():
         go = rng.normal(size=oref.shape).astype(np.float32)
         out.backward(T(go))
         duv, dtex = orc.texture_bwd(tex, uvimg, go, True)
-        np.testing.assert_allclose(uv_t.grad.cpu().numpy(), duv, rtol=1e-3, atol=1e-3)
-        np.testing.assert_allclose(tx_t.grad.cpu().numpy(), dtex, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(uv_t.grad.cpu().numpy(), duv, rtol=1e-4, atol=1e-4)  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
+        np.testing.assert_allclose(tx_t.grad.cpu().numpy(), dtex, rtol=1e-4, atol=1e-4)  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     # antialias with general colours (covered-vs-covered pairs matter here)
     col = rng.uniform(size=(2, H, W, 3)).astype(np.float32)
     c_t, p_t = T(col, requires_grad=True), T(pc, requires_grad=True)
@@ -202,7 +202,7 @@ def test_renderer_ops_forward_backward_vs_oracle():
     out.backward(T(go))
     dcol, dpos = orc.antialias_bwd(col, ref, pc, tri, go)
     np.testing.assert_allclose(c_t.grad.cpu().numpy(), dcol, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(p_t.grad.cpu().numpy(), dpos, rtol=5e-3, atol=5e-3 * np.abs(dpos).max())
+    np.testing.assert_allclose(p_t.grad.cpu().numpy(), dpos, rtol=5e-4, atol=5e-4 * np.abs(dpos).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     # the silhouette ops (antialias of the coverage image, in place, no colour operand): against the oracle's antialias of
     # interpolate(ones), and against the general op on the same colour
     from diffdope_amd.render import _silhouette_func, build_topology
@@ -216,7 +216,7 @@ def test_renderer_ops_forward_backward_vs_oracle():
     np.testing.assert_allclose(mask.detach().cpu().numpy(), mref, rtol=1e-5, atol=2e-5)
     mask.backward(T(go))
     _, dpos = orc.antialias_bwd(cover, ref, pc, tri, go)
-    np.testing.assert_allclose(p_t.grad.cpu().numpy(), dpos, rtol=5e-3, atol=5e-3 * np.abs(dpos).max())
+    np.testing.assert_allclose(p_t.grad.cpu().numpy(), dpos, rtol=5e-4, atol=5e-4 * np.abs(dpos).max())  # (round 5: a tenth of round 4's tolerance; passes at a third of this)
     p2 = T(pc, requires_grad=True)
     dd.antialias(T(cover), rast, p2, tri_t).backward(T(go))
     np.testing.assert_allclose(p_t.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * np.abs(dpos).max())
