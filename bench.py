@@ -90,7 +90,7 @@ def cpu_baseline(w, budget_s=12.0):
         kw = dict(uv=npy(w["uv"]), tex=npy(w["tex"])) if w["tex"] is not None else dict(vtx_color=npy(w["vtx_color"]))
         wts = {k: w["weights"].get(k) for k in ("rgb", "depth", "mask", "edge")}
         return orc.RenderOracle(npy(w["pos"]), npy(w["tri"]), npy(w["proj"]), w["H"], w["W"], {k: npy(v) for k, v in w["gt"].items()}, wts,
-                                dtype=np.float32, cull_backfaces=True, **kw)
+                                dtype=np.float32, cull_backfaces=False, **kw)  # (both faces: dr.rasterize's rule, as `value`)
 
     R = oracle_of(w)
     B = w["B"]
@@ -493,7 +493,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # (kept under 128 characters: the driver's parser cuts the string there)
             "config": {"workload": f"{args.config}: blob mesh T={T} V={V}, tex {tex_hw[0]}^2, {w['W']}x{w['H']}, {Bl} hyps/GPU, "
-                                   f"losses {'+'.join(sorted(w['weights']))}, {args.optimizer}, coverage {100 * w['coverage']:.2f}%",
+                                   f"{'+'.join(sorted(w['weights']))}, {args.optimizer}, both faces, cov {100 * w['coverage']:.2f}%",
+                       "rasteriser_rule": "both faces of every triangle drawn, as dr.rasterize (diffdope.py:198-200); also.cfg2_cull = deviation D5",
                        "hypotheses_per_gpu": Bl, "global_hypotheses": B_job, "parallelism": f"hyp-shard x{world}",
                        "hipgraph": bool(args.graph), "settle_ms": args.settle_ms,
                        "closing_barrier": ("torch.distributed.barrier()" if args.closing_barrier else "the job's all_reduce") if use_dist else "synchronize (one rank)"},
@@ -545,12 +546,13 @@ def main():
             out["also"] = {f"{args.config}_{other}": {"iters_per_s": args.steps / r2["elapsed"], "ms_per_step": r2["elapsed"] / args.steps * 1e3,
                                                       "what": ("the reference's SGD" if other == "sgd" else "Adam") + ", same workload"}}
             if args.distance is None and args.config == "cfg2":
-                # the reference's rasteriser rule: dr.rasterize (diffdope.py:198-200) draws BOTH faces of every triangle; the engine's
-                # default culls the back faces of a closed mesh inside the view volume (DESIGN.md deviation D5: same pixels in exact
-                # arithmetic; tools/cull_sweep.py counts how often float arithmetic differs).  Timed exactly like `value`.
-                rn = timed(w, args.optimizer, cull_backfaces=False)
-                out["also"]["cfg2_nocull"] = {"iters_per_s": args.steps / rn["elapsed"], "ms_per_step": rn["elapsed"] / args.steps * 1e3,
-                                              "what": "both faces drawn, as dr.rasterize does (cull_backfaces=False); same window as `value`"}
+                # `value` follows the reference's rasteriser rule: dr.rasterize (diffdope.py:198-200) draws BOTH faces of every triangle
+                # (workloads.engine_for: cull_backfaces=False).  Deviation D5 as an option: the back faces of a closed mesh inside the
+                # view volume skipped (same pixels in exact arithmetic; tools/cull_sweep.py counts how often float arithmetic differs).
+                # Timed exactly like `value`.
+                rn = timed(w, args.optimizer, cull_backfaces=True)
+                out["also"]["cfg2_cull"] = {"iters_per_s": args.steps / rn["elapsed"], "ms_per_step": rn["elapsed"] / args.steps * 1e3,
+                                            "what": "RefineEngine(cull_backfaces=True), deviation D5: back faces of the closed mesh skipped; same window as `value`"}
                 # BASELINE.md's own form of the metric: 200 iterations after 20 warm-up iterations, same workload and engine settings
                 rc = timed(w, args.optimizer, steps=200, warmup=20)
                 out["also"]["cfg2_contract200"] = {"iters_per_s": 200 / rc["elapsed"], "ms_per_step": rc["elapsed"] / 200 * 1e3, "steps": 200, "warmup": 20,

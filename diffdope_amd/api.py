@@ -109,16 +109,18 @@ def dist_batch_lr(tensor, learning_rates, channels=[1, 2, 3]):
 
 def _lr_weights(ddope, weight):
     """learning_rates * weight / B: with it, (v * learning_rates).mean() * weight (dist_batch_lr and the term's weight, diffdope.py:
-    534-544) is one weighted sum of v, which masked_l1_mean folds into its own launches.  Cached per (learning_rates, weight)."""
+    534-544) is one weighted sum of v, which masked_l1_mean folds into its own launches.  Cached per (the learning_rates TENSOR
+    OBJECT, its version counter, weight): the entry holds the tensor itself, so a replaced tensor can neither be mistaken for the
+    old one at a recycled address nor be freed under the cache.  (An edit through `learning_rates.data` bumps no version counter
+    and is not seen: assign a new tensor or write in place through the tensor itself, as set_batchsize and the examples do.)"""
     lr = ddope.learning_rates
-    tag = (lr.data_ptr(), lr._version, tuple(lr.shape), lr.device)
     cache = getattr(ddope, "_lr_weights_cache", None)
-    if cache is None or cache[0] != tag:
-        cache = (tag, {})
+    if cache is None or cache[0] is not lr or cache[1] != lr._version:
+        cache = (lr, lr._version, {})
         ddope._lr_weights_cache = cache
-    if float(weight) not in cache[1]:
-        cache[1][float(weight)] = (lr.detach() * (float(weight) / lr.shape[0])).contiguous()
-    return cache[1][float(weight)]
+    if float(weight) not in cache[2]:
+        cache[2][float(weight)] = (lr.detach() * (float(weight) / lr.shape[0])).contiguous()
+    return cache[2][float(weight)]
 
 
 def l1_rgb_with_mask(ddope):
@@ -619,11 +621,17 @@ class DiffDope:
         self.losses_values.add(key, values.detach().clone())
 
     # ---- rendering -------------------------------------------------------------------------------
-    def _render(self, mtx, outputs=None):
+    def _render(self, mtx, outputs=None, compact_mask=False):
         r = self.object3d.mesh()
         kw = dict(uv=r["uv"], uv_idx=r["uv_idx"], tex=r["tex"]) if self.object3d.mesh.has_textured_map else dict(vtx_color=r["vtx_color"])
         return render_texture_batch(glctx=self.glctx, proj_cam=self.camera.cam_proj, mtx=mtx, pos=r["pos"], pos_idx=r["pos_idx"],
-                                    resolution=self.resolution, outputs=outputs, **kw)
+                                    resolution=self.resolution, outputs=outputs, compact_mask=compact_mask, **kw)
+
+    def _builtin_losses_only(self):
+        """Every loss function of this run is one of this module's own (they read `mask` through masked_l1_mean, which works on the
+        one stored channel of a compact mask): only then does the loop ask render_texture_batch for the compact form -- a user
+        function gets the reference's ordinary [B,H,W,3] tensor (diffdope.py:212-214)."""
+        return bool(self.loss_functions) and all(f in _BUILTIN_LOSSES for f in self.loss_functions)
 
     def _loop_outputs(self):
         """What the loss functions of this run read from self.renders: known for the built-in ones (None = everything: a user
@@ -813,7 +821,7 @@ class DiffDope:
             prm.grad = None
         result = self.object3d()
         mtx_gu = matrix_batch_44_from_position_quat(p=result["trans"], q=result["quat"])
-        self.renders = self._render(mtx_gu, outputs=self._loop_outputs())
+        self.renders = self._render(mtx_gu, outputs=self._loop_outputs(), compact_mask=self._builtin_losses_only())
         loss = None  # (the reference starts from torch.zeros(1): a fill, an addition and a reshaping in the backward for nothing)
         for loss_function in self.loss_functions:
             l = loss_function(self)

@@ -80,7 +80,9 @@ def refine_frame(cfg, camera, scene, objects, meshes, masks, rank=0, world=1, op
     if mode == "group" and engines:
         from .engine import RefineEngineGroup
 
-        RefineEngineGroup(engines).run()
+        group = RefineEngineGroup(engines)
+        group.run()
+        group.finish()  # (synchronises and validates: a run whose in-launch tile pass timed out is repeated here, by the group)
     for i, dd in handles.items():
         dd.finish_optimization()
         best = int(dd.get_argmin())

@@ -5,6 +5,7 @@ built-in losses entirely on the device.  All buffers are torch tensors owned her
 only borrows pointers.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -126,10 +127,19 @@ class RefineEngine:
         self.handle = h
         self.it = 0
         self._unchecked = False  # a run has been enqueued that ddx_engine_run_check has not seen yet
+        self._group = None       # weak reference to the RefineEngineGroup whose run this engine's unchecked run was part of
         self.repeated_runs = 0   # runs ddx_engine_run_check had to repeat (the in-launch tile pass timed out: ddx.h)
 
     def _run_check(self):
-        """ddx_engine_run_check: synchronises the current stream; True when the last run was void and has been repeated."""
+        """ddx_engine_run_check: synchronises the current stream; True when the last run was void and has been repeated.  A run
+        that was part of a group's run is checked -- and, if void, repeated -- by the GROUP (ddx_engine_group_run_check: the
+        members ran in shared launches, one of them alone cannot be repeated)."""
+        grp = self._group() if self._group is not None else None
+        if grp is not None and grp._unchecked:
+            rep = grp._run_check()
+            self.repeated_runs += int(rep)
+            return rep
+        self._group = None
         rc = self.lib.ddx_engine_run_check(self.handle, _lib.stream_ptr())
         if rc not in (0, 1):
             _lib.check(rc, "ddx_engine_run_check")
@@ -257,9 +267,15 @@ class RefineEngine:
                     flags=st[7], repeated_runs=self.repeated_runs)
 
     def check(self):
+        """status() with its invariants enforced: no overflow, and no void run left standing -- status() has already let
+        ddx_engine_run_check act on a run whose bounded in-kernel wait ran out, so a flag that is STILL set means the results in
+        the buffers are void (a run of a group that nobody checked, a raw-handle caller): raise rather than hand them out."""
         st = self.status()
         if st["overflow"]:
             raise RuntimeError("engine reported an internal overflow")
+        if st["flags"]:
+            raise RuntimeError(f"engine status flags {st['flags']}: the last run is void (a bounded in-kernel wait ran out) and has not been "
+                               "repeated -- call finish() on the engine or on the group it ran in")
         return st
 
     def profile(self, it0=0, iters=5):
@@ -316,6 +332,10 @@ class RefineEngineGroup:
         if rc not in (0, 1):
             _lib.check(rc, "ddx_engine_group_run_check")
         self._unchecked = False
+        for e in self.engines:  # (the members' runs were this run: checked with it)
+            if e._group is not None and e._group() is self:
+                e._unchecked = False
+                e._group = None
         self.repeated_runs += int(rc == 1)
         return rc == 1
 
@@ -331,9 +351,15 @@ class RefineEngineGroup:
         n = e0.max_iters - e0.it if n is None else n
         if self._unchecked:
             self._run_check()
+        for e in self.engines:  # (a member with an unchecked run of its own: validated before the group builds on it)
+            if e._unchecked:
+                e._run_check()
         _lib.check(self.lib.ddx_engine_group_run(self.handle, e0.it, n, _lib.stream_ptr()), "ddx_engine_group_run")
         for e in self.engines:
             e.it += n
+            if n > 0:  # whoever synchronises a member next (finish / status / losses / a further run) checks the GROUP's run
+                e._unchecked = True
+                e._group = weakref.ref(self)
         self._unchecked = n > 0
 
     def invalidate(self):

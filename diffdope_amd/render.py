@@ -14,9 +14,10 @@ are returned as `PixelDerivativesNotComputed` placeholders of the right shape th
 interpolate / texture, as the reference does) but raise RuntimeError as soon as any arithmetic, indexing or copy
 consumes them, so a user loss that relies on them fails loudly instead of reading zeros; only filter_mode="linear" /
 boundary wrap is implemented (mip-mapped filtering raises); everything needs ROCm tensors (no CPU fallback);
-render_texture_batch's `mask` is, on its fused path, a [B,H,W,3] VIEW of one stored channel (last stride 0: its three channels are
-one number per pixel in the reference too) -- reading it, reducing it and differentiating through it work as on any tensor,
-writing into it in place needs a .clone() first (compact_mask=False stores the three copies).
+render_texture_batch's `mask` is an ordinary contiguous [B,H,W,3] tensor, as in the reference (diffdope.py:212-214); with
+compact_mask=True -- what the built-in loss loop of DiffDope asks for -- it is a [B,H,W,3] VIEW of one stored channel (last stride
+0: its three channels are one number per pixel in the reference too), which reads, reduces and differentiates like any tensor but
+cannot be written in place or .view()ed flat.
 """
 import numpy as np
 import torch
@@ -615,7 +616,7 @@ def _one_copy(t):
 
 
 def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None, uv_idx=None, tex=None, vtx_color=None,
-                         return_rast_out=False, fused=None, restrict_rows=True, compact_mask=True, outputs=None):
+                         return_rast_out=False, fused=None, restrict_rows=True, compact_mask=False, outputs=None):
     """The materialising render of diffdope.py:156-234 (same signature and outputs), for user loss functions that read
     ddope.renders; the built-in losses take the fused engine (diffdope_amd.engine) instead.
 
@@ -630,11 +631,12 @@ def render_texture_batch(glctx, proj_cam, mtx, pos, pos_idx, resolution, uv=None
     restrict_rows (fused path; round 4): the passes only visit the pixel rows each hypothesis draws into (the rows of its active
     tiles, from the rasteriser): outside them a pixel is background by construction, so nothing is read there -- the same
     images and gradients, bit for bit, at a fraction of the traffic (an object at 1.2 % of the frame spans a fifth of the rows).
-    compact_mask (fused path; round 5): the three channels of `mask` are one number per pixel (the reference interpolates a tensor
-    of ones, :212), so ONE is stored and `mask` is its expand(..., 3): the same shape and values, a zero stride on the last axis
-    (an in-place write into it needs a .clone() first).  masked_l1_mean recognises the view and works on the stored channel; any
-    other consumer sees an ordinary [B,H,W,3] tensor whose gradient autograd sums over the channels.  compact_mask=False: three
-    stored copies.
+    compact_mask (fused path): False (default) = `mask` is an ordinary contiguous [B,H,W,3] tensor, as the reference returns it
+    (:212-214): mask.view(B, -1) and in-place writes work.  True (what DiffDope's loop passes when every loss function is a built-in
+    one): the three channels are one number per pixel (the reference interpolates a tensor of ones, :212), so ONE is stored and
+    `mask` is its expand(..., 3): the same shape and values, a zero stride on the last axis.  masked_l1_mean recognises the view and
+    works on the stored channel (a third of the traffic); any other reader sees a [B,H,W,3] tensor whose gradient autograd sums over
+    the channels, but an in-place write or a flat .view() raises.
     outputs (fused path): None = all; a collection of names from ("rgb", "depth", "mask") = what the caller will read -- without
     "rgb" the colour pass (texture fetches, 12 bytes per pixel written) is left out and the entry is None; likewise "depth", and "mask" with its antialias pass.
     """

@@ -105,8 +105,12 @@ def bench_lr_schedule(n_it, optimizer):
 
 def engine_for(w, lrs, optimizer="sgd", params=None, global_batch=None, **kw):
     """RefineEngine on workload `w` exactly as bench.py times it (the parity tests build theirs through this too).
+    Both faces of every triangle are drawn unless the caller asks for `cull_backfaces=True`: dr.rasterize never culls
+    (diffdope/diffdope.py:198-200), and that rule is the one measured and tested (DESIGN.md deviation D5 is an option).
     Returns (engine, params): params [7,B] is updated in place by the engine."""
     from .engine import RefineEngine
+
+    kw.setdefault("cull_backfaces", False)
 
     params = w["params0"].clone() if params is None else params
     eng = RefineEngine(w["pos"], w["tri"], w["proj"], [w["H"], w["W"]], w["gt"], params, w["lr_mult"], lrs, w["weights"],

@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 KEYS = ("rgb", "depth", "mask_selection", "edge")
 
 
-def _oracle_for(w, dtype=np.float32):
+def _oracle_for(w, dtype=np.float32, cull=False):
     from oracle import oracle as orc
 
     npy = lambda t: None if t is None else t.detach().cpu().numpy()
     kw = dict(uv=npy(w["uv"]), tex=npy(w["tex"])) if w["tex"] is not None else dict(vtx_color=npy(w["vtx_color"]))
     wts = {k: w["weights"].get(k) for k in ("rgb", "depth", "mask", "edge")}
     R = orc.RenderOracle(npy(w["pos"]), npy(w["tri"]), npy(w["proj"]), w["H"], w["W"], {k: npy(v) for k, v in w["gt"].items()},
-                         wts, dtype=dtype, cull_backfaces=True, **kw)
+                         wts, dtype=dtype, cull_backfaces=cull, **kw)
     if dtype != np.float32:  # (the observed images are float32 data: the same numbers, widened)
         R.gt = {k: v.astype(dtype) for k, v in R.gt.items()}
     return R
@@ -39,18 +39,21 @@ def _pose_close(pa, pb, tol_rad=1e-3, tol_m=1e-3):
     return worst
 
 
+@pytest.mark.parametrize("cull", [False, True], ids=["both_faces", "culled"])
 @pytest.mark.parametrize("name,B,shard", [
     ("cfg2", 64, {}), ("cfg1", 1, {}), ("cfg1", 4, {}),
     ("cfg3", 128, {}),                                  # BASELINE configs[2] at its own batch: 51 200 triangles, rgb + depth + edge
     ("cfg4", 64, dict(global_lo=192, global_B=512)),    # configs[3]: rank 3's share of the 512-hypothesis job (untextured, depth + mask)
     ("cfg50k64", 64, {}),                               # north_star target sentence: 64 hypotheses of the 50k-triangle mesh
 ])
-def test_fused_engine_on_the_bench_workload_against_oracle(name, B, shard):
+def test_fused_engine_on_the_bench_workload_against_oracle(name, B, shard, cull):
     """The engine as bench.py builds it (cfg2: 80x128 mesh = 20 480 triangles, 640x480, rgb+mask, distance 7.5, 64 hypotheses;
     cfg1: 77x90 mesh = 13 860 triangles, 160x120, mask only; cfg3: 160x160 mesh = 51 200 triangles, 128 hypotheses, rgb + depth +
     edge; cfg4: 100x150 mesh = 30 000 triangles, vertex colours, depth + mask, hypotheses 192..255 of a global batch of 512):
     evaluation pass of the whole batch, two hypotheses against the oracle (losses rtol 5e-6, pose gradient 2e-5 of its largest
-    component, and against the oracle run in float64 as referee), duplicated hypotheses bit-identical, and the first optimiser iteration (SGD) reproduces params - lr * grad."""
+    component, and against the oracle run in float64 as referee), duplicated hypotheses bit-identical, and the first optimiser iteration (SGD) reproduces params - lr * grad.
+    cull = False: both faces of every triangle drawn -- dr.rasterize's rule (diffdope.py:198-200), the engine as bench.py's `value`
+    and the DiffDope API run it; cull = True: deviation D5 (back faces of the closed mesh skipped), engine and oracle alike."""
     from diffdope_amd import workloads as wl
 
     w = wl.build(name, torch.device("cuda"), B=B, **shard)
@@ -64,17 +67,17 @@ def test_fused_engine_on_the_bench_workload_against_oracle(name, B, shard):
         lrm[dup[1]] = lrm[dup[0]]
     w = dict(w, params0=p0, lr_mult=lrm)
     lrs = wl.bench_lr_schedule(25, "sgd")
-    eng, params = wl.engine_for(w, lrs, optimizer="sgd")
-    assert eng.desc.B == B and eng.desc.B_global == w["global_B"]
+    eng, params = wl.engine_for(w, lrs, optimizer="sgd", cull_backfaces=cull)
+    assert eng.desc.B == B and eng.desc.B_global == w["global_B"] and eng.desc.no_backface_cull == int(not cull)
     losses, grad = eng.loss_and_grad()
     torch.cuda.synchronize()
     st = eng.check()
-    assert st["active_tiles"] > 0
+    assert st["active_tiles"] > 0 and (eng.cull_sign != 0) == cull
     assert torch.equal(params, p0)
     lg, g = losses.cpu().numpy(), grad.cpu().numpy()
     if dup:
         assert np.array_equal(lg[:, dup[0]], lg[:, dup[1]]) and np.array_equal(g[:, dup[0]], g[:, dup[1]])
-    R = _oracle_for(w)
+    R = _oracle_for(w, cull=cull)
     pn, ln = p0.cpu().numpy(), lrm.cpu().numpy()
     for b in sorted({0, B // 2}):
         total, logs, g_ref, _ = R.loss_and_grad(pn[:, b:b + 1], ln[b:b + 1], global_B=w["global_B"])
@@ -92,7 +95,7 @@ def test_fused_engine_on_the_bench_workload_against_oracle(name, B, shard):
             # component away from it (texture lookups and L1 signs at pixels whose residual is an ulp: cfg50k64 4.9e-3, cfg2 1.2e-3,
             # cfg4 1.3e-6) -- the float32 oracle exactly as far as the kernel, which agree with EACH OTHER to 1e-7; the kernel must
             # be no further from the float64 gradient than a small multiple of what the float32 oracle is
-            R64 = _oracle_for(w, np.float64)
+            R64 = _oracle_for(w, np.float64, cull=cull)
             g64 = R64.loss_and_grad(pn[:, b:b + 1].astype(np.float64), ln[b:b + 1].astype(np.float64), global_B=w["global_B"])[2]
             scale = max(float(np.abs(g64).max()), 1e-12)
             e_gpu, e_orc = float(np.abs(g[:, b] - g64[:, 0]).max()) / scale, float(np.abs(g_ref[:, 0] - g64[:, 0]).max()) / scale

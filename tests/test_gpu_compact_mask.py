@@ -55,6 +55,29 @@ def test_one_stored_channel_equals_three(name):
     assert torch.allclose(ga, gb, rtol=2e-4, atol=2e-4 * float(ga.abs().max()))
 
 
+def test_default_mask_is_an_ordinary_tensor_as_the_reference_returns_it():
+    """render_texture_batch(...)["mask"] without asking for anything (diffdope.py:212-214 returns an ordinary
+    tensor): contiguous [B,H,W,3], mask.view(B, -1) works, an in-place write works and does not reach rgb / depth; the values are
+    those of the compact form, which only DiffDope's built-in loss loop asks for."""
+    from diffdope_amd.render import RasterizeContext, render_texture_batch
+
+    w, ex, kw, mtx = _scene("cfg2")
+    B, H, W = mtx.shape[0], w["H"], w["W"]
+    r = render_texture_batch(RasterizeContext(), ex(w["proj"]), mtx, ex(w["pos"]), ex(w["tri"]), [H, W], **kw)
+    m = r["mask"]
+    assert tuple(m.shape) == (B, H, W, 3) and m.is_contiguous() and m.stride(-1) == 1
+    flat = m.view(B, -1)
+    assert flat.shape == (B, H * W * 3)
+    c = render_texture_batch(RasterizeContext(), ex(w["proj"]), mtx, ex(w["pos"]), ex(w["tri"]), [H, W], compact_mask=True, **kw)
+    assert c["mask"].stride(-1) == 0 and torch.equal(c["mask"].contiguous(), m)
+    with pytest.raises(RuntimeError):
+        c["mask"].view(B, -1)
+    before, rgb0 = m.clone(), r["rgb"].clone()
+    m.mul_(0.5)
+    m[..., 1] += 1.0
+    assert torch.equal(m[..., 0], before[..., 0] * 0.5) and torch.equal(m[..., 1], before[..., 1] * 0.5 + 1.0) and torch.equal(r["rgb"], rgb0)
+
+
 def test_outputs_without_rgb():
     """outputs=("depth", "mask"): no colour image, depth and mask and their gradient as with it; outputs=("rgb",): the colour image
     alone, the same bits."""
@@ -139,12 +162,13 @@ def test_the_api_loop_renders_what_its_losses_read():
     B = 4
     seen = []
 
-    def user_mask_loss(ddope):  # (not a built-in: everything is rendered for it)
-        seen.append(ddope.renders["rgb"] is not None)
+    def user_mask_loss(ddope):  # (not a built-in: everything is rendered for it, and `mask` is the reference's ordinary tensor)
+        m = ddope.renders["mask"]
+        seen.append(ddope.renders["rgb"] is not None and m.is_contiguous() and m.view(m.shape[0], -1).shape[1] == m[0].numel())
         return api.l1_mask(ddope)
 
     a = _ddope(sc, ("depth", "mask"), B)
-    assert a._loop_outputs() == ("depth", "mask")
+    assert a._loop_outputs() == ("depth", "mask") and a._builtin_losses_only()
     a.run_optimization(fused=False)
     b = _ddope(sc, ("depth", "mask"), B)
     b.loss_functions = [f if f is not api.l1_mask else user_mask_loss for f in b.loss_functions]
