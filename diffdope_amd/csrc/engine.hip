@@ -115,8 +115,6 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
 
 // EngineState::flags
 #define ENGINE_FLAG_INLINE_TIMEOUT 1  // a shading workgroup gave up waiting for the workers of the in-launch tile pass (big_wait)
-#define ENGINE_FLAG_RUN_TIMEOUT 2     // run_kernel (the one-launch form of a run): a bounded wait of a team ran out
-#define ENGINE_FLAG_RUN_BIG 4         // run_kernel met a large / near-clipped triangle (its teams do not run the tile pass): the run is void
 
 // step_kernel(mode): STEP_FIRST draws the first iteration of a run from the caller's parameters (no optimiser step);
 // STEP_NORMAL steps the optimiser for iteration it - 1 and draws iteration it
@@ -208,13 +206,6 @@ struct EngineDev {
     float* run_snap;         // [21,B] parameters (7) and optimiser moments (14) as the LAST run / evaluation found them, written by its first
                              // step launch: what ddx_engine_run_check restores before it repeats a run whose in-launch tile pass timed out
     unsigned wait_ticks;     // big_wait's budget in ticks of the 100 MHz clock (DDX_BIG_WAIT_US; default 20 ms)
-    struct RunCtl* rctl;     // run_kernel's control block (tickets, team slots, queues): all zero between runs
-    float* fin_mtx;          // [B,16] run_kernel: the pose each hypothesis drew its run's LAST iteration with (system-scope stores: read by the
-                             // workgroup that writes the selection row, on whatever XCD it runs)
-    unsigned close_ticks;    // run_kernel: how long the first member of a team waits for the team to fill before it closes it undersized
-    int dbg_run;             // DDX_DEBUG_RUN (tests), bits: 1 = every team closes at once (teams of whatever has arrived: sizes 1..G);
-                             // 2 = the members of a team never learn its size (their wait runs out: the host's fallback);
-                             // 4 = the arrivals at the team barriers as workgroup-scope atomics (measurement)
     int dbg_reverse;         // DDX_DEBUG_REVERSE_SLABS=1 (tests): the worker slab of the in-launch tile pass BEHIND the shading slabs --
                              // the dispatch order in which the wait cannot be satisfied while the shading workgroups fill the chip
 };
@@ -252,12 +243,6 @@ struct ddx_engine {
     int probe_outcome = -1;  // ddx_engine_two_chains: the last answer of ensure_side_stream (-1: never asked)
     // the last run that ddx_engine_run_check has not yet seen clean, as it would have to be repeated (kind 0: none)
     struct { int kind = 0, it0 = 0, n = 0, use_graph = 0, sel_lo = 0; float* sel_out = nullptr; } last;
-    // the one-launch form of a run (run_kernel)
-    int run_kernel_on = 0;     // desc.one_launch_run / DDX_RUN_KERNEL=1: eligible runs take the one-launch form (default: launches -- measured faster)
-    bool run_kernel_off = false;  // a run in that form was void (ddx_engine_run_check): launches from then on
-    int run_resident = 0;      // run_kernel workgroups the chip holds at once (asked once); DDX_RUN_RESIDENT overrides
-    int run_team = 0;          // DDX_RUN_TEAM: workgroups per team (a power of two), 0 = from B and the residency
-    int run_form = 0;          // the form of the last run: 0 launches, 1 one launch (ddx_engine_run_form)
     int fwd_cached_it = -1;  // >= 0: dev.eval_tmp holds d loss / d params of the ddx_render_loss_fwd pass at this iteration (for the
                              // ddx_render_loss_bwd that follows); any other pass of the engine invalidates it
 };
@@ -281,25 +266,6 @@ __device__ __forceinline__ int group_find(const GroupHdr& G, int g)  // the memb
     for (int i = 1; i < G.n; ++i) o += g >= G.bpre[i] ? 1 : 0;
     return o;
 }
-
-// ---- run_kernel's control block (see there)
-#define RUN_MAXT 128  // team slots per XCD (a workgroup whose ticket lies beyond them leaves at once)
-struct RunTeam {      // one 128-byte line per team
-    unsigned join;    // members so far | RUN_CLOSED once its first member has closed it undersized
-    unsigned size;    // 0 until the team is complete / closed, then its size
-    unsigned hyp;     // the hypothesis the team works on (>= B: none left), published before a team barrier
-    unsigned bar;     // arrivals at the team's barriers, monotonic over the launch
-    unsigned pad[28];
-};
-struct RunCtl {
-    unsigned xq[8][32];   // [x][0]: workgroups that have started on XCD x (their tickets)
-    unsigned hq[32];      // [0]: next hypothesis
-    unsigned exits[32];   // [0]: workgroups that have left
-    unsigned acc[32];     // [0] active tiles, [1] hypotheses outside the view volume, [2] large triangles -- of every hypothesis' last iteration
-    RunTeam team[8][RUN_MAXT];
-};
-#define RUN_CLOSED 0x10000u
-static inline size_t run_ctl_bytes() { return sizeof(RunCtl); }
 
 // meshlet geometry of the two step_kernel variants (triangles, vertex slots): dense = (2, 256), small = (1, 64) threads
 static inline void mesh_geometry(bool small_mesh, int& ntri, int& nvc)
@@ -332,8 +298,6 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_etmp = carve((size_t)7 * d.B * sizeof(float));
     const size_t o_rsnap = carve((size_t)21 * d.B * sizeof(float));
     const size_t o_inside = carve((size_t)d.B * sizeof(int));
-    const size_t o_rctl = carve(run_ctl_bytes());
-    const size_t o_fin = carve((size_t)d.B * 16 * sizeof(float));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_spart = carve(((size_t)d.H * d.W / 4096 + 1) * 40);  // SetupPart per chunk of SETUP_CHUNK = 4096 pixels
@@ -371,8 +335,6 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.eval_tmp = (float*)(p + o_etmp);
     E.run_snap = (float*)(p + o_rsnap);
     E.inside = (int*)(p + o_inside);
-    E.rctl = (struct RunCtl*)(p + o_rctl);
-    E.fin_mtx = (float*)(p + o_fin);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.setup_part = (struct SetupPart*)(p + o_spart);
@@ -647,50 +609,6 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// LOADS OF WHAT ANOTHER WORKGROUP OF THE SAME LAUNCH HAS WRITTEN (run_kernel, the one-launch form of a run: template argument
-// PERS).  A CU's vector L1 is never refreshed by another CU's stores, and a launch that lives for a whole run sees the same
-// addresses rewritten every iteration: such a load must be served by the XCD's L2 -- `sc1` (what a relaxed agent-scope atomic load
-// lowers to; the 16-byte form is two 8-byte ones).  The producers use plain stores (write-through to L2, the line stays there) and
-// agent-scope atomics, drained (s_waitcnt vmcnt(0)) before the team barrier; producer and consumer sit on ONE XCD by construction
-// (run_kernel forms its teams per XCC_ID), so nothing has to travel further than that L2: tools/ubench/persist_proto.hip checks
-// exactly this protocol word by word under uneven load with an L1-warm consumer (profiles/r5a_ubench_persist_proto.jsonl).
-// PERS = false: the plain load the kernels of the launch form have always used -- their code does not change.
-template <bool PERS, typename T>
-__device__ __forceinline__ T ldd(const T* p)
-{
-    if (PERS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool PERS>
-__device__ __forceinline__ float4 ldd4(const float* p)
-{
-    if (PERS) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
-    }
-    return ld4(p);
-}
-template <bool PERS>
-__device__ __forceinline__ uint4 ldd4u(const unsigned* p)
-{
-    if (PERS) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32));
-    }
-    return *reinterpret_cast<const uint4*>(p);
-}
-// (a uniform value of that kind back into a scalar register: the plain form is a scalar load already)
-template <bool PERS>
-__device__ __forceinline__ float ldd_uniform(const float* p)
-{
-    if (PERS) return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
-    return *p;
-}
-
 // decode candidate pair `desc` = pixel lane | kind << 6 of the quadrant at (qx,qy):
 // kind 0: (p, right)  1: (p, up)  2: (left, p)  3: (down, p).  h0/h1 = halo indices of pixel0 / pixel1.
 __device__ __forceinline__ void pair_decode(int desc, int& h0, int& h1, int& d)
@@ -718,19 +636,17 @@ struct AAUnit {
 
 // silhouette flags (bit k = edge k) of a triangle cut by the eye plane; out of line and with its own loads (L2 hits): the rare path
 // must not cost the mask role registers
-template <bool PERS = false>
 __device__ __attribute__((noinline)) static int aa_sil_straddler(const float* __restrict__ P, int v0, int v1, int v2, int o0, int o1, int o2)
 {
-    const float4 p0 = ldd4<PERS>(P + (size_t)v0 * 4), p1 = ldd4<PERS>(P + (size_t)v1 * 4), p2 = ldd4<PERS>(P + (size_t)v2 * 4);
+    const float4 p0 = ld4(P + (size_t)v0 * 4), p1 = ld4(P + (size_t)v1 * 4), p2 = ld4(P + (size_t)v2 * 4);
     const float D = aa_det3_xyw(p0, p1, p2);
     int m = 7;
-    if (o0 >= 0) { const float4 q = ldd4<PERS>(P + (size_t)o0 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p1, p2)) != sign_bit(D)) m &= ~1; }
-    if (o1 >= 0) { const float4 q = ldd4<PERS>(P + (size_t)o1 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p2, p0)) != sign_bit(D)) m &= ~2; }
-    if (o2 >= 0) { const float4 q = ldd4<PERS>(P + (size_t)o2 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p0, p1)) != sign_bit(D)) m &= ~4; }
+    if (o0 >= 0) { const float4 q = ld4(P + (size_t)o0 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p1, p2)) != sign_bit(D)) m &= ~1; }
+    if (o1 >= 0) { const float4 q = ld4(P + (size_t)o1 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p2, p0)) != sign_bit(D)) m &= ~2; }
+    if (o2 >= 0) { const float4 q = ld4(P + (size_t)o2 * 4); if (q.w > 0.f && sign_bit(aa_det3_xyw(q, p0, p1)) != sign_bit(D)) m &= ~4; }
     return m;
 }
 
-template <bool PERS = false>
 __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const int4* __restrict__ rec, const float* __restrict__ pos,
                                              int H, int W, int px, int py, int d, int t0, int t1, AAUnit& o)
 {
@@ -754,8 +670,8 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     float ps[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        p[i] = ldd4<PERS>(P + (size_t)vi[i] * 4);
-        q[i] = ldd4<PERS>(P + (size_t)(ov[i] >= 0 ? ov[i] : vi[i]) * 4);
+        p[i] = ld4(P + (size_t)vi[i] * 4);
+        q[i] = ld4(P + (size_t)(ov[i] >= 0 ? ov[i] : vi[i]) * 4);
         ps[i][0] = pos[(size_t)vi[i] * 3 + 0]; ps[i][1] = pos[(size_t)vi[i] * 3 + 1]; ps[i][2] = pos[(size_t)vi[i] * 3 + 2];
     }
     // (every component of the six vertices is wanted HERE: left alone the compiler narrows the 16-byte loads -- w first, for the
@@ -797,7 +713,7 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
     } else {
         // a triangle cut by the eye plane (oracle aa_eval_pair, raster_math.h aa_eval_pair): homogeneous orientation tests; only
         // the edges with both endpoints in front can be the crossed edge
-        const int m = aa_sil_straddler<PERS>(P, vi[0], vi[1], vi[2], ov[0], ov[1], ov[2]);
+        const int m = aa_sil_straddler(P, vi[0], vi[1], vi[2], ov[0], ov[1], ov[2]);
         sil[0] = (m & 1) != 0; sil[1] = (m & 2) != 0; sil[2] = (m & 4) != 0;
     }
     if (!(sil[0] || sil[1] || sil[2])) return;
@@ -867,7 +783,6 @@ __device__ __forceinline__ void aa_eval_unit(const float* __restrict__ P, const 
 // whose rank is sl mod S are this slice's: those numbered [win, win + SCAN_LIST) among them go to list[] (ty << 8 | tx); g_active
 // (nullable) receives the whole ordered list.  Returns the number of set flags of the row.  Kept out of line: inlined, its loop
 // nest around the shading loop cost the kernel 34 spilled registers.
-template <bool PERS = false>
 __device__ __attribute__((noinline)) static int tile_scan(const unsigned* __restrict__ frow, int n_dw, int S, int sl, float invS, int ntx, int win,
                                                           unsigned short* list, int* g_active)
 {
@@ -879,7 +794,7 @@ __device__ __attribute__((noinline)) static int tile_scan(const unsigned* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int di = d0 + u * 256 + lane * 4;
-            dd[u] = di < n_dw ? ldd4u<PERS>(frow + di) : make_uint4(0u, 0u, 0u, 0u);
+            dd[u] = di < n_dw ? *reinterpret_cast<const uint4*>(frow + di) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -934,7 +849,7 @@ struct TileWork {
     unsigned short* list;      // LDS, this wave's: tiles [win, win + SCAN_LIST) of the slice, ty << 8 | tx
 };
 
-template <int ROLE, bool WLUM /* edge build: the colour role also feeds the edge term */, bool PERS = false /* inside run_kernel: ldd */>
+template <int ROLE, bool WLUM /* edge build: the colour role also feeds the edge term */>
 __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict__ pool, const TileWork& tw)
 {
     __shared__ int s_ids[WAVES_PER_TILE][QH * QH + 4];  // zbuf id + 1 (0 = background), -1 = outside the image
@@ -953,7 +868,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     if (ROLE == 0) {
         const float* Fm = E.mats + ((size_t)par * d.B + b) * 32 + 16;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { Fx[c] = ldd_uniform<PERS>(Fm + c); Fy[c] = ldd_uniform<PERS>(Fm + 4 + c); Fw[c] = ldd_uniform<PERS>(Fm + 12 + c); }
+        for (int c = 0; c < 4; ++c) { Fx[c] = *(Fm + c); Fy[c] = *(Fm + 4 + c); Fw[c] = *(Fm + 12 + c); }
     }
     // every lane accumulates its pixels' terms over ALL the tiles of the workgroup; one wave reduction, one fold over the four
     // waves and one partial row per (slice, role) at the end (update_head sums min(slices, tiles) rows per role)
@@ -969,7 +884,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
     for (int k = 0; k < n_mine; ++k) {
         if ((k & (SCAN_LIST - 1)) == 0 && k > 0) {  // further windows (a frame-filling object with few slices) on demand
             wave_lds_sync();
-            tile_scan<PERS>(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, k, tw.list, nullptr);
+            tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, k, tw.list, nullptr);
             wave_lds_sync();
         }
         const int txy8 = tw.list[k & (SCAN_LIST - 1)];
@@ -993,7 +908,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             // cfg2 shade 18.2 -> 19.0 us, 4.7 % coverage 38.3 -> 40.0: 13 spilled registers instead of 10, and the other waves of the SIMD
             // already cover the round trip)
             if (px < W && py < H) {
-                const unsigned long long key = ldd<PERS>(zb + zaddr(px, py, L.zwb));
+                const unsigned long long key = *(zb + zaddr(px, py, L.zwb));
                 id = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
             }
             if (__ballot(id > 0) == 0ull) continue;  // nothing drawn in this quadrant: only background terms
@@ -1008,7 +923,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                 const int gx = qx - 1 + e % QH, gy = qy - 1 + e / QH;
                 int v = -1;
                 if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
-                    const unsigned long long key = ldd<PERS>(zb + zaddr(gx, gy, L.zwb));
+                    const unsigned long long key = *(zb + zaddr(gx, gy, L.zwb));
                     v = key == ~0ull ? 0 : (int)(unsigned)(key & 0xffffffffull) + 1;
                 }
                 ids[e] = v;
@@ -1114,7 +1029,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             if (d.use_depth) {
                 const float k = d.w_depth * lrb * inv_b / ((float)H * (float)W);
                 const float* M = E.mats + ((size_t)par * d.B + b) * 32;
-                const float m20 = ldd_uniform<PERS>(M + 8), m21 = ldd_uniform<PERS>(M + 9), m22 = ldd_uniform<PERS>(M + 10), m23 = ldd_uniform<PERS>(M + 11);
+                const float m20 = *(M + 8), m21 = *(M + 9), m22 = *(M + 10), m23 = *(M + 11);
                 const float gbx = __fmaf_rn(w2, x2, __fmaf_rn(v, x1, u * x0));
                 const float gby = __fmaf_rn(w2, y2, __fmaf_rn(v, y1, u * y0));
                 const float gbz = __fmaf_rn(w2, z2, __fmaf_rn(v, z1, u * z0));
@@ -1174,7 +1089,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                     int h0, h1, dd;
                     pair_decode(s_pairs[wave][j], h0, h1, dd);
                     const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
-                    aa_eval_unit<PERS>(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
+                    aa_eval_unit(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
                     if (pr.valid) {
                         const int ht = pr.target0 ? h0 : h1;
                         const int tx = ht % QH - 1, ty = ht / QH - 1;
@@ -1219,7 +1134,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
                         pair_decode(s_pairs[wave][j], h0, h1, dd);
                         const int t0 = ids[h0] - 1, t1 = ids[h1] - 1;
                         AAUnit pr;
-                        aa_eval_unit<PERS>(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
+                        aa_eval_unit(P, E.trirec, pos, H, W, qx - 1 + h0 % QH, qy - 1 + h0 / QH, dd, t0, t1, pr);
                         if (pr.valid && !pr.clamped) {
                             const int ht = pr.target0 ? h0 : h1;
                             const int tx = ht % QH - 1, ty = ht / QH - 1;
@@ -1341,7 +1256,7 @@ __device__ __attribute__((noinline)) static void big_wait(int* arrive, int S, un
     __syncthreads();
 }
 
-template <bool EDGE, bool PERS = false /* inside run_kernel: the iteration is named, the tile pass is the team's business, loads are ldd */>
+template <bool EDGE>
 __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int S, int z, int it_arg)
 {
     // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's active tiles in ascending tile order.  There is no list kernel:
@@ -1363,7 +1278,7 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
     tw.b = b;
     const int it_cur = it_arg >= 0 ? it_arg : E.st->it_next - 1;  // the iteration being drawn (it_next is stable during this launch)
     tw.par = it_cur & 1;
-    if (!PERS && z == 0 && sl == 0 && b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
+    if (z == 0 && sl == 0 && b == 0 && tid == 0) E.st->it = it_cur + 1;  // read by the next step_kernel / finish_kernel
     tw.sl = sl;
     tw.S = S;
     tw.frow = reinterpret_cast<const unsigned*>(L.tile_flag + ((size_t)tw.par * E.d.B + tw.b) * L.NTp);
@@ -1374,16 +1289,16 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int 
     const int wg_id = (z * S + sl) * E.d.B + b;
     STAMP(E, 1, wg_id, 0);
     // (inline tile pass: the hypothesis' count of large triangles, requested before the scan and looked at after it)
-    const int n_big_list = (!PERS && E.big_inline) ? __builtin_amdgcn_readfirstlane(L.bigcount[(size_t)tw.par * E.d.B + b]) : 0;
-    tw.n_flags = tile_scan<PERS>(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, 0, tw.list, lister ? L.active + (size_t)tw.b * L.NT : nullptr);
+    const int n_big_list = E.big_inline ? __builtin_amdgcn_readfirstlane(L.bigcount[(size_t)tw.par * E.d.B + b]) : 0;
+    tw.n_flags = tile_scan(tw.frow, tw.n_dw, tw.S, tw.sl, tw.invS, L.ntx, 0, tw.list, lister ? L.active + (size_t)tw.b * L.NT : nullptr);
     tw.n_mine = tw.n_flags > tw.sl ? (tw.n_flags - tw.sl + tw.S - 1) / tw.S : 0;
     wave_lds_sync();
     if (lister && tw.sl == 0 && lane == 0) L.b_count[tw.b] = tw.n_flags;
     if (n_big_list > 0) big_wait(L.bigarrive + (size_t)tw.par * E.d.B + b, min(S, E.big_workers), E.wait_ticks, &E.st->flags);  // (workgroup-uniform; rare)
     STAMP(E, 1, wg_id, 1);
     const int role = z == 0 ? E.roles[0] : E.roles[1];
-    if (role == 0) shade_body<0, EDGE, PERS>(E, pool, tw);
-    else shade_body<1, EDGE, PERS>(E, pool, tw);
+    if (role == 0) shade_body<0, EDGE>(E, pool, tw);
+    else shade_body<1, EDGE>(E, pool, tw);
     STAMP(E, 1, wg_id, 2);
     STAMP(E, 1, wg_id, 3);
     if (tid == 0 && E.trace && wg_id < TRACE_WG) E.trace[((size_t)TRACE_WG + wg_id) * 8 + 4] = ((unsigned long long)z << 32) | (unsigned)tw.n_mine;
@@ -1585,23 +1500,64 @@ __global__ __launch_bounds__(256) void edge_group_kernel(const EngineDev* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// The optimiser step of iteration j for hypothesis b: the head of step_kernel and all of finish_kernel.
-// EVERY workgroup of the hypothesis runs it, redundantly (one kernel less in the iteration's chain; the partial rows are a few
-// KB from L2): fixed-order sum of the hypothesis' partial rows (one per shade / edge slice and role), whole-frame constants +
-// the background depth term sum |seg| |d_bg - gt| of the whole frame from the depth-sorted seg list with prefix sums in
-// double (two 64-way searches on one wave + six loads), proj^T chain, quaternion chain, SGD/Adam (lane-parallel tail), loss
-// log.  Workgroup `slice` of `n_slices` also re-arms its share of what iteration j dirtied (zbuf of the active tiles and their
-// flags, parity j & 1), and slice 0 writes parameters, optimiser state and logs.  Returns (after a barrier) with
-// snew[0..6] = the updated parameters and sc[16..31] = proj in LDS.
-// The sum is grouped the same way whatever the workgroup size (8 buckets of rows q = bucket mod 8, folded pairwise), so the
-// 64- and 256-thread variants of step_kernel produce the same bits.
-#define UPD_SLICES 8  // workgroups per hypothesis of finish_kernel; fewer for large batches (upd_slices())
+#define UPD_SLICES 8  // step_kernel: at least this many slots per hypothesis where the chip holds them (they share the re-arm of the previous iteration's tiles)
 
-template <int NTH, bool SEL = false /* finish_kernel: the selection of ddx_engine_run_select is compiled in */, bool PERS = false /* inside run_kernel: ldd */>
-__device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, int slice, int n_slices, float* snew, float* sc)
+// THE OPTIMISER HEAD OF A HYPOTHESIS, RUN BY THE LAST WORKGROUP THAT FINISHES ITS SHADING (round 6).
+// Through round 5 the optimiser step of iteration j -- fixed-order sum of the hypothesis' partial rows, whole-frame constants, proj^T
+// and quaternion chains, SGD / Adam, loss log -- was the HEAD of step_kernel: every one of the 20 workgroups of a hypothesis ran it,
+// redundantly, in front of its rasteriser work (4.6-5.3 us of an 18-19 us step phase per workgroup, ~40 % of the launch's
+// instructions: HISTORY.md round 5 items 1 and 8), and finish_kernel ran it once more at the end of a run.  Now the last kernel of
+// an iteration that writes partial rows (shade_kernel; edge_kernel with the edge term) counts its workgroups per hypothesis, and
+// the LAST ARRIVER of hypothesis b runs the head ONCE: it sums the rows in the same fixed order (the same bits), steps the
+// optimiser, and leaves what the next iteration's step_kernel needs -- mtx | final of the new pose in mats[(j + 1) & 1] -- so that
+// step_kernel's head is ONE 16-byte load per lane, requested together with its first meshlet.  finish_kernel is gone: the head of a
+// run's last iteration also selects (ddx_engine_run_select), re-arms what that iteration dirtied and leaves the status words.
+//
+// HAND-OVER (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"; cdna_hip_programming.md Guideline 16,
+// the counter form of R1).  Nothing depends on dispatch order, placement or residency, and nobody waits:
+//   producer   the partial row leaves as 8-byte agent-scope (sc1, write-through) stores by lanes of wave 0; that wave drains its
+//              stores (asm s_waitcnt vmcnt(0): performed, whatever XCD the reader sits on) and THEN lane 0 adds one to the
+//              hypothesis' arrival counter (relaxed, agent scope: performed in memory order behind the drained stores).
+//   consumer   the workgroup whose add returns target - 1 knows every row of the hypothesis is in memory; it reads them with
+//              sc1 loads (served by L2 / memory, never by its CU's L1, which another CU's stores do not refresh).  No fence on
+//              either side: a release fence would write back the XCD's whole L2 (1.7-6.5 us per workgroup, price list) for 96 bytes.
+//   everything else the head reads (parameters, optimiser moments, matrices, schedule) was written by EARLIER launches.
+// The arrival counters are zero between iterations: the last arriver puts its own back to zero.
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one partial row [NPART] from the four per-wave rows in LDS, as sc1 stores: lanes 0..11 of wave 0 write 8 bytes each
+__device__ __forceinline__ void store_partial_row(float* part, const float (*s_rows)[NPART], int tid)
 {
-    constexpr int NG = NTH / 32, NW = NTH / 64, NBK = 8 / NG;  // groups of 32 threads, waves, row buckets per thread
-    constexpr int SPEC = 64 / 8;                               // rows per bucket requested before the tile count is known (64 rows in all)
+    if (tid < NPART / 2) {
+        const int i = 2 * tid;
+        const float a = (s_rows[0][i] + s_rows[1][i]) + (s_rows[2][i] + s_rows[3][i]);
+        const float b = (s_rows[0][i + 1] + s_rows[1][i + 1]) + (s_rows[2][i + 1] + s_rows[3][i + 1]);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(part) + tid, ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Count this workgroup among the `target` workgroups of hypothesis b in this launch; true (workgroup-uniform) for the last one.
+// Called by ALL threads, after the workgroup's partial row (if it has one) has been issued by wave 0.
+__device__ __forceinline__ bool hyp_arrive(const EngineDev& E, int b, int target)
+{
+    __shared__ int s_last;
+    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // wave 0: its row has been performed
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(E.arrive + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == target - 1 ? 1 : 0;
+        if (s_last) __hip_atomic_store(E.arrive + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nobody else touches it before the next iteration's launch)
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// the head proper: 256 threads of ONE workgroup.  j = the iteration whose rows are summed; n_act = its active tiles; fin = this
+// is the last iteration of a run (or an evaluation pass): selection, re-arm of parity j & 1, status words.
+// The sum is grouped as it always was (8 buckets of rows q = bucket mod 8, thread group g of 32 sums bucket g in ascending row
+// order, buckets 2w and 2w + 1 folded first, then the four pairs): the bits of rounds 2-5.
+__device__ __attribute__((noinline)) static void hyp_head(const EngineDev& E, int b, int j, int n_act, int fin)
+{
     const ddx_engine_desc& d = E.d;
     const int B = d.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1610,20 +1566,15 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
     __shared__ float sG[16];
     __shared__ float sgrad[8];
     __shared__ float s_bg[2];
-    const int NT = E.L.NT;
+    __shared__ float sc[64];    // params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45
+    __shared__ float snew[8];   // the updated parameters
     const int cur = j & 1;
-    const int jj = tid % 32, grp = tid / 32;  // thread jj < NVALS of group g sums value jj of the rows of its buckets
-#ifdef DDX_TRACE_HEAD
-#define HSTAMP(i) do { if (E.trace && tid == 0 && NTH == 256 && b * n_slices + slice < TRACE_WG) E.trace[((size_t)2 * TRACE_WG + b * n_slices + slice) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define HSTAMP(i)
-#endif
+    const int jj = tid % 32, grp = tid / 32;  // thread jj < NVALS of group grp sums value jj of the rows q = grp mod 8
+    const int hw = b;
+    (void)hw;
+#define HSTAMP(i) STAMP(E, 2, b, i)
     HSTAMP(0);
-    const int n_act = ldd<PERS>(E.L.b_count + b);
-    const int* tiles = E.L.active + (size_t)b * NT;
-    // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the partial
-    // rows (speculative: rows of slices beyond the tile count are stale and masked below), the first tile of the re-arm
-    // share, the totals of the sorted seg list.  The head is a chain of dependent round trips; these would otherwise each add one.
+    // ---- everything is requested at once: the partial rows (sc1), the scalars of the tail, the totals of the sorted seg list
     const int rmask = E.role_mask;
     constexpr int NR = NROLE;
     const int PS = E.pslices, nrow = PS * NR;
@@ -1632,88 +1583,48 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
         const int r = q % NR, s = q / NR;
         return q < nrow && ((rmask >> r) & 1) && s < (r == 2 ? E.s_edge : E.s_shade);
     };
-    float v0[NBK][SPEC];
+    const int nlive = min(PS, n_act) * NR;  // (slice s has a tile <=> s < n_act)
+    float v0[8];
 #pragma unroll
-    for (int i = 0; i < NBK; ++i)
-#pragma unroll
-        for (int u = 0; u < SPEC; ++u) {
-            const int q = (grp + NG * i) + 8 * u;
-            v0[i][u] = (jj < NVALS && row_ok(q)) ? ldd<PERS>(pbase + (size_t)q * NPART) : 0.f;
-        }
-    const int txy_first = slice < NT ? ldd<PERS>(tiles + slice) : 0;
+    for (int u = 0; u < 8; ++u) {
+        const int q = grp + 8 * u;
+        v0[u] = (jj < NVALS && q < nlive && row_ok(q)) ? ld_sc1(pbase + (size_t)q * NPART) : 0.f;
+    }
     const int ns = d.use_depth ? E.nseg : 0;  // (the size of the sorted seg list is known to the host since setup)
     const double segWn = E.seg_W[ns], segGn = E.seg_G[ns];
-    // ---- the scalars of the tail, one per thread, into LDS: params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45
     float sc_val = 0.f;
-    if (tid < 7) sc_val = ldd<PERS>(E.params2 + ((size_t)cur * 7 + tid) * B + b);
+    if (tid < 7) sc_val = E.params2[((size_t)cur * 7 + tid) * B + b];
     else if (tid == 7) sc_val = E.b.lr_mult[b];
     else if (tid == 8) sc_val = E.b.lr_sched[j];
     else if (tid >= 16 && tid < 32) sc_val = E.b.proj[tid - 16];
-    else if (tid >= 32 && tid < 46) sc_val = ldd<PERS>(E.adam + ((size_t)cur * 14 + (tid - 32)) * B + b);
-    const float dbg = -ldd<PERS>(E.mats + ((size_t)cur * B + b) * 32 + 11);
+    else if (tid >= 32 && tid < 46) sc_val = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
+    const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
     // ---- partial sums, fixed order => bit-reproducible
-    float acc[NBK];
-    {
-        const int nlive = min(PS, n_act) * NR;  // (slice s has a tile <=> s < n_act)
+    float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < NBK; ++i) {
-            acc[i] = 0.f;
-            const int q0 = grp + NG * i;
+    for (int u = 0; u < 8; ++u) acc += v0[u];
+    if (jj < NVALS)
+        for (int q1 = grp + 64; q1 < nlive; q1 += 64) {
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < SPEC; ++u) acc[i] += (q0 + 8 * u < nlive) ? v0[i][u] : 0.f;
-            if (jj < NVALS)
-                for (int q1 = q0 + 8 * SPEC; q1 < nlive; q1 += 64) {
-                    float v[8];
+            for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per row)
+                const int q = q1 + 8 * u;
+                v[u] = (q < nlive && row_ok(q)) ? ld_sc1(pbase + (size_t)q * NPART) : 0.f;
+            }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per row)
-                        const int q = q1 + 8 * u;
-                        v[u] = (q < nlive && row_ok(q)) ? ldd<PERS>(pbase + (size_t)q * NPART) : 0.f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc[i] += v[u];
-                }
+            for (int u = 0; u < 8; ++u) acc += v[u];
         }
-    }
-    HSTAMP(1);
     if (tid < 46) sc[tid] = sc_val;
-    // ---- re-arm what iteration j dirtied (zbuf of its active tiles, their flags; parity j & 1) so that no pass needs a
-    // memset: tile k of the hypothesis' list is re-armed by workgroup k % n_slices.  Independent of the sums.
-    {
-        unsigned long long* Z = E.L.zbuf + ((size_t)cur * B + b) * E.L.zper;
-        unsigned char* flag = E.L.tile_flag + ((size_t)cur * B + b) * E.L.NTp;
-        unsigned char* big = E.L.tile_big + ((size_t)cur * B + b) * E.L.NTp;
-        for (int k = slice; k < n_act; k += n_slices) {  // (workgroup-uniform)
-            const int txy = k == slice ? txy_first : ldd<PERS>(tiles + k);
-            const int tx = txy & 0xffff, ty = txy >> 16;
-            if (tid == 0) {
-                flag[ty * E.L.ntx + tx] = 0;
-                big[ty * E.L.ntx + tx] = 0;
-            }
-#pragma unroll
-            for (int p = tid; p < DDX_TILE * DDX_TILE; p += NTH) {
-                const int zx = tx * DDX_TILE + p % DDX_TILE, zy = ty * DDX_TILE + p / DDX_TILE;
-                if (zx < d.W && zy < d.H) Z[zaddr(zx, zy, E.L.zwb)] = ~0ull;
-            }
-        }
-    }
-    // buckets 2w and 2w+1 are folded first (for 256 threads they live in the two halves of wave w), then the four pairs
-#pragma unroll
-    for (int i = 0; i < NBK; ++i) acc[i] += __shfl_xor(acc[i], 32, 64);
-    if (lane < NPART) {
-        if (NBK == 1) red[wave][lane] = acc[0];
-        else {
-#pragma unroll
-            for (int i = 0; i < NBK; ++i) red[i % 4][lane] = acc[i];  // (NTH = 64: thread group g in {0,1} holds buckets g, g+2, g+4, g+6 = pairs 0..3)
-        }
-    }
-    HSTAMP(2);
+    // buckets 2w and 2w+1 are folded first (they live in the two halves of wave w), then the four pairs
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < NPART) red[wave][lane] = acc;
+    HSTAMP(1);
     __syncthreads();
-    HSTAMP(3);
     if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     // ---- whole-frame background depth term: sum_i w_i |dbg - g_i| and sum_i w_i sgn(dbg - g_i) (w = |seg0|, g = observed depth)
     // from the sorted list: k1 = #(g < dbg), k2 = #(g <= dbg) by a 64-way search per round on the last wave (no barrier), then
     // prefix-sum differences in double
-    if (d.use_depth && wave == NW - 1) {
+    if (d.use_depth && wave == 3) {
         int lo1 = 0, hi1 = ns, lo2 = 0, hi2 = ns, k1 = -1, k2 = -1;
         while (k1 < 0 || k2 < 0) {  // (wave-uniform)
             const int span1 = hi1 - lo1, span2 = hi2 - lo2;
@@ -1740,39 +1651,33 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
         }
     }
     __syncthreads();
-    HSTAMP(4);
+    HSTAMP(2);
     const float bgsum = d.use_depth ? s_bg[0] : 0.f, bgder = d.use_depth ? s_bg[1] : 0.f;
     // ---- tail on wave 0, one lane per output where the work allows
-    const bool writer = slice == 0;
     if (wave == 0) {
         const float npx = (float)d.H * (float)d.W;
         const float lrb = sc[7];
-        // loss log: weighted, not LR-scaled (diffdope.py:558-560,576-578,604-608)
-        if (writer && lane < 4 && (E.eval_grad ? E.eval_loss != nullptr : E.b.loss_log != nullptr)) {
-            float v = 0.f;
-            if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
-            if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
-            if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
-            if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
-            if (E.eval_grad) E.eval_loss[(size_t)lane * B + b] = v;
-            else E.b.loss_log[((size_t)j * 4 + lane) * B + b] = v;
+        // the weighted, not LR-scaled losses of the hypothesis (diffdope.py:558-560,576-578,604-608): lanes 0..3
+        float lv = 0.f;
+        if (lane == 0 && d.use_rgb) lv = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
+        if (lane == 1 && d.use_depth) lv = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
+        if (lane == 2 && d.use_mask) lv = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
+        if (lane == 3 && d.use_edge) lv = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
+        if (lane < 4 && (E.eval_grad ? E.eval_loss != nullptr : E.b.loss_log != nullptr)) {
+            if (E.eval_grad) E.eval_loss[(size_t)lane * B + b] = lv;
+            else E.b.loss_log[((size_t)j * 4 + lane) * B + b] = lv;
         }
         // ---- arg-min over the hypotheses inside this launch (ddx_engine_run_select; get_argmin / get_pose, diffdope.py:1488-1513,
         // 1618-1632): the mean of the used loss rows exactly as select_best_kernel forms it, ties to the lowest index
-        if (SEL && writer && E.sel_out) {
-            float v = 0.f;
-            if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
-            if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
-            if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
-            if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
-            const float v0 = __shfl(v, 0, 64), v1 = __shfl(v, 1, 64), v2 = __shfl(v, 2, 64), v3 = __shfl(v, 3, 64);
+        if (fin && E.sel_out) {
+            const float l0 = __shfl(lv, 0, 64), l1 = __shfl(lv, 1, 64), l2 = __shfl(lv, 2, 64), l3 = __shfl(lv, 3, 64);
             if (lane == 0) {
                 float a = 0.f;
                 int n_used = 0;
-                if (d.use_rgb) { a += v0; ++n_used; }
-                if (d.use_depth) { a += v1; ++n_used; }
-                if (d.use_mask) { a += v2; ++n_used; }
-                if (d.use_edge) { a += v3; ++n_used; }
+                if (d.use_rgb) { a += l0; ++n_used; }
+                if (d.use_depth) { a += l1; ++n_used; }
+                if (d.use_mask) { a += l2; ++n_used; }
+                if (d.use_edge) { a += l3; ++n_used; }
                 a = __fdiv_rn(a, (float)max(n_used, 1));
                 if (a == a) {  // (a NaN loss never wins: select_best_kernel's comparisons)
                     unsigned u = __float_as_uint(a);
@@ -1793,16 +1698,12 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
                     }
                     // (a run whose in-launch tile pass timed out is void: NaN tells the reader of the row to call ddx_engine_run_check)
                     const int fl = __hip_atomic_load(&E.st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    E.sel_out[0] = fl ? __uint_as_float(0x7fc00000u) : best;
+                    const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the launch that set that pose)
+                    for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
                     E.sel_out[1] = (float)(w + E.sel_lo);
-                    if (PERS) {
-                        // (run_kernel: the winner's team may sit on another XCD -- its writer left the pose of the run's last iteration in
-                        // fin_mtx with system-scope stores, drained before it counted itself in sel_arrive)
-                        for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = __hip_atomic_load(E.fin_mtx + (size_t)w * 16 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    } else {
-                        const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the step_kernel that drew it)
-                        for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
-                    }
+                    // (the loss LAST, behind the rest of the row: a host that polls the row's first word in pinned memory reads a complete row)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(E.sel_out, fl ? __uint_as_float(0x7fc00000u) : best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(&E.st->sel_key, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&E.st->sel_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1838,7 +1739,7 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
         wave_lds_sync();
         // optimiser step: lane = parameter
         if (lane < 7 && E.eval_grad) {  // evaluation pass: hand out the gradient, leave every state as it is
-            if (writer) E.eval_grad[(size_t)lane * B + b] = sgrad[lane];
+            E.eval_grad[(size_t)lane * B + b] = sgrad[lane];
             snew[lane] = sc[lane];
         } else if (lane < 7) {
             const float g = sgrad[lane], lr = sc[8];
@@ -1850,37 +1751,101 @@ __device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, in
                 const float c1 = 1.f - exp2f((float)(j + 1) * log2f(b1)), c2 = 1.f - exp2f((float)(j + 1) * log2f(b2));
                 const float m1 = b1 * sc[32 + lane] + (1.f - b1) * g;
                 const float m2 = b2 * sc[39 + lane] + (1.f - b2) * g * g;
-                if (writer) {
-                    E.adam[((size_t)(1 - cur) * 14 + lane) * B + b] = m1;
-                    E.adam[((size_t)(1 - cur) * 14 + 7 + lane) * B + b] = m2;
-                }
+                E.adam[((size_t)(1 - cur) * 14 + lane) * B + b] = m1;
+                E.adam[((size_t)(1 - cur) * 14 + 7 + lane) * B + b] = m2;
                 pnew = sc[lane] - lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
             }
             snew[lane] = pnew;
-            if (writer) {
-                E.params2[((size_t)(1 - cur) * 7 + lane) * B + b] = pnew;
-                E.b.params[(size_t)lane * B + b] = pnew;
-            }
+            E.params2[((size_t)(1 - cur) * 7 + lane) * B + b] = pnew;
+            E.b.params[(size_t)lane * B + b] = pnew;
         }
-        if (!PERS && writer && b == 0) {
-            // status of iteration j (single lanes across kernel boundaries, no atomics; run_kernel: its last workgroup, from accumulators)
-            int tot = 0, out = 0;
-            for (int i = lane; i < B; i += 64) {
-                tot += E.L.b_count[i];
-                out += E.inside[i] == 0;
-            }
+        wave_lds_sync();
+        // ---- the pose of iteration j + 1: q/|q| (diffdope.py:1091), [R|t] (:46-89), final = proj . mtx (:195) -- lanes 0..3 hold the
+        // rows of both matrices -- into mats[(j + 1) & 1] (and the pose log): what step_kernel's head used to compute in every lane
+        if (!E.eval_grad && j + 1 < d.max_iters && lane < 4) {
+            float q[4], t3[3], M4[16], pr[4], Fr[4];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, 64); out += __shfl_xor(out, o, 64); }
-            if (lane == 0) {
-                E.st->last_active = tot;
-                E.st->outside = out;
-                E.st->last_pairs = E.L.counters[3 + cur];
+            for (int i = 0; i < 4; ++i) q[i] = snew[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t3[i] = snew[4 + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[k] = sc[16 + lane * 4 + k];  // row `lane` of proj
+            const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
+            quat_to_matrix(q, t3, M4);
+            final_row(pr, M4, Fr);
+            float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
+            float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)(j + 1) * B + b) * 16 : nullptr;
+            const float Mr[4] = {lane == 0 ? M4[0] : (lane == 1 ? M4[4] : (lane == 2 ? M4[8] : M4[12])), lane == 0 ? M4[1] : (lane == 1 ? M4[5] : (lane == 2 ? M4[9] : M4[13])),
+                                 lane == 0 ? M4[2] : (lane == 1 ? M4[6] : (lane == 2 ? M4[10] : M4[14])), lane == 0 ? M4[3] : (lane == 1 ? M4[7] : (lane == 2 ? M4[11] : M4[15]))};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dst[lane * 4 + c] = Mr[c];
+                dst[16 + lane * 4 + c] = Fr[c];
+                if (logm) logm[lane * 4 + c] = Mr[c];
             }
         }
     }
-    HSTAMP(5);
-    __syncthreads();
-    HSTAMP(6);
+    HSTAMP(3);
+    if (!fin) return;  // (workgroup-uniform)
+    // ---- the LAST iteration of a run (or an evaluation pass): nothing comes after it that would re-arm what iteration j dirtied
+    // (step_kernel of iteration j + 1 does that for iteration j), so this workgroup does, for its hypothesis: zbuf of the active
+    // tiles and their flags (parity j & 1), the tile pass's words; and the status words, once every hypothesis has come by.
+    {
+        __shared__ int s_n;
+        __shared__ unsigned short s_t[1024];  // (a trip looks at 1024 tiles)
+        unsigned long long* Z = E.L.zbuf + ((size_t)cur * B + b) * E.L.zper;
+        unsigned char* flag = E.L.tile_flag + ((size_t)cur * B + b) * E.L.NTp;
+        unsigned char* big = E.L.tile_big + ((size_t)cur * B + b) * E.L.NTp;
+        const unsigned* frow = reinterpret_cast<const unsigned*>(flag);  // (written by step_kernel / the tile pass: earlier launches)
+        const int n_dw = E.L.NTp >> 2;
+        for (int d0 = 0; d0 < n_dw; d0 += 256) {  // (workgroup-uniform) 1024 tiles per trip
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            const int di = d0 + tid;
+            unsigned w4 = di < n_dw ? frow[di] : 0u;
+            for (int k = 0; w4 && k < 4; ++k)
+                if ((w4 >> (8 * k)) & 0xffu) {
+                    s_t[atomicAdd(&s_n, 1)] = (unsigned short)(di * 4 + k - d0 * 4);  // (LDS atomic; the order does not matter)
+                }
+            __syncthreads();
+            const int n = s_n;
+            for (int k = 0; k < n; ++k) {  // (workgroup-uniform)
+                const int tile = d0 * 4 + (int)s_t[k], ty = tile / E.L.ntx, tx = tile - ty * E.L.ntx;
+#pragma unroll
+                for (int p = tid; p < DDX_TILE * DDX_TILE; p += 256) {
+                    const int zx = tx * DDX_TILE + p % DDX_TILE, zy = ty * DDX_TILE + p / DDX_TILE;
+                    if (zx < d.W && zy < d.H) Z[zaddr(zx, zy, E.L.zwb)] = ~0ull;
+                }
+            }
+            __syncthreads();
+            if (di < n_dw) {  // (every flag of the piece back to zero, set or not: plain dword stores)
+                reinterpret_cast<unsigned*>(flag)[di] = 0u;
+                reinterpret_cast<unsigned*>(big)[di] = 0u;
+            }
+        }
+    }
+    if (tid == 0) {
+        E.L.bigcount[(size_t)cur * B + b] = 0;
+        E.L.bigarrive[(size_t)cur * B + b] = 0;
+        // status of the run's last iteration: summed over the hypotheses as they come by; the last one publishes and re-arms
+        __hip_atomic_fetch_add(&E.st->acc_active, n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (E.inside[b] == 0) __hip_atomic_fetch_add(&E.st->acc_outside, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int came = __hip_atomic_fetch_add(&E.st->fin_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (came == B - 1) {
+            E.st->last_active = __hip_atomic_load(&E.st->acc_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            E.st->outside = __hip_atomic_load(&E.st->acc_outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            E.st->last_pairs = E.L.counters[3 + cur];
+            E.L.counters[3 + cur] = 0;
+            __hip_atomic_store(&E.st->acc_active, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&E.st->acc_outside, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&E.st->fin_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    HSTAMP(4);
 #undef HSTAMP
 }
 

@@ -17,6 +17,8 @@ import statistics
 import sys
 
 tag = sys.argv[1]
+BS = [int(a) for a in sys.argv[2:]] or [64, 128, 256, 512]   # the driver's batch sizes, in its order
+N_IT = 24                                                      # ... and its iterations per engine (BN_ITERS)
 root = f"gpurun_out/bn_{tag}"
 KEEP = ("step_kernel", "shade_kernel")
 CLK = 2.4e9
@@ -27,29 +29,39 @@ def short(name):
     return "step" if "step_kernel" in n else ("shade" if "shade_kernel" in n else n)
 
 
-def grid_of(r):
-    if "Grid_Size" in r and r["Grid_Size"]:
-        return int(r["Grid_Size"])
-    g = 1
-    for a in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"):
-        g *= int(r.get(a) or 1)
-    return g
+def rows_by_batch(path):
+    """(kernel, B) -> rows: the driver runs its engines one after the other, N_IT launches of each kernel per engine, so the k-th
+    launch of a kernel (in dispatch order) belongs to batch size BS[k // N_IT] (grids cannot tell: 20 slots x 64 hypotheses and
+    10 x 128 are both 1 280 workgroups)."""
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if any(k in r["Kernel_Name"] for k in KEEP):
+            per[short(r["Kernel_Name"])].append(r)
+    out = collections.defaultdict(list)
+    for k, rows in per.items():
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+        rank = {d: i for i, d in enumerate(ids)}
+        for r in rows:
+            i = rank[int(r["Dispatch_Id"])]
+            if i // N_IT < len(BS) and i % N_IT >= 2:  # (the first launches of an engine -- first iteration, calibration -- left out)
+                out[(k, BS[i // N_IT])].append(r)
+    return out
 
 
 # ---- durations from the un-profiled trace, per (kernel, grid); the first launches of an engine (set-up, first iteration) dropped
 dur = collections.defaultdict(list)
 for path in glob.glob(f"{root}/trace/**/*kernel_trace.csv", recursive=True):
-    for r in csv.DictReader(open(path)):
-        if any(k in r["Kernel_Name"] for k in KEEP):
-            dur[(short(r["Kernel_Name"]), grid_of(r))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-dur = {k: statistics.mean(sorted(v)[: max(1, len(v) * 3 // 4)][2:] or v) for k, v in dur.items()}
+    for kb, rows in rows_by_batch(path).items():
+        dur[kb] += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+dur = {k: statistics.mean(v) for k, v in dur.items()}
 # ---- counters
 val = collections.defaultdict(dict)
 for path in glob.glob(f"{root}/*/**/pmc_counter_collection.csv", recursive=True):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if any(k in r["Kernel_Name"] for k in KEEP):
-            acc[(short(r["Kernel_Name"]), grid_of(r), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, g), rows in rows_by_batch(path).items():
+        for r in rows:
+            acc[(k, g, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, g, c), v in acc.items():
         val[(k, g)][c] = statistics.median(v)
 
@@ -59,7 +71,7 @@ for k in ("step", "shade"):
     gs = sorted(g for (kk, g) in keys if kk == k)
     grids[k] = gs
 print(f"# Which unit saturates?  (tools/bottleneck_passes.sh {tag}; cfg2 mesh and frame, both faces, one chain of full-batch launches)\n")
-print("Batch sizes are told apart by the launches' grids; under `rocprofv3 --pmc` kernels run one at a time, so the load of a second "
+print("Batch sizes are told apart by the order of the launches; under `rocprofv3 --pmc` kernels run one at a time, so the load of a second "
       "chain beside the first is reproduced by doubling the hypotheses of ONE launch (the same load on every shared unit).\n")
 try:
     print("```\n" + open(f"{root}/trace.log").read().strip()[-600:] + "\n```\n")
@@ -156,7 +168,7 @@ for k in ("step", "shade"):
     if not gs:
         continue
     print(f"## {k}_kernel\n")
-    print("| | " + " | ".join(f"grid {g // 256} WGs" for g in gs) + " |")
+    print("| | " + " | ".join(f"{g} hypotheses" for g in gs) + " |")
     print("|---|" + "---|" * len(gs))
     rows, allc = frac_rows(k)
     for name, out in rows:
@@ -166,7 +178,7 @@ for k in ("step", "shade"):
         print(f"| {name} | " + " | ".join(cells) + " |")
     print()
     print("<details><summary>raw medians per launch</summary>\n")
-    print("| counter | " + " | ".join(str(g // 256) for g in gs) + " |")
+    print("| counter | " + " | ".join(str(g) for g in gs) + " |")
     print("|---|" + "---|" * len(gs))
     for c in allc:
         print(f"| {c} | " + " | ".join("" if val.get((k, g), {}).get(c) is None else f"{val[(k, g)][c]:,.0f}" for g in gs) + " |")
