@@ -558,13 +558,7 @@ def main():
                 out["also"]["cfg2_contract200"] = {"iters_per_s": 200 / rc["elapsed"], "ms_per_step": rc["elapsed"] / 200 * 1e3, "steps": 200, "warmup": 20,
                                                    "what": "BASELINE.md's window: 200 timed iterations after 20 warm-up (+ selection), behind the settle phase",
                                                    "no_settle_iters_per_s": (200 / rc["cold"]) if rc["cold"] else None}
-                # the one-launch form of a run (engine.hip run_kernel, ddx.h one_launch_run): the whole window -- first iteration, optimiser
-                # steps, selection -- as ONE kernel in which a team of workgroups per hypothesis meets at team barriers.  Same bits as the
-                # launches (tests/test_gpu_run_kernel.py); timed exactly like `value`.  It is the slower form, hence an option.
-                ro = timed(w, args.optimizer, one_launch_run=True)
-                out["also"]["cfg2_one_launch"] = {"iters_per_s": args.steps / ro["elapsed"], "ms_per_step": ro["elapsed"] / args.steps * 1e3,
-                                                  "what": "RefineEngine(one_launch_run=True): a run as one persistent launch; same window as `value`"}
-                del rn, rc, ro
+                del rn, rc
                 wc = wl.build(args.config, dev, B=Bl, distance=3.75)
                 r3 = timed(wc, args.optimizer)
                 out["also"]["cfg2_d3.75"] = {"iters_per_s": args.steps / r3["elapsed"], "ms_per_step": r3["elapsed"] / args.steps * 1e3,

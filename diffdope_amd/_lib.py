@@ -30,7 +30,7 @@ class EngineDesc(ctypes.Structure):
         ("adam_beta1", ctypes.c_float), ("adam_beta2", ctypes.c_float), ("adam_eps", ctypes.c_float),
         ("max_iters", ctypes.c_int32), ("use_edge", ctypes.c_int32), ("w_edge", ctypes.c_float),
         ("shade_slices", ctypes.c_int32), ("edge_slices", ctypes.c_int32), ("no_backface_cull", ctypes.c_int32),
-        ("compat", ctypes.c_int32), ("separate_big_pass", ctypes.c_int32), ("single_stream", ctypes.c_int32), ("one_launch_run", ctypes.c_int32),
+        ("compat", ctypes.c_int32), ("separate_big_pass", ctypes.c_int32), ("single_stream", ctypes.c_int32),
     ]
 
 
@@ -98,7 +98,6 @@ _SIGNATURES = {
     "ddx_engine_status_ptr": (_P, [_P]),
     "ddx_engine_cull_sign": (_I, [_P]),
     "ddx_engine_two_chains": (_I, [_P]),
-    "ddx_engine_run_form": (_I, [_P]),
     "ddx_engine_new_observation": (_I, [_P]),
     "ddx_engine_profile": (_I, [_P, _I, _I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), _I, _P]),
     "ddx_engine_destroy": (None, [_P]),

@@ -52,15 +52,11 @@ class RefineEngine:
             default: the set-up decides from the expected triangle size (no launch where no large triangle is expected; same results).
         single_stream: True = every launch of a run on the caller's stream (ddx.h single_stream); default: a run of 16 or more
             iterations goes out as two half-batch chains, one of them on a stream the engine owns (same results, bit for bit).
-        one_launch_run: True = where the engine is eligible (no edge term, dense mesh, no large triangle expected) a whole run is ONE
-            launch in which a team of workgroups per hypothesis meets at team barriers (ddx.h one_launch_run; same results, bit for
-            bit; `run_form` tells which form the last run took).  Default: a chain of launches, the faster form on MI355X.
     """
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
                  vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True, shade_slices=0,
-                 edge_slices=0, cull_backfaces=True, compat=None, separate_big_pass=False, single_stream=False,
-                 one_launch_run=False):
+                 edge_slices=0, cull_backfaces=True, compat=None, separate_big_pass=False, single_stream=False):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":
@@ -105,7 +101,6 @@ class RefineEngine:
         d.no_backface_cull = int(not cull_backfaces)
         d.separate_big_pass = int(bool(separate_big_pass))
         d.single_stream = int(bool(single_stream))
-        d.one_launch_run = int(bool(one_launch_run))
         d.compat = {None: 0, "nvdiffrast": _lib.COMPAT_UNCLAMPED_BARY_GRAD}[compat]
         self.desc = d
         nbytes = self.lib.ddx_engine_scratch_bytes(ctypes.byref(d))
@@ -237,12 +232,6 @@ class RefineEngine:
     def cull_sign(self):
         """0 = both faces drawn; +-1 = back faces (snapped area of that sign) culled (decided by the first run / eval)."""
         return int(self.lib.ddx_engine_cull_sign(self.handle))
-
-    @property
-    def run_form(self):
-        """The form the last run took: 1 = one launch (run_kernel: a team of workgroups per hypothesis for the whole run), 0 = launches
-        (ddx.h ddx_engine_run_form)."""
-        return int(self.lib.ddx_engine_run_form(self.handle))
 
     @property
     def two_chains(self):

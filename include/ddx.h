@@ -274,7 +274,7 @@ typedef struct ddx_engine_desc {
      * launches; never above 7 000 meshlet-hypothesis pairs, where one launch fills the chip; no graph replay, no capture in
      * progress, tile pass inside the shading launch, B a multiple of 16) as two chains of half-batch launches: one on the
      * caller's stream, one on a second stream of the library, forked from the caller's stream after the first iteration and joined to
-     * it before the run's last kernel -- so everything the call enqueues is still ordered on `stream` as far as the caller can
+     * it behind the run's last kernel -- so everything the call enqueues is still ordered on `stream` as far as the caller can
      * see, and the results are the same bit for bit.  The second stream comes from a process-wide registry keyed by (device,
      * caller stream): the first engine that needs one for a caller stream checks with two 30-us kernels that a candidate really
      * runs beside it (streams that share a hardware queue take turns), tries up to six, and records the answer -- one chain if
@@ -282,18 +282,6 @@ typedef struct ddx_engine_desc {
      * caller's stream only.  Environment DDX_TWO_STREAMS=0
      * has the same effect for every engine of the process; DDX_TWO_MIN=n forks every eligible run of n or more iterations. */
     int32_t single_stream;
-    /* 1: a run (ddx_engine_run / ddx_engine_run_select without graph replay, outside a capture) of an engine without the edge term,
-     * on a dense mesh (the 256-thread rasteriser variants) where the set-up expects no large triangle (see separate_big_pass), is
-     * ONE kernel launch: the hypotheses are independent, so each is advanced through all n iterations by a team of workgroups
-     * that meet at two team barriers per iteration -- no kernel boundary inside the run (engine.hip
-     * run_kernel).  Teams are formed per XCD from HW_REG_XCC_ID at run time and every phase works for any team size, so nothing is
-     * assumed about dispatch order, placement or residency; every wait is bounded (DDX_BIG_WAIT_US).  A wait that runs out sets
-     * bit 1 of status word 7, a hypothesis that has a large / near-clipped triangle after all sets bit 2; either way the launch
-     * terminates, its numbers are void (out18[0] = NaN) and ddx_engine_run_check repeats the run as launches, which this engine
-     * then keeps.  Same results as the launches, bit for bit.  0 (default): launches -- on MI355X they are the faster form at
-     * every batch size measured (cfg2: 38.4 against 53 us per iteration; profiles/r5b_run_kernel_*), which is why this form is an
-     * option and not the default.  Environment DDX_RUN_KERNEL=1 / 0 switches it for every engine of the process. */
-    int32_t one_launch_run;
 } ddx_engine_desc;
 
 typedef struct ddx_engine_buffers {
@@ -339,11 +327,12 @@ int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
  * (diffdope/diffdope.py:1488-1513, 1618-1632) for iteration it0 + n - 1 without a further launch: out18 (18 floats; device memory
  * or mapped pinned host memory) receives what ddx_select_best writes for that iteration's rows -- (mean over the engine's enabled
  * loss terms of the winner's weighted losses, lo + its local index, its 4x4 pose row-major), ties to the lowest index, a NaN
- * loss never wins.  With out18 in mapped host memory the end of a run costs one kernel and one synchronisation. */
+ * loss never wins.  The row is written by the run's last kernel (there is no closing launch: the optimiser step of every iteration
+ * runs in the tail of that iteration's last kernel), out18[0] LAST and behind the rest of the row: with out18 in mapped pinned host
+ * memory a caller may poll out18[0] (set it to a sentinel before the call) instead of synchronising the stream. */
 int ddx_engine_run_select(ddx_engine* e, int it0, int n, int use_graph, int lo, float* out18, void* stream);
 /* The host half of every bounded in-kernel wait (at present: the tile pass inside the shading launch, separate_big_pass above).
- * Synchronises `stream` and reads status word 7 (bit 0: the in-launch tile pass; bits 1, 2: the one-launch run, one_launch_run
- * above, which is then repeated as launches).  0: the work enqueued so far is valid.  1: a wait of the last ddx_engine_run /
+ * Synchronises `stream` and reads status word 7 (bit 0: the in-launch tile pass).  0: the work enqueued so far is valid.  1: a wait of the last ddx_engine_run /
  * ddx_engine_run_select ran out -- the engine has been switched to the separate tile-pass launch for good, parameters and
  * optimiser state have been put back to what that run started from (a snapshot its first kernel takes) and the run has been
  * repeated, same iterations, same out18, and has finished: its results are valid now, bit for bit those of an engine created
@@ -393,8 +382,6 @@ int ddx_engine_cull_sign(ddx_engine* e);
  * (a stream of the engine's was measured to run beside the caller's); 0 = probed and refused (streams sharing a hardware queue
  * take turns: one chain); -1 = not eligible or not probed yet. */
 int ddx_engine_two_chains(ddx_engine* e);
-/* The form the last run of this engine took: 1 = one launch (one_launch_run above), 0 = launches, -1 = NULL engine. */
-int ddx_engine_run_form(ddx_engine* e);
 /* The same object in a new frame (tracking): the caller has overwritten the contents of gt_rgb / gt_depth / gt_seg, params, lr_mult
  * and / or lr_sched IN PLACE (same buffers, same shapes); mesh, texture and projection are unchanged.  The next run / eval redoes
  * the observation half of the set-up only (frame constants, sorted segmentation list, optimiser state, iteration 0) and keeps the

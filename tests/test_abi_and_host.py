@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.ddx_rasterize_scratch_bytes(2, 60, 100, 48, 64) > 2 * 48 * 64 * 8
     d = _lib.EngineDesc()
     assert lib.ddx_engine_scratch_bytes(ctypes.byref(d)) == 0  # all-zero desc is invalid
-    assert ctypes.sizeof(_lib.EngineDesc) == 28 * 4 and ctypes.sizeof(_lib.EngineBuffers) == 17 * 8
+    assert ctypes.sizeof(_lib.EngineDesc) == 27 * 4 and ctypes.sizeof(_lib.EngineBuffers) == 17 * 8
 
 
 def test_ctypes_structs_follow_the_header_member_for_member():
