@@ -95,7 +95,7 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     int overflow;
     int last_pairs;
     int last_active;
-    int it;          // iteration the next step_kernel draws (written by one lane of shade_kernel, read by a step_kernel replayed from a graph)
+    int it;          // iteration the next step_kernel draws (written by one lane of shade_kernel, read by step / finish)
     int n_seg;       // entries in the compact seg list
     int it_next;     // iteration being drawn + 1 (written by one lane of step_kernel, read by big_pass / shade / edge): no kernel
                      // reads a word that the same launch writes
@@ -105,13 +105,12 @@ struct EngineState {  // device-resident; the first 8 ints are what ddx_engine_s
     double c_rgb;    // sum over the frame of |gt_rgb * seg|
     double c_mask;   // sum over the frame of |seg|
     double c_edge;   // sum over the frame of |Gx| + |Gy| of the observed, masked image (edge extension)
-    // selection of the best hypothesis inside the run's last kernel (ddx_engine_run_select; hyp_head): the hypotheses' heads fold
+    // selection of the best hypothesis inside finish_kernel (ddx_engine_run_select): the hypotheses' writer workgroups fold
     // (order-preserving bits of the mean loss << 32 | index) into sel_key with atomicMin and count themselves in sel_arrive; the
     // last one writes the [18] row.  Both words are all-ones / zero between runs (re-armed by that last workgroup).
     unsigned long long sel_key;
     int sel_arrive;
-    // the status words of a run's last iteration, summed over the hypotheses as their heads come by (hyp_head); all zero between runs
-    int fin_arrive, acc_active, acc_outside;
+    int sel_pad;
 };
 
 // EngineState::flags
@@ -130,7 +129,6 @@ struct EngineDev {
     float* mats;      // [2][B,2,16]: mtx | final, by iteration parity
     float* params2;   // [2][7,B]: the parameters, by iteration parity (b.params is the user-visible copy)
     float* partials;  // [B, pslices, NROLE, NPART]: one row per slice (workgroup of the shade / edge grid) and role
-    int* arrive;      // [B] workgroups of the iteration's last row-writing kernel that have finished hypothesis b (hyp_arrive); zero between launches
     float2* gtedge;   // [H*W] Sobel gradients of lum(gt_rgb * seg) (edge extension), or null
     float* lumbuf;    // [B,H*W] luminance of the rendered colour at covered pixels (written by the colour role, read by
     float* ubuf;      // [B,H*W,12] edge_kernel; garbage where zbuf says "background") and U = d lum / d final per pixel
@@ -202,7 +200,7 @@ struct EngineDev {
     float* eval_grad;        // [7,B] or null.  Non-null = evaluation pass (ddx_engine_eval): d loss / d params and the
     float* eval_loss;        // [4,B] losses are written here, no optimiser step
     float* eval_tmp;         // [7,B] gradient sink of ddx_render_loss_fwd
-    float* sel_out;          // [18] or null.  Non-null (the last kernel of ddx_engine_run_select): (mean loss of the best hypothesis, its
+    float* sel_out;          // [18] or null.  Non-null (finish_kernel of ddx_engine_run_select): (mean loss of the best hypothesis, its
     int sel_lo;              // global index = sel_lo + local index, its 4x4 pose) is written here by the last writer workgroup
     int b_off;               // first hypothesis of this launch (0 except in the half-batch launches of a two-stream run, engine_run_impl)
     float* run_snap;         // [21,B] parameters (7) and optimiser moments (14) as the LAST run / evaluation found them, written by its first
@@ -300,7 +298,6 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     const size_t o_etmp = carve((size_t)7 * d.B * sizeof(float));
     const size_t o_rsnap = carve((size_t)21 * d.B * sizeof(float));
     const size_t o_inside = carve((size_t)d.B * sizeof(int));
-    const size_t o_arrive = carve((size_t)d.B * sizeof(int));
     const size_t o_clip = carve((size_t)d.B * d.V * 4 * sizeof(float));
     const size_t o_seg = carve((size_t)d.H * d.W * sizeof(float2));
     const size_t o_spart = carve(((size_t)d.H * d.W / 4096 + 1) * 40);  // SetupPart per chunk of SETUP_CHUNK = 4096 pixels
@@ -338,7 +335,6 @@ static size_t engine_layout(EngineDev& E, const ddx_engine_desc& d, void* base)
     E.eval_tmp = (float*)(p + o_etmp);
     E.run_snap = (float*)(p + o_rsnap);
     E.inside = (int*)(p + o_inside);
-    E.arrive = (int*)(p + o_arrive);
     E.clip = (float*)(p + o_clip);
     E.seglist = (float2*)(p + o_seg);
     E.setup_part = (struct SetupPart*)(p + o_spart);
@@ -611,369 +607,6 @@ __device__ __forceinline__ void wave_lds_sync()
     // LDS operations of one wave execute in issue order; this only stops the compiler from moving them
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-#define UPD_SLICES 8  // step_kernel: at least this many slots per hypothesis where the chip holds them (they share the re-arm of the previous iteration's tiles)
-
-// THE OPTIMISER HEAD OF A HYPOTHESIS, RUN BY THE LAST WORKGROUP THAT FINISHES ITS SHADING (round 6).
-// Through round 5 the optimiser step of iteration j -- fixed-order sum of the hypothesis' partial rows, whole-frame constants, proj^T
-// and quaternion chains, SGD / Adam, loss log -- was the HEAD of step_kernel: every one of the 20 workgroups of a hypothesis ran it,
-// redundantly, in front of its rasteriser work (4.6-5.3 us of an 18-19 us step phase per workgroup, ~40 % of the launch's
-// instructions: HISTORY.md round 5 items 1 and 8), and finish_kernel ran it once more at the end of a run.  Now the last kernel of
-// an iteration that writes partial rows (shade_kernel; edge_kernel with the edge term) counts its workgroups per hypothesis, and
-// the LAST ARRIVER of hypothesis b runs the head ONCE: it sums the rows in the same fixed order (the same bits), steps the
-// optimiser, and leaves what the next iteration's step_kernel needs -- mtx | final of the new pose in mats[(j + 1) & 1] -- so that
-// step_kernel's head is ONE 16-byte load per lane, requested together with its first meshlet.  finish_kernel is gone: the head of a
-// run's last iteration also selects (ddx_engine_run_select), re-arms what that iteration dirtied and leaves the status words.
-//
-// HAND-OVER (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"; cdna_hip_programming.md Guideline 16,
-// the counter form of R1).  Nothing depends on dispatch order, placement or residency, and nobody waits:
-//   producer   the partial row leaves as 8-byte agent-scope (sc1, write-through) stores by lanes of wave 0; that wave drains its
-//              stores (asm s_waitcnt vmcnt(0): performed, whatever XCD the reader sits on) and THEN lane 0 adds one to the
-//              hypothesis' arrival counter (relaxed, agent scope: performed in memory order behind the drained stores).
-//   consumer   the workgroup whose add returns target - 1 knows every row of the hypothesis is in memory; it reads them with
-//              sc1 loads (served by L2 / memory, never by its CU's L1, which another CU's stores do not refresh).  No fence on
-//              either side: a release fence would write back the XCD's whole L2 (1.7-6.5 us per workgroup, price list) for 96 bytes.
-//   everything else the head reads (parameters, optimiser moments, matrices, schedule) was written by EARLIER launches.
-// The arrival counters are zero between iterations: the last arriver puts its own back to zero.
-__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// one partial row [NPART] from the four per-wave rows in LDS, as sc1 stores: lanes 0..11 of wave 0 write 8 bytes each
-__device__ __forceinline__ void store_partial_row(float* part, const float (*s_rows)[NPART], int tid)
-{
-    if (tid < NPART / 2) {
-        const int i = 2 * tid;
-        const float a = (s_rows[0][i] + s_rows[1][i]) + (s_rows[2][i] + s_rows[3][i]);
-        const float b = (s_rows[0][i + 1] + s_rows[1][i + 1]) + (s_rows[2][i + 1] + s_rows[3][i + 1]);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(part) + tid, ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// Count this workgroup among the `target` workgroups of hypothesis b in this launch; true (workgroup-uniform) for the last one.
-// Called by ALL threads, after the workgroup's partial row (if it has one) has been issued by wave 0.
-__device__ __forceinline__ bool hyp_arrive(const EngineDev& E, int b, int target)
-{
-    __shared__ int s_last;
-    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // wave 0: its row has been performed
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(E.arrive + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == target - 1 ? 1 : 0;
-        if (s_last) __hip_atomic_store(E.arrive + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nobody else touches it before the next iteration's launch)
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-
-// the head proper: 256 threads of ONE workgroup.  j = the iteration whose rows are summed; n_act = its active tiles; fin = this
-// is the last iteration of a run (or an evaluation pass): selection, re-arm of parity j & 1, status words.
-// The sum is grouped as it always was (8 buckets of rows q = bucket mod 8, thread group g of 32 sums bucket g in ascending row
-// order, buckets 2w and 2w + 1 folded first, then the four pairs): the bits of rounds 2-5.
-// A CALL: inlined into the shading kernels' tails the head would be allocated with them (128 registers, the mask role already spills);
-// as a function it is allocated on its own, and it reads the engine's description where it lies -- the kernel's argument segment
-// (EngineDev is the kernels' FIRST parameter) or the group's device table -- through the constant address space, so its fields
-// arrive by scalar loads as in a kernel.  (The address travels as an integer argument -- the kernarg-pointer intrinsic is null
-// inside a callee -- and through v_readfirstlane: arguments arrive in vector registers, and loads through a "divergent" pointer
-// would be vector loads.)
-typedef const EngineDev __attribute__((address_space(4))) * EngineArgPtr;
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }  // (an argument every lane holds the same value of)
-__device__ __forceinline__ const EngineDev& engine_at(unsigned long long ek)
-{
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ek), hi = __builtin_amdgcn_readfirstlane((unsigned)(ek >> 32));
-    return *(const EngineDev*)(EngineArgPtr)(((unsigned long long)hi << 32) | lo);
-}
-
-__device__ __attribute__((noinline)) static void hyp_head(unsigned long long ek, int b, int j, int n_act, int fin)
-{
-    const EngineDev& E = engine_at(ek);
-    b = uni(b); j = uni(j); n_act = uni(n_act); fin = uni(fin);
-    const ddx_engine_desc& d = E.d;
-    const int B = d.B;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ float red[4][NPART];
-    __shared__ float sums[NPART];
-    __shared__ float sG[16];
-    __shared__ float sgrad[8];
-    __shared__ float s_bg[2];
-    __shared__ float sc[64];    // params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45
-    __shared__ float snew[8];   // the updated parameters
-    const int cur = j & 1;
-    const int jj = tid % 32, grp = tid / 32;  // thread jj < NVALS of group grp sums value jj of the rows q = grp mod 8
-#define HSTAMP(i) STAMP(E, 2, b, i)
-    HSTAMP(0);
-    // ---- everything is requested at once: the partial rows (sc1), the scalars of the tail, the totals of the sorted seg list
-    const int rmask = E.role_mask;
-    constexpr int NR = NROLE;
-    const int PS = E.pslices, nrow = PS * NR;
-    const float* pbase = E.partials + (size_t)b * nrow * NPART + jj;
-    auto row_ok = [&](int q) {  // row q = slice * NR + role: written by shade_kernel (roles 0, 1) / edge_kernel (role 2) when the slice has a tile
-        const int r = q % NR, s = q / NR;
-        return q < nrow && ((rmask >> r) & 1) && s < (r == 2 ? E.s_edge : E.s_shade);
-    };
-    const int nlive = min(PS, n_act) * NR;  // (slice s has a tile <=> s < n_act)
-    float v0[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int q = grp + 8 * u;
-        v0[u] = (jj < NVALS && q < nlive && row_ok(q)) ? ld_sc1(pbase + (size_t)q * NPART) : 0.f;
-    }
-    const int ns = d.use_depth ? E.nseg : 0;  // (the size of the sorted seg list is known to the host since setup)
-    const double segWn = E.seg_W[ns], segGn = E.seg_G[ns];
-    float sc_val = 0.f;
-    if (tid < 7) sc_val = E.params2[((size_t)cur * 7 + tid) * B + b];
-    else if (tid == 7) sc_val = E.b.lr_mult[b];
-    else if (tid == 8) sc_val = E.b.lr_sched[j];
-    else if (tid >= 16 && tid < 32) sc_val = E.b.proj[tid - 16];
-    else if (tid >= 32 && tid < 46) sc_val = E.adam[((size_t)cur * 14 + (tid - 32)) * B + b];
-    const float dbg = -E.mats[((size_t)cur * B + b) * 32 + 11];
-    // ---- partial sums, fixed order => bit-reproducible
-    float acc = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v0[u];
-    if (jj < NVALS)
-        for (int q1 = grp + 64; q1 < nlive; q1 += 64) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per row)
-                const int q = q1 + 8 * u;
-                v[u] = (q < nlive && row_ok(q)) ? ld_sc1(pbase + (size_t)q * NPART) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
-        }
-    if (tid < 46) sc[tid] = sc_val;
-    // buckets 2w and 2w+1 are folded first (they live in the two halves of wave w), then the four pairs
-    acc += __shfl_xor(acc, 32, 64);
-    if (lane < NPART) red[wave][lane] = acc;
-    HSTAMP(1);
-    __syncthreads();
-    if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    // ---- whole-frame background depth term: sum_i w_i |dbg - g_i| and sum_i w_i sgn(dbg - g_i) (w = |seg0|, g = observed depth)
-    // from the sorted list: k1 = #(g < dbg), k2 = #(g <= dbg) by a 64-way search per round on the last wave (no barrier), then
-    // prefix-sum differences in double
-    if (d.use_depth && wave == 3) {
-        int lo1 = 0, hi1 = ns, lo2 = 0, hi2 = ns, k1 = -1, k2 = -1;
-        while (k1 < 0 || k2 < 0) {  // (wave-uniform)
-            const int span1 = hi1 - lo1, span2 = hi2 - lo2;
-            const int step1 = (span1 + 63) / 64, step2 = (span2 + 63) / 64;
-            const int i1 = lo1 + lane * step1, i2 = lo2 + lane * step2;
-            const bool in1 = k1 < 0 && span1 > 0 && i1 < hi1, in2 = k2 < 0 && span2 > 0 && i2 < hi2;
-            const float g1 = in1 ? E.seg_gd[i1] : 0.f, g2 = in2 ? E.seg_gd[i2] : 0.f;
-            const int c1 = __popcll(__ballot(in1 && g1 < dbg)), c2 = __popcll(__ballot(in2 && g2 <= dbg));
-            if (k1 < 0) {
-                if (span1 <= 0 || c1 == 0) k1 = lo1;
-                else if (step1 == 1) k1 = lo1 + c1;
-                else { const int pv = lo1 + (c1 - 1) * step1; lo1 = pv + 1; hi1 = min(pv + step1, hi1); }
-            }
-            if (k2 < 0) {
-                if (span2 <= 0 || c2 == 0) k2 = lo2;
-                else if (step2 == 1) k2 = lo2 + c2;
-                else { const int pv = lo2 + (c2 - 1) * step2; lo2 = pv + 1; hi2 = min(pv + step2, hi2); }
-            }
-        }
-        if (lane == 0) {
-            const double W1 = E.seg_W[k1], G1 = E.seg_G[k1], W2 = E.seg_W[k2], G2 = E.seg_G[k2], dd = (double)dbg;
-            s_bg[0] = (float)((dd * W1 - G1) + ((segGn - G2) - dd * (segWn - W2)));
-            s_bg[1] = (float)(W1 - (segWn - W2));
-        }
-    }
-    __syncthreads();
-    HSTAMP(2);
-    const float bgsum = d.use_depth ? s_bg[0] : 0.f, bgder = d.use_depth ? s_bg[1] : 0.f;
-    // ---- tail on wave 0, one lane per output where the work allows
-    if (wave == 0) {
-        const float npx = (float)d.H * (float)d.W;
-        const float lrb = sc[7];
-        // the weighted, not LR-scaled losses of the hypothesis (diffdope.py:558-560,576-578,604-608): lanes 0..3
-        float lv = 0.f;
-        if (lane == 0 && d.use_rgb) lv = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
-        if (lane == 1 && d.use_depth) lv = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
-        if (lane == 2 && d.use_mask) lv = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
-        if (lane == 3 && d.use_edge) lv = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
-        if (lane < 4 && (E.eval_grad ? E.eval_loss != nullptr : E.b.loss_log != nullptr)) {
-            if (E.eval_grad) E.eval_loss[(size_t)lane * B + b] = lv;
-            else E.b.loss_log[((size_t)j * 4 + lane) * B + b] = lv;
-        }
-        // ---- arg-min over the hypotheses inside this launch (ddx_engine_run_select; get_argmin / get_pose, diffdope.py:1488-1513,
-        // 1618-1632): the mean of the used loss rows exactly as select_best_kernel forms it, ties to the lowest index
-        if (fin && E.sel_out) {
-            const float l0 = __shfl(lv, 0, 64), l1 = __shfl(lv, 1, 64), l2 = __shfl(lv, 2, 64), l3 = __shfl(lv, 3, 64);
-            if (lane == 0) {
-                float a = 0.f;
-                int n_used = 0;
-                if (d.use_rgb) { a += l0; ++n_used; }
-                if (d.use_depth) { a += l1; ++n_used; }
-                if (d.use_mask) { a += l2; ++n_used; }
-                if (d.use_edge) { a += l3; ++n_used; }
-                a = __fdiv_rn(a, (float)max(n_used, 1));
-                if (a == a) {  // (a NaN loss never wins: select_best_kernel's comparisons)
-                    unsigned u = __float_as_uint(a);
-                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                    atomicMin(&E.st->sel_key, ((unsigned long long)u << 32) | (unsigned)b);
-                }
-                __builtin_amdgcn_s_waitcnt(0);  // the key has been folded in before this workgroup counts itself
-                const int arrived = __hip_atomic_fetch_add(&E.st->sel_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (arrived == B - 1) {  // the last hypothesis: every key is in
-                    const unsigned long long key = __hip_atomic_load(&E.st->sel_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    int w = 0;
-                    float best = INFINITY;
-                    if (key != ~0ull) {
-                        unsigned ub = (unsigned)(key >> 32);
-                        ub = (ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub;
-                        best = __uint_as_float(ub);
-                        w = (int)(unsigned)(key & 0xffffffffull);
-                    }
-                    // (a run whose in-launch tile pass timed out is void: NaN tells the reader of the row to call ddx_engine_run_check)
-                    const int fl = __hip_atomic_load(&E.st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the launch that set that pose)
-                    for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
-                    E.sel_out[1] = (float)(w + E.sel_lo);
-                    // (the loss LAST, behind the rest of the row: a host that polls the row's first word in pinned memory reads a complete row)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(E.sel_out, fl ? __uint_as_float(0x7fc00000u) : best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(&E.st->sel_key, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&E.st->sel_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        // d loss / d mtx = proj^T . dFinal (+ direct depth row): lane = k*4 + j
-        if (lane < 16) {
-            const int k = lane >> 2, c = lane & 3;
-            float a = 0.f;
-            a = __fmaf_rn(sc[16 + 0 * 4 + k], sums[0 + c], a);   // dFinal row x
-            a = __fmaf_rn(sc[16 + 1 * 4 + k], sums[4 + c], a);   // row y
-            a = __fmaf_rn(sc[16 + 3 * 4 + k], sums[8 + c], a);   // row w (row z carries no gradient)
-            if (d.use_depth && k == 2) {
-                a += sums[12 + c];
-                if (c == 3) a += -(d.w_depth * lrb / ((float)d.B_global * npx)) * bgder;  // whole-frame background term (depth_bg = -m23)
-            }
-            sG[lane] = a;
-        }
-        wave_lds_sync();
-        if (lane == 0) {
-            // quaternion chain (the reverse of diffdope.py:57-80 and :1091)
-            const float* G = sG;
-            const float nq = sqrtf(sc[0] * sc[0] + sc[1] * sc[1] + sc[2] * sc[2] + sc[3] * sc[3]);
-            const float x = sc[0] / nq, y = sc[1] / nq, z = sc[2] / nq, w = sc[3] / nq;
-            const float gx = G[1] * 2 * y + G[2] * 2 * z + G[4] * 2 * y + G[5] * (-4 * x) + G[6] * (-2 * w) + G[8] * 2 * z + G[9] * 2 * w + G[10] * (-4 * x);
-            const float gy = G[0] * (-4 * y) + G[1] * 2 * x + G[2] * 2 * w + G[4] * 2 * x + G[6] * 2 * z + G[8] * (-2 * w) + G[9] * 2 * z + G[10] * (-4 * y);
-            const float gz = G[0] * (-4 * z) + G[1] * (-2 * w) + G[2] * 2 * x + G[4] * 2 * w + G[5] * (-4 * z) + G[6] * 2 * y + G[8] * 2 * x + G[9] * 2 * y;
-            const float gw = G[1] * (-2 * z) + G[2] * 2 * y + G[4] * 2 * z + G[6] * (-2 * x) + G[8] * (-2 * y) + G[9] * 2 * x;
-            const float dot = gx * x + gy * y + gz * z + gw * w;
-            sgrad[0] = (gx - x * dot) / nq; sgrad[1] = (gy - y * dot) / nq; sgrad[2] = (gz - z * dot) / nq; sgrad[3] = (gw - w * dot) / nq;
-            sgrad[4] = G[3]; sgrad[5] = G[7]; sgrad[6] = G[11];
-        }
-        wave_lds_sync();
-        // optimiser step: lane = parameter
-        if (lane < 7 && E.eval_grad) {  // evaluation pass: hand out the gradient, leave every state as it is
-            E.eval_grad[(size_t)lane * B + b] = sgrad[lane];
-            snew[lane] = sc[lane];
-        } else if (lane < 7) {
-            const float g = sgrad[lane], lr = sc[8];
-            float pnew;
-            if (d.optimizer == 0) {
-                pnew = sc[lane] - lr * g;
-            } else {
-                const float b1 = d.adam_beta1, b2 = d.adam_beta2;
-                const float c1 = 1.f - exp2f((float)(j + 1) * log2f(b1)), c2 = 1.f - exp2f((float)(j + 1) * log2f(b2));
-                const float m1 = b1 * sc[32 + lane] + (1.f - b1) * g;
-                const float m2 = b2 * sc[39 + lane] + (1.f - b2) * g * g;
-                E.adam[((size_t)(1 - cur) * 14 + lane) * B + b] = m1;
-                E.adam[((size_t)(1 - cur) * 14 + 7 + lane) * B + b] = m2;
-                pnew = sc[lane] - lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
-            }
-            snew[lane] = pnew;
-            E.params2[((size_t)(1 - cur) * 7 + lane) * B + b] = pnew;
-            E.b.params[(size_t)lane * B + b] = pnew;
-        }
-        wave_lds_sync();
-        // ---- the pose of iteration j + 1: q/|q| (diffdope.py:1091), [R|t] (:46-89), final = proj . mtx (:195) -- lanes 0..3 hold the
-        // rows of both matrices -- into mats[(j + 1) & 1] (and the pose log): what step_kernel's head used to compute in every lane
-        if (!E.eval_grad && j + 1 < d.max_iters && lane < 4) {
-            float q[4], t3[3], M4[16], pr[4], Fr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = snew[i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) t3[i] = snew[4 + i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pr[k] = sc[16 + lane * 4 + k];  // row `lane` of proj
-            const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
-            quat_to_matrix(q, t3, M4);
-            final_row(pr, M4, Fr);
-            float* dst = E.mats + ((size_t)(1 - cur) * B + b) * 32;
-            float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)(j + 1) * B + b) * 16 : nullptr;
-            const float Mr[4] = {lane == 0 ? M4[0] : (lane == 1 ? M4[4] : (lane == 2 ? M4[8] : M4[12])), lane == 0 ? M4[1] : (lane == 1 ? M4[5] : (lane == 2 ? M4[9] : M4[13])),
-                                 lane == 0 ? M4[2] : (lane == 1 ? M4[6] : (lane == 2 ? M4[10] : M4[14])), lane == 0 ? M4[3] : (lane == 1 ? M4[7] : (lane == 2 ? M4[11] : M4[15]))};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dst[lane * 4 + c] = Mr[c];
-                dst[16 + lane * 4 + c] = Fr[c];
-                if (logm) logm[lane * 4 + c] = Mr[c];
-            }
-        }
-    }
-    HSTAMP(3);
-    if (!fin) return;  // (workgroup-uniform)
-    // ---- the LAST iteration of a run (or an evaluation pass): nothing comes after it that would re-arm what iteration j dirtied
-    // (step_kernel of iteration j + 1 does that for iteration j), so this workgroup does, for its hypothesis: zbuf of the active
-    // tiles and their flags (parity j & 1), the tile pass's words; and the status words, once every hypothesis has come by.
-    {
-        __shared__ int s_n;
-        __shared__ unsigned short s_t[1024];  // (a trip looks at 1024 tiles)
-        unsigned long long* Z = E.L.zbuf + ((size_t)cur * B + b) * E.L.zper;
-        unsigned char* flag = E.L.tile_flag + ((size_t)cur * B + b) * E.L.NTp;
-        unsigned char* big = E.L.tile_big + ((size_t)cur * B + b) * E.L.NTp;
-        const unsigned* frow = reinterpret_cast<const unsigned*>(flag);  // (written by step_kernel / the tile pass: earlier launches)
-        const int n_dw = E.L.NTp >> 2;
-        for (int d0 = 0; d0 < n_dw; d0 += 256) {  // (workgroup-uniform) 1024 tiles per trip
-            __syncthreads();
-            if (tid == 0) s_n = 0;
-            __syncthreads();
-            const int di = d0 + tid;
-            unsigned w4 = di < n_dw ? frow[di] : 0u;
-            for (int k = 0; w4 && k < 4; ++k)
-                if ((w4 >> (8 * k)) & 0xffu) {
-                    s_t[atomicAdd(&s_n, 1)] = (unsigned short)(di * 4 + k - d0 * 4);  // (LDS atomic; the order does not matter)
-                }
-            __syncthreads();
-            const int n = s_n;
-            for (int k = 0; k < n; ++k) {  // (workgroup-uniform)
-                const int tile = d0 * 4 + (int)s_t[k], ty = tile / E.L.ntx, tx = tile - ty * E.L.ntx;
-#pragma unroll
-                for (int p = tid; p < DDX_TILE * DDX_TILE; p += 256) {
-                    const int zx = tx * DDX_TILE + p % DDX_TILE, zy = ty * DDX_TILE + p / DDX_TILE;
-                    if (zx < d.W && zy < d.H) Z[zaddr(zx, zy, E.L.zwb)] = ~0ull;
-                }
-            }
-            __syncthreads();
-            if (di < n_dw) {  // (every flag of the piece back to zero, set or not: plain dword stores)
-                reinterpret_cast<unsigned*>(flag)[di] = 0u;
-                reinterpret_cast<unsigned*>(big)[di] = 0u;
-            }
-        }
-    }
-    if (tid == 0) {
-        E.L.bigcount[(size_t)cur * B + b] = 0;
-        E.L.bigarrive[(size_t)cur * B + b] = 0;
-        // status of the run's last iteration: summed over the hypotheses as they come by; the last one publishes and re-arms
-        __hip_atomic_fetch_add(&E.st->acc_active, n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (E.inside[b] == 0) __hip_atomic_fetch_add(&E.st->acc_outside, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int came = __hip_atomic_fetch_add(&E.st->fin_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (came == B - 1) {
-            E.st->last_active = __hip_atomic_load(&E.st->acc_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            E.st->outside = __hip_atomic_load(&E.st->acc_outside, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            E.st->last_pairs = E.L.counters[3 + cur];
-            E.L.counters[3 + cur] = 0;
-            __hip_atomic_store(&E.st->acc_active, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&E.st->acc_outside, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&E.st->fin_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    HSTAMP(4);
-#undef HSTAMP
 }
 
 // decode candidate pair `desc` = pixel lane | kind << 6 of the quadrant at (qx,qy):
@@ -1550,7 +1183,7 @@ __device__ __forceinline__ void shade_body(const EngineDev& E, float* __restrict
             if (lane < 56) s_rows[wave][lane - 32] = mine2;
         }
         __syncthreads();
-        store_partial_row(part, s_rows, tid);  // (write-through: read by the hypothesis' last arriver, hyp_head, on whatever XCD it runs)
+        if (tid < NPART) part[tid] = (s_rows[0][tid] + s_rows[1][tid]) + (s_rows[2][tid] + s_rows[3][tid]);
     }
 }
 
@@ -1624,7 +1257,7 @@ __device__ __attribute__((noinline)) static void big_wait(int* arrive, int S, un
 }
 
 template <bool EDGE>
-__device__ __forceinline__ void shade_wg(const EngineDev& E, unsigned long long ek, int b, int sl, int S, int z, int it_arg, int fin)
+__device__ __forceinline__ void shade_wg(const EngineDev& E, int b, int sl, int S, int z, int it_arg)
 {
     // workgroup (b, s) takes tiles s, s+S, ... of hypothesis b's active tiles in ascending tile order.  There is no list kernel:
     // every WAVE scans the hypothesis' row of tile flags itself (tile_scan: bytes written by step_kernel, 1.2 KB at 640x480),
@@ -1667,20 +1300,13 @@ __device__ __forceinline__ void shade_wg(const EngineDev& E, unsigned long long 
     if (role == 0) shade_body<0, EDGE>(E, pool, tw);
     else shade_body<1, EDGE>(E, pool, tw);
     STAMP(E, 1, wg_id, 2);
+    STAMP(E, 1, wg_id, 3);
     if (tid == 0 && E.trace && wg_id < TRACE_WG) E.trace[((size_t)TRACE_WG + wg_id) * 8 + 4] = ((unsigned long long)z << 32) | (unsigned)tw.n_mine;
-    // ---- the last shading workgroup of the hypothesis -- whichever it is, wherever it runs -- steps the optimiser (hyp_head).  With
-    // the edge term the partial rows are complete only after edge_kernel: its last workgroup does.
-    if (!E.d.use_edge) {
-        const bool last = hyp_arrive(E, b, S * E.n_roles);
-        STAMP(E, 1, wg_id, 3);
-        if (last) hyp_head(ek, b, it_cur, tw.n_flags, fin);
-    }
-    STAMP(E, 1, wg_id, 5);
 }
 
 // (HALF: the same kernel under a second name, for the half-batch launches of a two-stream run -- a profile lists them apart)
 template <bool EDGE, bool HALF = false>
-__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E /* must stay the first parameter: engine_at() */, int it_arg, int fin)
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E, int it_arg)
 {
     // grid (B, S, roles), or (B, S, 1 + roles) with the tile pass inside the launch: slab z = 0 = its workers
     int z = blockIdx.z;
@@ -1692,12 +1318,12 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_kernel(EngineDev E
         }
         --z;
     }
-    shade_wg<EDGE>(E, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(), E.b_off + blockIdx.x, blockIdx.y, gridDim.y, z, it_arg, fin);
+    shade_wg<EDGE>(E, E.b_off + blockIdx.x, blockIdx.y, gridDim.y, z, it_arg);
 }
 
 // group form: grid (sum of the members' hypotheses, largest slice count, 2)
 template <bool EDGE>
-__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg, int fin)
+__global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
 {
     const int o = group_find(G, blockIdx.x);
     const EngineDev& E = tab[G.idx[o]];
@@ -1712,7 +1338,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_group_kernel(const
         --z;
     }
     if (z >= E.n_roles) return;
-    shade_wg<EDGE>(E, (unsigned long long)&tab[G.idx[o]], (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_shade, z, it_arg, fin);
+    shade_wg<EDGE>(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_shade, z, it_arg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1724,7 +1350,7 @@ __global__ __launch_bounds__(256, SHADE_MIN_WAVES) void shade_group_kernel(const
 // texture fetch, no barycentrics -- the old edge role re-shaded the 100 halo pixels of every quadrant in two rounds.
 #define EH (QUAD + 4)  // 12: luminance halo
 #define ET (QUAD + 2)  // 10: loss terms
-__device__ __forceinline__ void edge_wg(const EngineDev& E, unsigned long long ek, int b, int sl, int S, int it_arg, int fin)
+__device__ __forceinline__ void edge_wg(const EngineDev& E, int b, int sl, int S, int it_arg)
 {
     __shared__ float s_l[WAVES_PER_TILE][EH * EH];
     __shared__ float s_cx[WAVES_PER_TILE][ET * ET + 4], s_cy[WAVES_PER_TILE][ET * ET + 4];
@@ -1857,29 +1483,318 @@ __device__ __forceinline__ void edge_wg(const EngineDev& E, unsigned long long e
             if (lane < 56) s_rows[wave][lane - 32] = mine2;
         }
         __syncthreads();
-        store_partial_row(part, s_rows, tid);
+        if (tid < NPART) part[tid] = (s_rows[0][tid] + s_rows[1][tid]) + (s_rows[2][tid] + s_rows[3][tid]);
     }
-    // ---- with the edge term this is the last kernel of an iteration that writes partial rows: its last workgroup of the hypothesis
-    // runs the optimiser head (hyp_head)
-    if (hyp_arrive(E, b, S)) hyp_head(ek, b, it_arg >= 0 ? it_arg : E.st->it_next - 1, n_tiles, fin);
 }
 
 template <bool HALF = false>
-__global__ __launch_bounds__(256) void edge_kernel(EngineDev E /* must stay the first parameter: engine_at() */, int it_arg, int fin)
-{
-    edge_wg(E, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(), E.b_off + blockIdx.x, blockIdx.y, gridDim.y, it_arg, fin);
-}
+__global__ __launch_bounds__(256) void edge_kernel(EngineDev E, int it_arg) { edge_wg(E, E.b_off + blockIdx.x, blockIdx.y, gridDim.y, it_arg); }
 
 // group form: grid (sum of the members' hypotheses, largest slice count); members without the edge term leave at once
-__global__ __launch_bounds__(256) void edge_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg, int fin)
+__global__ __launch_bounds__(256) void edge_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
 {
     const int o = group_find(G, blockIdx.x);
     const EngineDev& E = tab[G.idx[o]];
     if (!E.d.use_edge || (int)blockIdx.y >= E.s_edge) return;
-    edge_wg(E, (unsigned long long)&tab[G.idx[o]], (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_edge, it_arg, fin);
+    edge_wg(E, (int)blockIdx.x - G.bpre[o], blockIdx.y, E.s_edge, it_arg);
 }
 
 // ---------------------------------------------------------------------------------------------
+// The optimiser step of iteration j for hypothesis b: the head of step_kernel and all of finish_kernel.
+// EVERY workgroup of the hypothesis runs it, redundantly (one kernel less in the iteration's chain; the partial rows are a few
+// KB from L2): fixed-order sum of the hypothesis' partial rows (one per shade / edge slice and role), whole-frame constants +
+// the background depth term sum |seg| |d_bg - gt| of the whole frame from the depth-sorted seg list with prefix sums in
+// double (two 64-way searches on one wave + six loads), proj^T chain, quaternion chain, SGD/Adam (lane-parallel tail), loss
+// log.  Workgroup `slice` of `n_slices` also re-arms its share of what iteration j dirtied (zbuf of the active tiles and their
+// flags, parity j & 1), and slice 0 writes parameters, optimiser state and logs.  Returns (after a barrier) with
+// snew[0..6] = the updated parameters and sc[16..31] = proj in LDS.
+// The sum is grouped the same way whatever the workgroup size (8 buckets of rows q = bucket mod 8, folded pairwise), so the
+// 64- and 256-thread variants of step_kernel produce the same bits.
+#define UPD_SLICES 8  // workgroups per hypothesis of finish_kernel; fewer for large batches (upd_slices())
+
+template <int NTH, bool SEL = false /* finish_kernel: the selection of ddx_engine_run_select is compiled in */>
+__device__ __forceinline__ void update_head(const EngineDev& E, int b, int j, int slice, int n_slices, float* snew, float* sc)
+{
+    constexpr int NG = NTH / 32, NW = NTH / 64, NBK = 8 / NG;  // groups of 32 threads, waves, row buckets per thread
+    constexpr int SPEC = 64 / 8;                               // rows per bucket requested before the tile count is known (64 rows in all)
+    const ddx_engine_desc& d = E.d;
+    const int B = d.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float red[4][NPART];
+    __shared__ float sums[NPART];
+    __shared__ float sG[16];
+    __shared__ float sgrad[8];
+    __shared__ float s_bg[2];
+    const int NT = E.L.NT;
+    const int cur = j & 1;
+    const int jj = tid % 32, grp = tid / 32;  // thread jj < NVALS of group g sums value jj of the rows of its buckets
+#ifdef DDX_TRACE_HEAD
+#define HSTAMP(i) do { if (E.trace && tid == 0 && NTH == 256 && b * n_slices + slice < TRACE_WG) E.trace[((size_t)2 * TRACE_WG + b * n_slices + slice) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HSTAMP(i)
+#endif
+    HSTAMP(0);
+    const int n_act = *(E.L.b_count + b);
+    const int* tiles = E.L.active + (size_t)b * NT;
+    // ---- everything that does not depend on this iteration's sums is REQUESTED here, before the first wait: the partial
+    // rows (speculative: rows of slices beyond the tile count are stale and masked below), the first tile of the re-arm
+    // share, the totals of the sorted seg list.  The head is a chain of dependent round trips; these would otherwise each add one.
+    const int rmask = E.role_mask;
+    constexpr int NR = NROLE;
+    const int PS = E.pslices, nrow = PS * NR;
+    const float* pbase = E.partials + (size_t)b * nrow * NPART + jj;
+    auto row_ok = [&](int q) {  // row q = slice * NR + role: written by shade_kernel (roles 0, 1) / edge_kernel (role 2) when the slice has a tile
+        const int r = q % NR, s = q / NR;
+        return q < nrow && ((rmask >> r) & 1) && s < (r == 2 ? E.s_edge : E.s_shade);
+    };
+    float v0[NBK][SPEC];
+#pragma unroll
+    for (int i = 0; i < NBK; ++i)
+#pragma unroll
+        for (int u = 0; u < SPEC; ++u) {
+            const int q = (grp + NG * i) + 8 * u;
+            v0[i][u] = (jj < NVALS && row_ok(q)) ? *(pbase + (size_t)q * NPART) : 0.f;
+        }
+    const int txy_first = slice < NT ? *(tiles + slice) : 0;
+    const int ns = d.use_depth ? E.nseg : 0;  // (the size of the sorted seg list is known to the host since setup)
+    const double segWn = E.seg_W[ns], segGn = E.seg_G[ns];
+    // ---- the scalars of the tail, one per thread, into LDS: params 0..6, lr_mult 7, lr 8, proj 16..31, adam 32..45
+    float sc_val = 0.f;
+    if (tid < 7) sc_val = *(E.params2 + ((size_t)cur * 7 + tid) * B + b);
+    else if (tid == 7) sc_val = E.b.lr_mult[b];
+    else if (tid == 8) sc_val = E.b.lr_sched[j];
+    else if (tid >= 16 && tid < 32) sc_val = E.b.proj[tid - 16];
+    else if (tid >= 32 && tid < 46) sc_val = *(E.adam + ((size_t)cur * 14 + (tid - 32)) * B + b);
+    const float dbg = -*(E.mats + ((size_t)cur * B + b) * 32 + 11);
+    // ---- partial sums, fixed order => bit-reproducible
+    float acc[NBK];
+    {
+        const int nlive = min(PS, n_act) * NR;  // (slice s has a tile <=> s < n_act)
+#pragma unroll
+        for (int i = 0; i < NBK; ++i) {
+            acc[i] = 0.f;
+            const int q0 = grp + NG * i;
+#pragma unroll
+            for (int u = 0; u < SPEC; ++u) acc[i] += (q0 + 8 * u < nlive) ? v0[i][u] : 0.f;
+            if (jj < NVALS)
+                for (int q1 = q0 + 8 * SPEC; q1 < nlive; q1 += 64) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {  // 8 loads in flight (a load-add chain would pay one L2 round trip per row)
+                        const int q = q1 + 8 * u;
+                        v[u] = (q < nlive && row_ok(q)) ? *(pbase + (size_t)q * NPART) : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[i] += v[u];
+                }
+        }
+    }
+    HSTAMP(1);
+    if (tid < 46) sc[tid] = sc_val;
+    // ---- re-arm what iteration j dirtied (zbuf of its active tiles, their flags; parity j & 1) so that no pass needs a
+    // memset: tile k of the hypothesis' list is re-armed by workgroup k % n_slices.  Independent of the sums.
+    {
+        unsigned long long* Z = E.L.zbuf + ((size_t)cur * B + b) * E.L.zper;
+        unsigned char* flag = E.L.tile_flag + ((size_t)cur * B + b) * E.L.NTp;
+        unsigned char* big = E.L.tile_big + ((size_t)cur * B + b) * E.L.NTp;
+        for (int k = slice; k < n_act; k += n_slices) {  // (workgroup-uniform)
+            const int txy = k == slice ? txy_first : *(tiles + k);
+            const int tx = txy & 0xffff, ty = txy >> 16;
+            if (tid == 0) {
+                flag[ty * E.L.ntx + tx] = 0;
+                big[ty * E.L.ntx + tx] = 0;
+            }
+#pragma unroll
+            for (int p = tid; p < DDX_TILE * DDX_TILE; p += NTH) {
+                const int zx = tx * DDX_TILE + p % DDX_TILE, zy = ty * DDX_TILE + p / DDX_TILE;
+                if (zx < d.W && zy < d.H) Z[zaddr(zx, zy, E.L.zwb)] = ~0ull;
+            }
+        }
+    }
+    // buckets 2w and 2w+1 are folded first (for 256 threads they live in the two halves of wave w), then the four pairs
+#pragma unroll
+    for (int i = 0; i < NBK; ++i) acc[i] += __shfl_xor(acc[i], 32, 64);
+    if (lane < NPART) {
+        if (NBK == 1) red[wave][lane] = acc[0];
+        else {
+#pragma unroll
+            for (int i = 0; i < NBK; ++i) red[i % 4][lane] = acc[i];  // (NTH = 64: thread group g in {0,1} holds buckets g, g+2, g+4, g+6 = pairs 0..3)
+        }
+    }
+    HSTAMP(2);
+    __syncthreads();
+    HSTAMP(3);
+    if (tid < NPART) sums[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    // ---- whole-frame background depth term: sum_i w_i |dbg - g_i| and sum_i w_i sgn(dbg - g_i) (w = |seg0|, g = observed depth)
+    // from the sorted list: k1 = #(g < dbg), k2 = #(g <= dbg) by a 64-way search per round on the last wave (no barrier), then
+    // prefix-sum differences in double
+    if (d.use_depth && wave == NW - 1) {
+        int lo1 = 0, hi1 = ns, lo2 = 0, hi2 = ns, k1 = -1, k2 = -1;
+        while (k1 < 0 || k2 < 0) {  // (wave-uniform)
+            const int span1 = hi1 - lo1, span2 = hi2 - lo2;
+            const int step1 = (span1 + 63) / 64, step2 = (span2 + 63) / 64;
+            const int i1 = lo1 + lane * step1, i2 = lo2 + lane * step2;
+            const bool in1 = k1 < 0 && span1 > 0 && i1 < hi1, in2 = k2 < 0 && span2 > 0 && i2 < hi2;
+            const float g1 = in1 ? E.seg_gd[i1] : 0.f, g2 = in2 ? E.seg_gd[i2] : 0.f;
+            const int c1 = __popcll(__ballot(in1 && g1 < dbg)), c2 = __popcll(__ballot(in2 && g2 <= dbg));
+            if (k1 < 0) {
+                if (span1 <= 0 || c1 == 0) k1 = lo1;
+                else if (step1 == 1) k1 = lo1 + c1;
+                else { const int pv = lo1 + (c1 - 1) * step1; lo1 = pv + 1; hi1 = min(pv + step1, hi1); }
+            }
+            if (k2 < 0) {
+                if (span2 <= 0 || c2 == 0) k2 = lo2;
+                else if (step2 == 1) k2 = lo2 + c2;
+                else { const int pv = lo2 + (c2 - 1) * step2; lo2 = pv + 1; hi2 = min(pv + step2, hi2); }
+            }
+        }
+        if (lane == 0) {
+            const double W1 = E.seg_W[k1], G1 = E.seg_G[k1], W2 = E.seg_W[k2], G2 = E.seg_G[k2], dd = (double)dbg;
+            s_bg[0] = (float)((dd * W1 - G1) + ((segGn - G2) - dd * (segWn - W2)));
+            s_bg[1] = (float)(W1 - (segWn - W2));
+        }
+    }
+    __syncthreads();
+    HSTAMP(4);
+    const float bgsum = d.use_depth ? s_bg[0] : 0.f, bgder = d.use_depth ? s_bg[1] : 0.f;
+    // ---- tail on wave 0, one lane per output where the work allows
+    const bool writer = slice == 0;
+    if (wave == 0) {
+        const float npx = (float)d.H * (float)d.W;
+        const float lrb = sc[7];
+        // loss log: weighted, not LR-scaled (diffdope.py:558-560,576-578,604-608)
+        if (writer && lane < 4 && (E.eval_grad ? E.eval_loss != nullptr : E.b.loss_log != nullptr)) {
+            float v = 0.f;
+            if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
+            if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
+            if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
+            if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
+            if (E.eval_grad) E.eval_loss[(size_t)lane * B + b] = v;
+            else E.b.loss_log[((size_t)j * 4 + lane) * B + b] = v;
+        }
+        // ---- arg-min over the hypotheses inside this launch (ddx_engine_run_select; get_argmin / get_pose, diffdope.py:1488-1513,
+        // 1618-1632): the mean of the used loss rows exactly as select_best_kernel forms it, ties to the lowest index
+        if (SEL && writer && E.sel_out) {
+            float v = 0.f;
+            if (lane == 0 && d.use_rgb) v = d.w_rgb * ((float)(E.st->c_rgb + (double)sums[16]) / (3.0f * npx));
+            if (lane == 1 && d.use_depth) v = d.w_depth * ((float)((double)bgsum + (double)sums[17]) / npx);
+            if (lane == 2 && d.use_mask) v = d.w_mask * ((float)(E.st->c_mask + (double)sums[18]) / (3.0f * npx));
+            if (lane == 3 && d.use_edge) v = d.w_edge * ((float)(E.st->c_edge + (double)sums[19]) / (2.0f * npx));
+            const float v0 = __shfl(v, 0, 64), v1 = __shfl(v, 1, 64), v2 = __shfl(v, 2, 64), v3 = __shfl(v, 3, 64);
+            if (lane == 0) {
+                float a = 0.f;
+                int n_used = 0;
+                if (d.use_rgb) { a += v0; ++n_used; }
+                if (d.use_depth) { a += v1; ++n_used; }
+                if (d.use_mask) { a += v2; ++n_used; }
+                if (d.use_edge) { a += v3; ++n_used; }
+                a = __fdiv_rn(a, (float)max(n_used, 1));
+                if (a == a) {  // (a NaN loss never wins: select_best_kernel's comparisons)
+                    unsigned u = __float_as_uint(a);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    atomicMin(&E.st->sel_key, ((unsigned long long)u << 32) | (unsigned)b);
+                }
+                __builtin_amdgcn_s_waitcnt(0);  // the key has been folded in before this workgroup counts itself
+                const int arrived = __hip_atomic_fetch_add(&E.st->sel_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived == B - 1) {  // the last hypothesis: every key is in
+                    const unsigned long long key = __hip_atomic_load(&E.st->sel_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int w = 0;
+                    float best = INFINITY;
+                    if (key != ~0ull) {
+                        unsigned ub = (unsigned)(key >> 32);
+                        ub = (ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub;
+                        best = __uint_as_float(ub);
+                        w = (int)(unsigned)(key & 0xffffffffull);
+                    }
+                    // (a run whose in-launch tile pass timed out is void: NaN tells the reader of the row to call ddx_engine_run_check)
+                    const int fl = __hip_atomic_load(&E.st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    E.sel_out[1] = (float)(w + E.sel_lo);
+                    const float* Mw = E.mats + ((size_t)cur * B + w) * 32;  // mtx of iteration j (written by the step_kernel that drew it)
+                    for (int i = 0; i < 16; ++i) E.sel_out[2 + i] = Mw[i];
+                    // (the loss LAST and behind the rest of the row: a host that polls the row's first word in mapped pinned memory reads a complete row)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(E.sel_out, fl ? __uint_as_float(0x7fc00000u) : best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&E.st->sel_key, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&E.st->sel_arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // d loss / d mtx = proj^T . dFinal (+ direct depth row): lane = k*4 + j
+        if (lane < 16) {
+            const int k = lane >> 2, c = lane & 3;
+            float a = 0.f;
+            a = __fmaf_rn(sc[16 + 0 * 4 + k], sums[0 + c], a);   // dFinal row x
+            a = __fmaf_rn(sc[16 + 1 * 4 + k], sums[4 + c], a);   // row y
+            a = __fmaf_rn(sc[16 + 3 * 4 + k], sums[8 + c], a);   // row w (row z carries no gradient)
+            if (d.use_depth && k == 2) {
+                a += sums[12 + c];
+                if (c == 3) a += -(d.w_depth * lrb / ((float)d.B_global * npx)) * bgder;  // whole-frame background term (depth_bg = -m23)
+            }
+            sG[lane] = a;
+        }
+        wave_lds_sync();
+        if (lane == 0) {
+            // quaternion chain (the reverse of diffdope.py:57-80 and :1091)
+            const float* G = sG;
+            const float nq = sqrtf(sc[0] * sc[0] + sc[1] * sc[1] + sc[2] * sc[2] + sc[3] * sc[3]);
+            const float x = sc[0] / nq, y = sc[1] / nq, z = sc[2] / nq, w = sc[3] / nq;
+            const float gx = G[1] * 2 * y + G[2] * 2 * z + G[4] * 2 * y + G[5] * (-4 * x) + G[6] * (-2 * w) + G[8] * 2 * z + G[9] * 2 * w + G[10] * (-4 * x);
+            const float gy = G[0] * (-4 * y) + G[1] * 2 * x + G[2] * 2 * w + G[4] * 2 * x + G[6] * 2 * z + G[8] * (-2 * w) + G[9] * 2 * z + G[10] * (-4 * y);
+            const float gz = G[0] * (-4 * z) + G[1] * (-2 * w) + G[2] * 2 * x + G[4] * 2 * w + G[5] * (-4 * z) + G[6] * 2 * y + G[8] * 2 * x + G[9] * 2 * y;
+            const float gw = G[1] * (-2 * z) + G[2] * 2 * y + G[4] * 2 * z + G[6] * (-2 * x) + G[8] * (-2 * y) + G[9] * 2 * x;
+            const float dot = gx * x + gy * y + gz * z + gw * w;
+            sgrad[0] = (gx - x * dot) / nq; sgrad[1] = (gy - y * dot) / nq; sgrad[2] = (gz - z * dot) / nq; sgrad[3] = (gw - w * dot) / nq;
+            sgrad[4] = G[3]; sgrad[5] = G[7]; sgrad[6] = G[11];
+        }
+        wave_lds_sync();
+        // optimiser step: lane = parameter
+        if (lane < 7 && E.eval_grad) {  // evaluation pass: hand out the gradient, leave every state as it is
+            if (writer) E.eval_grad[(size_t)lane * B + b] = sgrad[lane];
+            snew[lane] = sc[lane];
+        } else if (lane < 7) {
+            const float g = sgrad[lane], lr = sc[8];
+            float pnew;
+            if (d.optimizer == 0) {
+                pnew = sc[lane] - lr * g;
+            } else {
+                const float b1 = d.adam_beta1, b2 = d.adam_beta2;
+                const float c1 = 1.f - exp2f((float)(j + 1) * log2f(b1)), c2 = 1.f - exp2f((float)(j + 1) * log2f(b2));
+                const float m1 = b1 * sc[32 + lane] + (1.f - b1) * g;
+                const float m2 = b2 * sc[39 + lane] + (1.f - b2) * g * g;
+                if (writer) {
+                    E.adam[((size_t)(1 - cur) * 14 + lane) * B + b] = m1;
+                    E.adam[((size_t)(1 - cur) * 14 + 7 + lane) * B + b] = m2;
+                }
+                pnew = sc[lane] - lr * (m1 / c1) / (sqrtf(m2 / c2) + d.adam_eps);
+            }
+            snew[lane] = pnew;
+            if (writer) {
+                E.params2[((size_t)(1 - cur) * 7 + lane) * B + b] = pnew;
+                E.b.params[(size_t)lane * B + b] = pnew;
+            }
+        }
+        if (writer && b == 0) {
+            // status of iteration j (single lanes across kernel boundaries, no atomics)
+            int tot = 0, out = 0;
+            for (int i = lane; i < B; i += 64) {
+                tot += E.L.b_count[i];
+                out += E.inside[i] == 0;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o, 64); out += __shfl_xor(out, o, 64); }
+            if (lane == 0) {
+                E.st->last_active = tot;
+                E.st->outside = out;
+                E.st->last_pairs = E.L.counters[3 + cur];
+            }
+        }
+    }
+    HSTAMP(5);
+    __syncthreads();
+    HSTAMP(6);
+#undef HSTAMP
+}
+
 // Meshlet geometry of a step_kernel instantiation: TPL triangles per thread, two vertex slots per thread.
 // MODE: the fragment variant of scatter_resolve (raster_dev.h).
 //
@@ -1891,20 +1806,21 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
 {
     constexpr int NTRI = TPL * NTH, NVC = 2 * NTH;
     const ddx_engine_desc& d = E.d;
-    // workgroup `slot` of the SL of hypothesis b; SL is chosen so that all workgroups are resident (launch_step)
+    // workgroup `slot` of the SL of hypothesis b: the head is paid once per workgroup, and SL is chosen so that all workgroups are
+    // resident (launch_step)
     const int B = d.B, V = d.V, M = E.n_meshlets;
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ float4 s_clip[NVC];
     __shared__ int2 s_snap[NVC];
-    __shared__ float snew[8];  // first iteration of a run: the caller's parameters
-    __shared__ float sc[32];   // ... and proj (16..31)
+    __shared__ float snew[8];  // the parameters this iteration is drawn with
+    __shared__ float sc[64];   // update_head's scalars; 16..31 = proj
     const int wg_id = b * SL + slot;
     STAMP(E, 0, wg_id, 0);
     // (it_arg >= 0: the host names the iteration -- plain stream launches -- and the kernel starts without a dependent scalar load;
     // -1: replayed from a captured graph, whose arguments are frozen: the device counter says which iteration this is)
     const int it = it_arg >= 0 ? it_arg : E.st->it;
     const int par = it & 1;
-    // ---- the first meshlet (static tables, fixed-size slots: nothing here depends on another load)
+    // ---- the first meshlet (static tables, fixed-size slots: nothing here depends on another load): requested before the head
     float4 vr[2];
     int2 tr[TPL];
     // workgroup `slot` draws the meshlets [slot npw, (slot + 1) npw) of the INTERLEAVED order (engine_setup: front / back of the
@@ -1919,56 +1835,29 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     // (the slot's list goes to LDS once: indexing the kernel arguments inside the meshlet loop would put a scalar load and its wait,
     // which also waits for the LDS traffic, into every trip)
     __shared__ unsigned short s_items[TAB ? 64 : 1];
-    if (tabled && tid < min(n_my, 64)) s_items[tid] = E.slot_items[t_off + tid];  // (first read behind the meshlet loop's first barrier)
+    if (tabled && tid < min(n_my, 64)) s_items[tid] = E.slot_items[t_off + tid];  // (visible after the barrier of the head / first-iteration branch)
     auto meshlet_of = [&](int k) { return tabled ? (int)s_items[k] : m_begin + k; };
-    const int m0 = n_my > 0 ? (tabled ? (int)E.slot_items[t_off] : m_begin) : M - 1;  // (a slot without meshlets only shares the re-arm work)
+    const int m0 = n_my > 0 ? (tabled ? (int)E.slot_items[t_off] : m_begin) : M - 1;  // (a slot without meshlets only shares the head's re-arm work)
 #pragma unroll
     for (int u = 0; u < 2; ++u) vr[u] = E.mvert[(size_t)m0 * NVC + u * NTH + tid];
 #pragma unroll
     for (int k = 0; k < TPL; ++k) tr[k] = E.mtri[(size_t)m0 * NTRI + k * NTH + tid];
-    const bool writer = slot == 0;
-    float Fr[4];  // row lane % 4 of final = proj . mtx of THIS iteration
     if (mode == STEP_NORMAL) {
-        // ---- THE HEAD (round 6): one 16-byte load.  The optimiser step of iteration it - 1 ran in the tail of that iteration's last
-        // kernel (hyp_head: the last-arriving shading workgroup of the hypothesis), which left mtx | final of the new pose in
-        // mats[it & 1]; requested together with the first meshlet above -- nothing between the kernel's start and its matrix-core
-        // transform depends on a second memory level.
-        const float4 fr = ld4(E.mats + ((size_t)par * B + b) * 32 + 16 + (lane & 3) * 4);
-        // ---- this slot's share of the re-arm of what iteration it - 1 dirtied (zbuf of its active tiles, their flags; parity
-        // (it - 1) & 1): count, list (written by that iteration's shading launch) and the first tile are requested at once too;
-        // tile k of the list is re-armed by slot k % SL.  No pass needs a memset.
-        {
-            const int cur = 1 - par;
-            const int n_act = E.L.b_count[b];
-            const int* tiles = E.L.active + (size_t)b * E.L.NT;
-            const int txy_first = slot < E.L.NT ? tiles[slot] : 0;  // (speculative: stale beyond the count, never used then)
-            unsigned long long* Z = E.L.zbuf + ((size_t)cur * B + b) * E.L.zper;
-            unsigned char* flag = E.L.tile_flag + ((size_t)cur * B + b) * E.L.NTp;
-            unsigned char* big = E.L.tile_big + ((size_t)cur * B + b) * E.L.NTp;
-            for (int k = slot; k < n_act; k += SL) {  // (workgroup-uniform)
-                const int txy = k == slot ? txy_first : tiles[k];
-                const int tx = txy & 0xffff, ty = txy >> 16;
-                if (tid == 0) {
-                    flag[ty * E.L.ntx + tx] = 0;
-                    big[ty * E.L.ntx + tx] = 0;
-                }
-#pragma unroll
-                for (int p = tid; p < DDX_TILE * DDX_TILE; p += NTH) {
-                    const int zx = tx * DDX_TILE + p % DDX_TILE, zy = ty * DDX_TILE + p / DDX_TILE;
-                    if (zx < d.W && zy < d.H) Z[zaddr(zx, zy, E.L.zwb)] = ~0ull;
-                }
-            }
-        }
-        Fr[0] = fr.x; Fr[1] = fr.y; Fr[2] = fr.z; Fr[3] = fr.w;
+        update_head<NTH, false>(E, b, it - 1, slot, SL, snew, sc);
     } else {
-        // first iteration of a run: the parameters as the caller holds them (un-normalised) -> q/|q| (diffdope.py:1091), [R|t]
-        // (:46-89), final = proj . mtx (:195, k-ordered fma) in every lane, from LDS broadcasts
+        // first iteration of a run: the parameters as the caller holds them (un-normalised)
         if (tid < 7) snew[tid] = E.b.params[(size_t)tid * B + b];
         if (tid >= 16 && tid < 32) sc[tid] = E.b.proj[tid - 16];
-        if (mode == STEP_FIRST && writer && tid < 21) {  // what ddx_engine_run_check restores should this run have to be repeated (EngineDev::run_snap)
+        if (mode == STEP_FIRST && slot == 0 && tid < 21) {  // what ddx_engine_run_check restores should this run have to be repeated (EngineDev::run_snap)
             E.run_snap[(size_t)tid * B + b] = tid < 7 ? E.b.params[(size_t)tid * B + b] : E.adam[((size_t)par * 14 + (tid - 7)) * B + b];
         }
         __syncthreads();
+    }
+    const bool writer = slot == 0;
+    STAMP(E, 0, wg_id, 1);
+    // ---- pose -> matrices (every lane, from LDS broadcasts: ~150 flops, cheaper than a dependent load)
+    float Fr[4];
+    {
         float q[4], t3[3], M4[16], pr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = snew[i];
@@ -1976,11 +1865,13 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
         for (int i = 0; i < 3; ++i) t3[i] = snew[4 + i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) pr[k] = sc[16 + (lane & 3) * 4 + k];  // row lane % 4 of proj
-        const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        {   // q / |q| (diffdope.py:1091) and [R|t] (diffdope.py:46-89)
+            const float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
-        quat_to_matrix(q, t3, M4);
-        final_row(pr, M4, Fr);
+            for (int i = 0; i < 4; ++i) q[i] = __fdiv_rn(q[i], nq);
+            quat_to_matrix(q, t3, M4);
+        }
+        final_row(pr, M4, Fr);  // row lane % 4 of final = proj . mtx (torch.matmul at :195, k-ordered fma)
         if (writer && tid < 4) {  // lanes 0..3 hold rows 0..3 of final; each writes its row of both matrices
             float* dst = E.mats + ((size_t)par * B + b) * 32;
             float* logm = E.b.mtx_log ? E.b.mtx_log + ((size_t)it * B + b) * 16 : nullptr;
@@ -1993,9 +1884,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
                 if (logm) logm[tid * 4 + c] = Mr[c];
             }
         }
-        if (writer && tid < 7) E.params2[((size_t)par * 7 + tid) * B + b] = snew[tid];
     }
-    STAMP(E, 0, wg_id, 1);
     // ---- is the whole object inside the view volume?  The 8 corners of its object-space bounding box through the same
     // transform (lanes 0..7 of every wave): w > 0, -w <= z <= w at every corner => at every vertex (see EngineDev::cull_sign)
     bool inside_all;
@@ -2007,6 +1896,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     }
     const int cull = (E.cull_sign != 0 && inside_all) ? E.cull_sign : 0;
     if (writer) {
+        if (mode != STEP_NORMAL && tid < 7) E.params2[((size_t)par * 7 + tid) * B + b] = snew[tid];
         if (tid == 0) {
             E.inside[b] = inside_all ? 1 : 0;
             E.L.bigcount[(size_t)(1 - par) * B + b] = 0;  // the other parity's list of large triangles: consumed, nobody reads it now
@@ -2032,7 +1922,7 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     const bool rec = TAB && E.mcost_rec != 0;
     unsigned long long t_m = rec ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (int mk = 0; mk < n_my; ++mk) {  // (workgroup-uniform)
-        const int m = mk == 0 ? m0 : meshlet_of(mk);  // (the slot's list in LDS is readable behind the first barrier of this loop)
+        const int m = meshlet_of(mk);
         // ---- the meshlet's vertices on the matrix core -> LDS (clip + 1/256-pixel window snap); the owner of a vertex also
         // stores it for the antialias pass and the tile pass
 #pragma unroll
@@ -2116,6 +2006,29 @@ __global__ __launch_bounds__(NTH, STEP_WAVES(MODE)) void step_group_kernel(const
     step_wg<TPL, NTH, MODE>(tab[G.idx[o]], (int)blockIdx.y - G.bpre[o], blockIdx.x, G.sl[o], mode, it_arg);
 }
 
+// the optimiser step of the LAST iteration of a run (or of an evaluation pass): update_head alone, then both parities are clean
+__device__ __forceinline__ void finish_wg(const EngineDev& E, int b, int slice, int n_slices, int it_arg)
+{
+    __shared__ float snew[8];
+    __shared__ float sc[64];
+    const int it = it_arg >= 0 ? it_arg : E.st->it, par = it & 1;
+    update_head<256, true>(E, b, it - 1, slice, n_slices, snew, sc);
+    if (slice == 0 && threadIdx.x == 0) {
+        E.L.bigcount[(size_t)(1 - par) * E.d.B + b] = 0;
+        E.L.bigarrive[(size_t)(1 - par) * E.d.B + b] = 0;
+        if (b == 0) E.L.counters[3 + (1 - par)] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(EngineDev E, int it_arg) { finish_wg(E, blockIdx.y, blockIdx.x, gridDim.x, it_arg); }
+
+// group form: grid (slices, sum of the members' hypotheses)
+__global__ __launch_bounds__(256) void finish_group_kernel(const EngineDev* __restrict__ tab, GroupHdr G, int it_arg)
+{
+    const int o = group_find(G, blockIdx.y);
+    finish_wg(tab[G.idx[o]], (int)blockIdx.y - G.bpre[o], blockIdx.x, gridDim.x, it_arg);
+}
+
 // the tile pass for large / near-clipped triangles of the iteration being drawn (raster_dev.h big_pass_body); exits on one
 // scalar load when the batch has none (always, for the 20k-50k-triangle meshes of the benchmark)
 #define BIG_WAVES 16
@@ -2138,8 +2051,8 @@ __global__ __launch_bounds__(BIG_WAVES * 64) void big_pass_group_kernel(const En
 }
 
 // ---------------------------------------------------------------------------------------------
-enum { K_STEP, K_BIG, K_SHADE, K_EDGE, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"step_kernel", "big_pass_kernel", "shade_kernel", "edge_kernel"};
+enum { K_STEP, K_BIG, K_SHADE, K_EDGE, K_FINISH, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"step_kernel", "big_pass_kernel", "shade_kernel", "edge_kernel", "finish_kernel"};
 
 // shading grid (B, S): S slices per hypothesis, SHADE_GRID workgroups per role in total (all resident at 4 waves/SIMD)
 static dim3 shade_grid(const ddx_engine_desc& d)
@@ -2154,6 +2067,14 @@ static dim3 shade_grid(const ddx_engine_desc& d)
     if (S < 1) S = 1;
     if (S > 64) S = 64;
     return dim3(d.B, S);
+}
+
+// finish_kernel: the slices of a hypothesis only share its re-arm work
+static int upd_slices(const ddx_engine_desc& d)
+{
+    int sl = UPD_SLICES;
+    while (sl > 1 && (long long)d.B * sl > 1024) sl >>= 1;
+    return sl;
 }
 
 // edge_kernel: 66 VGPRs, 7 waves/SIMD, so more resident workgroups than the shade kernel has
@@ -2339,8 +2260,7 @@ static int launch_step(ddx_engine* e, int mode, int it, hipStream_t s, int half 
 }
 
 // the rest of an iteration after its step_kernel: tile pass for large triangles, shading (+ edge term)
-// fin: this is the last iteration of a run (or an evaluation pass): the hypotheses' heads also select, re-arm and leave the status
-static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */, int half = -1, int fin = 0)
+static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K_COUNT+1 events or null */, int half = -1)
 {
     EngineDev& E = e->dev;
     const ddx_engine_desc& d = E.d;
@@ -2356,28 +2276,38 @@ static int launch_rest(ddx_engine* e, int it, hipStream_t s, hipEvent_t* ev /* K
         RoctxRange rr("ddx.shade_kernel");
         const dim3 g(nb, E.s_shade, E.n_roles + (E.big_inline ? 1 : 0));  // (the slices fixed at creation: the partial rows are laid out for them)
         if (half >= 0) {
-            if (d.use_edge) shade_kernel<true, true><<<g, 256, 0, s>>>(E, it, fin);
-            else shade_kernel<false, true><<<g, 256, 0, s>>>(E, it, fin);
-        } else if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E, it, fin);
-        else shade_kernel<false><<<g, 256, 0, s>>>(E, it, fin);
+            if (d.use_edge) shade_kernel<true, true><<<g, 256, 0, s>>>(E, it);
+            else shade_kernel<false, true><<<g, 256, 0, s>>>(E, it);
+        } else if (d.use_edge) shade_kernel<true><<<g, 256, 0, s>>>(E, it);
+        else shade_kernel<false><<<g, 256, 0, s>>>(E, it);
     }
     if (ev) DDX_HIP(hipEventRecord(ev[K_EDGE], s));
     if (d.use_edge) {
         RoctxRange rr("ddx.edge_kernel");
-        if (half >= 0) edge_kernel<true><<<dim3(nb, E.s_edge), 256, 0, s>>>(E, it, fin);
-        else edge_kernel<false><<<dim3(nb, E.s_edge), 256, 0, s>>>(E, it, fin);
+        if (half >= 0) edge_kernel<true><<<dim3(nb, E.s_edge), 256, 0, s>>>(E, it);
+        else edge_kernel<false><<<dim3(nb, E.s_edge), 256, 0, s>>>(E, it);
     }
     E.b_off = 0;
-    if (ev) DDX_HIP(hipEventRecord(ev[K_COUNT], s));
+    if (ev) DDX_HIP(hipEventRecord(ev[K_FINISH], s));
     DDX_LAUNCH_CHECK();
     return 0;
 }
 
-static int run_iteration(ddx_engine* e, int it, hipStream_t s, int fin = 0)  // one iteration after the first of a run (it = -1: for a graph)
+static int launch_finish(ddx_engine* e, int it /* the iteration after the last one drawn */, hipStream_t s)
+{
+    RoctxRange rr("ddx.finish_kernel");
+    EngineDev& E = e->dev;
+    const dim3 g(upd_slices(E.d), E.d.B);
+    finish_kernel<<<g, 256, 0, s>>>(E, it);
+    DDX_LAUNCH_CHECK();
+    return 0;
+}
+
+static int run_iteration(ddx_engine* e, int it, hipStream_t s)  // one iteration after the first of a run (it = -1: for a graph)
 {
     RoctxRange rr("ddx.iteration");
     if (int err = launch_step(e, STEP_NORMAL, it, s)) return err;
-    return launch_rest(e, it, s, nullptr, -1, fin);
+    return launch_rest(e, it, s, nullptr);
 }
 
 static int check_desc(const ddx_engine_desc* d)
@@ -2560,7 +2490,6 @@ static int engine_setup(ddx_engine* e, hipStream_t s)
 {
     EngineDev& E = e->dev;
     DDX_HIP(hipMemsetAsync(E.st, 0, sizeof(EngineState), s));
-    DDX_HIP(hipMemsetAsync(E.arrive, 0, (size_t)E.d.B * sizeof(int), s));  // (the last arriver of every launch puts its counter back)
     DDX_HIP(hipMemsetAsync(&E.st->sel_key, 0xFF, sizeof(unsigned long long), s));
     DDX_HIP(hipMemsetAsync(E.adam, 0, (size_t)2 * 14 * E.d.B * sizeof(float), s));
     DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));  // (both parities) kept zero by update_head afterwards
@@ -3080,14 +3009,15 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
     if (n == 0) return 0;
     RoctxRange rr("ddx_engine_run");
     if (int err = run_prologue(e, it0, s)) return err;
-    // iteration it0 is drawn from the caller's parameters; the optimiser step of every iteration runs in the tail of that iteration's
-    // last kernel (hyp_head), the run's last one with fin = 1 (selection, re-arm, status): a run of n iterations is 2 n launches
+    // iteration it0 is drawn from the caller's parameters; each later step_kernel first steps the optimiser for the iteration
+    // before it; finish_kernel steps it for the last one
     // Long runs: the iterations after the first as two chains of half-batch launches, one on the caller's stream and one on a
     // stream of the engine's own, forked from and joined to the caller's by events -- one chain's kernel boundaries and launch
-    // prologues are covered by the other chain's work (fork + join cost 25-30 us per run -- tools/two_stream_threshold.py --: hence
-    // two_min_iters).  Every hypothesis runs the slots, slices and sums it runs in the full launches -- the same bits --; the words
-    // the halves share are atomically counted (selection key, status sums: hyp_head) and the tile pass's global "a large triangle
-    // exists" word, which only the separate big_pass_kernel reads: hence big_inline only.
+    // prologues are covered by the other chain's work (cfg2: 40.0 -> 37.8 us per iteration; fork + join cost 25-30 us per run: even
+    // at 14-16 iterations, 1.5 % ahead at 20, 4.7 % at 48, 6 % at 100 -- tools/two_stream_threshold.py --: hence two_min_iters).
+    // Every hypothesis runs the slots, slices and sums it runs in the full launches -- the same bits --; the words the halves share
+    // are the status counters (rewritten by finish_kernel after the join) and the tile pass's global "a large triangle exists"
+    // word, which only the separate big_pass_kernel reads: hence big_inline only.
     // (Forking before the first iteration as well measured 7 us worse per run.)
     bool capturing = false;
     {
@@ -3097,12 +3027,9 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
     bool two = two_streams_possible(e) && !use_graph && !capturing && n >= two_streams_min_iters(e) && !e->dev.trace;
     if (two)  // (a caller stream this engine has not met yet is probed here, once: synchronises it)
         if (int err = ensure_side_stream(e, s, &two)) return err;
-    e->dev.sel_out = sel_out;  // (the by-value copy of the arguments carries it; read by the heads of the LAST iteration only)
-    e->dev.sel_lo = sel_lo;
-    struct Unset { EngineDev& E; ~Unset() { E.sel_out = nullptr; } } unset{e->dev};
     if (int err = launch_step(e, STEP_FIRST, it0, s)) return err;
-    if (int err = launch_rest(e, it0, s, nullptr, -1, n == 1)) return err;
-    if (use_graph && !e->exec && n > 2) {
+    if (int err = launch_rest(e, it0, s, nullptr)) return err;
+    if (use_graph && !e->exec && n > 1) {
         hipStream_t cs;
         DDX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         DDX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
@@ -3123,11 +3050,10 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         DDX_HIP(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         int err = 0;
         for (int i = 1; i < n && !err; ++i) {
-            const int fin = i == n - 1;
             err = launch_step(e, STEP_NORMAL, it0 + i, s, 0);
             if (!err) err = launch_step(e, STEP_NORMAL, it0 + i, e->side, 1);
-            if (!err) err = launch_rest(e, it0 + i, s, nullptr, 0, fin);
-            if (!err) err = launch_rest(e, it0 + i, e->side, nullptr, 1, fin);
+            if (!err) err = launch_rest(e, it0 + i, s, nullptr, 0);
+            if (!err) err = launch_rest(e, it0 + i, e->side, nullptr, 1);
         }
         // (joined on the error path too: whatever did go out on the engine's stream stays ordered before the caller's next work)
         DDX_HIP(hipEventRecord(e->ev_join, e->side));
@@ -3135,15 +3061,19 @@ static int engine_run_impl(ddx_engine* e, int it0, int n, int use_graph, void* s
         if (err) return err;
     }
     for (int i = two ? n : 1; i < n;) {
-        // (the run's last iteration is never part of a replayed graph: its launches carry fin = 1)
-        if (use_graph && e->exec && i + e->graph_chunk <= n - 1) {
+        if (use_graph && e->exec && i + e->graph_chunk <= n) {
             DDX_HIP(hipGraphLaunch(e->exec, s));
             i += e->graph_chunk;
         } else {
-            if (int err = run_iteration(e, it0 + i, s, i == n - 1)) return err;
+            if (int err = run_iteration(e, it0 + i, s)) return err;
             ++i;
         }
     }
+    e->dev.sel_out = sel_out;  // (finish_kernel's by-value copy of the arguments carries it)
+    e->dev.sel_lo = sel_lo;
+    const int ferr = launch_finish(e, it0 + n, s);
+    e->dev.sel_out = nullptr;
+    if (ferr) return ferr;
     e->adam_parity = (it0 + n) & 1;
     e->last.kind = 1; e->last.it0 = it0; e->last.n = n; e->last.use_graph = use_graph; e->last.sel_out = sel_out; e->last.sel_lo = sel_lo;
     return 0;
@@ -3171,15 +3101,7 @@ static int disable_inline(ddx_engine* e, hipStream_t s)
     if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
     if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     ++e->setup_gen;  // (a group compares generations: its table row of this member is stale now)
-    // The workers whose arrival was not waited for drew into the depth buffer BEHIND the shading workgroups -- in a run's last
-    // iteration behind the re-arm its heads do (hyp_head, fin) --: everything a run expects clean goes back to what the set-up
-    // leaves (the stream has been synchronised by read_flags: nothing of the void run is still in flight).
-    EngineDev& E = e->dev;
-    DDX_HIP(hipMemsetAsync(E.L.counters, 0, E.L.zero_bytes, s));
-    DDX_HIP(hipMemsetAsync(E.L.zbuf, 0xFF, E.L.zbuf_bytes, s));
-    DDX_HIP(hipMemsetAsync(E.arrive, 0, (size_t)E.d.B * sizeof(int), s));
-    DDX_HIP(hipMemsetAsync(&E.st->sel_key, 0xFF, sizeof(unsigned long long), s));
-    DDX_HIP(hipMemsetAsync(&E.st->sel_arrive, 0, 4 * sizeof(int), s));  // sel_arrive, fin_arrive, acc_active, acc_outside
+    (void)s;
     return 0;
 }
 
@@ -3277,12 +3199,12 @@ extern "C" int ddx_engine_eval(ddx_engine* e, int it, float* grad_out, float* lo
     // runs to repeat; same bits either way)
     const int keep_inline = e->dev.big_inline;
     e->dev.big_inline = 0;
-    // (the heads of an evaluation's launches hand out gradient and losses and step nothing: EngineDev::eval_grad)
-    e->dev.eval_grad = grad_out;
-    e->dev.eval_loss = loss_out;
     int err = launch_step(e, STEP_EVAL, it, s);
-    if (!err) err = launch_rest(e, it, s, nullptr, -1, 1);
+    if (!err) err = launch_rest(e, it, s, nullptr);
     e->dev.big_inline = keep_inline;
+    e->dev.eval_grad = grad_out;  // (finish_kernel in evaluation mode: hands out gradient and losses, steps nothing)
+    e->dev.eval_loss = loss_out;
+    if (!err) err = launch_finish(e, it + 1, s);
     e->dev.eval_grad = nullptr;
     e->dev.eval_loss = nullptr;
     return err;
@@ -3397,21 +3319,26 @@ extern "C" int ddx_engine_profile(ddx_engine* e, int it0, int iters, float* ms_o
     for (int i = 0; i < iters; ++i) {
         DDX_HIP(hipEventRecord(ev[K_STEP], s));
         if (int err = launch_step(e, i == 0 ? STEP_EVAL : STEP_NORMAL, it0 + i, s)) return err;
-        if (int err = launch_rest(e, it0 + i, s, ev, -1, i == iters - 1)) return err;  // (records ev[K_BIG .. K_COUNT])
-        DDX_HIP(hipEventSynchronize(ev[K_COUNT]));
+        if (int err = launch_rest(e, it0 + i, s, ev)) return err;
+        DDX_HIP(hipEventSynchronize(ev[K_FINISH]));
         if (i == 0 && iters > 1) continue;
         ++timed;
-        for (int k = K_STEP; k < K_COUNT; ++k) {
+        for (int k = K_STEP; k < K_FINISH; ++k) {
             float ms = 0.f;
             DDX_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             ms_out[k] += ms;
         }
     }
+    DDX_HIP(hipEventRecord(ev[K_FINISH], s));
+    if (int err = launch_finish(e, it0 + iters, s)) return err;
+    DDX_HIP(hipEventRecord(ev[K_COUNT], s));
+    DDX_HIP(hipEventSynchronize(ev[K_COUNT]));
     e->adam_parity = (it0 + iters) & 1;
     e->last.kind = 0;  // (a profile steps the optimiser without a snapshot: nothing to repeat)
-    for (int k = K_STEP; k < K_COUNT; ++k) ms_out[k] /= (float)timed;
+    for (int k = K_STEP; k < K_FINISH; ++k) ms_out[k] /= (float)timed;
     if (!e->dev.d.use_edge) ms_out[K_EDGE] = 0.f;  // (not launched)
     if (e->dev.big_inline) ms_out[K_BIG] = 0.f;    // (not launched: the tile pass rides in the shading launch; the interval is two event records)
+    DDX_HIP(hipEventElapsedTime(&ms_out[K_FINISH], ev[K_FINISH], ev[K_COUNT]));  // once per run, not per iteration
     for (int k = 0; k < K_COUNT; ++k)
         if (names_out) names_out[k] = kKernelNames[k];
     for (auto& x : ev) (void)hipEventDestroy(x);
@@ -3439,7 +3366,7 @@ extern "C" int ddx_engine_group_create(ddx_engine** engines, int n, ddx_engine_g
         DDX_REQUIRE(engines[i]->dev.d.max_iters == engines[0]->dev.d.max_iters, DDX_E_SHAPE, "engine_group_create: members differ in max_iters");
         for (int j = 0; j < i; ++j) DDX_REQUIRE(engines[j] != engines[i], DDX_E_SHAPE, "engine_group_create: member %d listed twice", i);
     }
-    {   // the hypotheses of all members share one grid dimension (y of the step launches: at most 65535)
+    {   // the hypotheses of all members share one grid dimension (y of the step / finish launches: at most 65535)
         long long btot = 0;
         for (int i = 0; i < n; ++i) btot += engines[i]->dev.d.B;
         DDX_REQUIRE(btot <= 65535, DDX_E_SHAPE, "engine_group_create: %lld hypotheses in all (at most 65535 per group)", btot);
@@ -3515,7 +3442,7 @@ static GroupHdr group_all(const ddx_engine_group* g)
     return H;
 }
 
-static int group_rest(ddx_engine_group* g, int it, hipStream_t s, int fin)
+static int group_rest(ddx_engine_group* g, int it, hipStream_t s)
 {
     const GroupHdr H = group_all(g);
     int smax = 1, semax = 0;
@@ -3526,9 +3453,9 @@ static int group_rest(ddx_engine_group* g, int it, hipStream_t s, int fin)
     }
     if (!g->big_inline) big_pass_group_kernel<<<dim3(BIG_GRID, H.n), BIG_WAVES * 64, 0, s>>>(g->d_tab, H, it);
     const dim3 gs(H.bpre[H.n], smax, g->big_inline ? 3 : 2);
-    if (edge) shade_group_kernel<true><<<gs, 256, 0, s>>>(g->d_tab, H, it, fin);
-    else shade_group_kernel<false><<<gs, 256, 0, s>>>(g->d_tab, H, it, fin);
-    if (edge) edge_group_kernel<<<dim3(H.bpre[H.n], semax), 256, 0, s>>>(g->d_tab, H, it, fin);
+    if (edge) shade_group_kernel<true><<<gs, 256, 0, s>>>(g->d_tab, H, it);
+    else shade_group_kernel<false><<<gs, 256, 0, s>>>(g->d_tab, H, it);
+    if (edge) edge_group_kernel<<<dim3(H.bpre[H.n], semax), 256, 0, s>>>(g->d_tab, H, it);
     DDX_LAUNCH_CHECK();
     return 0;
 }
@@ -3582,10 +3509,15 @@ extern "C" int ddx_engine_group_run(ddx_engine_group* g, int it0, int n, void* s
         g->uploaded = true;
     }
     if (int err = group_step(g, STEP_FIRST, it0, s)) return err;
-    if (int err = group_rest(g, it0, s, n == 1)) return err;
+    if (int err = group_rest(g, it0, s)) return err;
     for (int i = 1; i < n; ++i) {
         if (int err = group_step(g, STEP_NORMAL, it0 + i, s)) return err;
-        if (int err = group_rest(g, it0 + i, s, i == n - 1)) return err;
+        if (int err = group_rest(g, it0 + i, s)) return err;
+    }
+    {
+        const GroupHdr H = group_all(g);
+        finish_group_kernel<<<dim3(UPD_SLICES, H.bpre[H.n]), 256, 0, s>>>(g->d_tab, H, it0 + n);
+        DDX_LAUNCH_CHECK();
     }
     for (auto* e : g->members) { e->adam_parity = (it0 + n) & 1; e->last.kind = 0; }
     g->last_it0 = it0;

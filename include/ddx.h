@@ -274,7 +274,7 @@ typedef struct ddx_engine_desc {
      * launches; never above 7 000 meshlet-hypothesis pairs, where one launch fills the chip; no graph replay, no capture in
      * progress, tile pass inside the shading launch, B a multiple of 16) as two chains of half-batch launches: one on the
      * caller's stream, one on a second stream of the library, forked from the caller's stream after the first iteration and joined to
-     * it behind the run's last kernel -- so everything the call enqueues is still ordered on `stream` as far as the caller can
+     * it before the run's last kernel -- so everything the call enqueues is still ordered on `stream` as far as the caller can
      * see, and the results are the same bit for bit.  The second stream comes from a process-wide registry keyed by (device,
      * caller stream): the first engine that needs one for a caller stream checks with two 30-us kernels that a candidate really
      * runs beside it (streams that share a hardware queue take turns), tries up to six, and records the answer -- one chain if
@@ -327,9 +327,10 @@ int ddx_engine_run(ddx_engine* e, int it0, int n, int use_graph, void* stream);
  * (diffdope/diffdope.py:1488-1513, 1618-1632) for iteration it0 + n - 1 without a further launch: out18 (18 floats; device memory
  * or mapped pinned host memory) receives what ddx_select_best writes for that iteration's rows -- (mean over the engine's enabled
  * loss terms of the winner's weighted losses, lo + its local index, its 4x4 pose row-major), ties to the lowest index, a NaN
- * loss never wins.  The row is written by the run's last kernel (there is no closing launch: the optimiser step of every iteration
- * runs in the tail of that iteration's last kernel), out18[0] LAST and behind the rest of the row: with out18 in mapped pinned host
- * memory a caller may poll out18[0] (set it to a sentinel before the call) instead of synchronising the stream. */
+ * loss never wins.  The row is written by the run's last kernel, out18[0] LAST and behind the rest of the row: with out18 in mapped
+ * pinned host memory the end of a run costs one kernel and one synchronisation, and a caller may instead poll out18[0] (set to a
+ * sentinel before the call: a loss is never negative) -- the re-arm work of that last kernel may then still be in flight, so the
+ * NEXT call on the engine still orders itself behind it through `stream`. */
 int ddx_engine_run_select(ddx_engine* e, int it0, int n, int use_graph, int lo, float* out18, void* stream);
 /* The host half of every bounded in-kernel wait (at present: the tile pass inside the shading launch, separate_big_pass above).
  * Synchronises `stream` and reads status word 7 (bit 0: the in-launch tile pass).  0: the work enqueued so far is valid.  1: a wait of the last ddx_engine_run /
