@@ -17,6 +17,8 @@ import random
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -906,13 +908,21 @@ class DiffDope:
         finally:
             self._capture = None
         torch.cuda.current_stream().wait_stream(side)
-        # (nothing ran during the capture: the counter still names the first iteration to replay)
+        # THE COUNTER.  The captured iteration indexes the learning-rate table, the loss-row buffers and the pose log with the
+        # DEVICE-SIDE counter cap["it"], which the graph itself increments: exactly n_it - n_eager replays fit, and one more runs
+        # index_select / index_copy_ past the ends of those buffers -- the index kernels answer with a trap (the queue aborts with
+        # HSA_STATUS_ERROR_EXCEPTION 0x1016; tools/graph_fault_repro.py 8 6).  Nothing ran during the capture: the counter still
+        # names the first iteration to replay.
         for _ in range(n_eager, n_it):
             g.replay()
-        # The graph lives for this call only.  Results leave its buffers as copies, the last rendering (self.renders: tensors of the
-        # graph's pool) and the gradients go with it: a replay of a kept graph AFTER the caller had read the logs faulted on a device
-        # address in three of four orders of host-side operations tried (cfg2, 8 and 64 hypotheses; the same operations captured by
-        # hand in tools/bench_opbyop.py do not), and that is not understood -- so nothing is replayed once this call has returned.
+        # THE GRAPH LIVES FOR THIS CALL ONLY (HISTORY.md round 6 item 4 has the whole investigation).  A graph kept for the next
+        # call replays correctly when its counter is put back first -- three calls with the results read in between, six orders of
+        # host operations, 0.75-0.83 ms per iteration on cfg2 (tools/graph_fault_repro.py, graph_fault_repro2.py) -- but in the call
+        # sequence of tools/bench_opbyop.py the FIRST replay of a freshly captured graph faults on an address 15.8 GB above the
+        # rasteriser's scratch whenever a Python object is stored on this object between the capture and that replay (five variants
+        # of what is stored, graph included or not; without the store, and in the round-5 tree, the same sequence passes; the same
+        # iteration run eagerly in its captured form passes; no host-to-device copy and no BLAS call is among the captured nodes).
+        # That dependence on host-side allocation is not explained, so nothing is replayed once this call has returned.
         torch.cuda.current_stream().synchronize()
         mtx_rows = mtx_log[n_eager:].clone()
         for i in range(n_it - n_eager):
@@ -924,6 +934,9 @@ class DiffDope:
             rows = buf[n_eager:].clone()
             for i in range(n_it - n_eager):
                 self.losses_values.add(key, rows[i])
+        if os.environ.get("DDX_DEBUG_KEEP_GRAPH"):  # (tools/graph_fault_repro.py only: the graph and everything it was captured with stay alive)
+            self._kept_graph = dict(g=g, cap=cap, lr_table=lr_table, mtx_log=mtx_log, side=side, renders=self.renders, n_eager=n_eager)
+            return
         self.renders = None
         self.optimizer.zero_grad(set_to_none=True)
         del g

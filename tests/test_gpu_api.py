@@ -365,3 +365,40 @@ def test_captured_iteration_of_the_op_by_op_path_equals_the_eager_loop():
     assert len(b.optimization_results) == nb + 1 and len(junk) == 3
     for k in first:
         np.testing.assert_allclose(first[k].numpy(), b.losses_values[k].numpy(), rtol=3e-4, atol=1e-7)
+
+
+def test_captured_iteration_called_again_and_again_with_the_results_read_in_between(monkeypatch):
+    """run_optimization(fused=False, graph=True) three times on one object with get_argmin / the logs / a lazily rendered image
+    (through the rasteriser context the captured kernels point into) read in between: every call reproduces the eager loop from
+    the same start.  Round 6: the captured iteration indexes its learning-rate table, loss-row buffers and
+    pose log with a DEVICE-SIDE counter that the graph increments itself -- it must stand at the first iteration to replay before
+    the first replay and at the schedule's length after the last (one replay more and index_select / index_copy_ run past their
+    buffers: tools/graph_fault_repro.py 8 6, the queue aborts with 0x1016).  DDX_DEBUG_KEEP_GRAPH keeps the tables for the check."""
+    monkeypatch.setenv("DDX_DEBUG_KEEP_GRAPH", "1")
+    sc = make_scene(16, 20, 60, 80, B=1, dist=1.8)
+    B, nb = 4, 9
+    ref = _ddope(sc, ("rgb", "depth", "mask"), B, nb=nb)
+    ref.run_optimization(fused=False)
+    p_ref = ref.object3d.params_tensor().cpu().numpy()
+    l_ref = {k: v.numpy().copy() for k, v in ref.losses_values.items()}
+    d = _ddope(sc, ("rgb", "depth", "mask"), B, nb=nb)
+    p0 = [p.detach().clone() for p in d.object3d.parameters()]
+    for call in range(3):
+        with torch.no_grad():
+            for p, q in zip(d.object3d.parameters(), p0):
+                p.copy_(q)
+        d.run_optimization(fused=False, graph=True)
+        k = d._kept_graph
+        assert int(k["cap"]["it"]) == nb + 1 == k["lr_table"].numel() == k["mtx_log"].shape[0]  # (the counter: exactly at the end)
+        np.testing.assert_allclose(d.object3d.params_tensor().cpu().numpy(), p_ref, rtol=0, atol=2e-4)
+        for key in l_ref:
+            assert tuple(d.losses_values[key].shape) == (nb + 1, B)
+            np.testing.assert_allclose(d.losses_values[key].numpy(), l_ref[key], rtol=2e-3, atol=1e-6)
+        assert int(d.get_argmin()) == int(ref.get_argmin())
+        assert tuple(d.optimization_results[-1]["rgb"].shape) == (B, 60, 80, 3)
+        # the kept graph of THIS call replays once more when its counter is put back first (the mechanism a kept graph needs)
+        k["cap"]["it"].fill_(k["n_eager"])
+        k["g"].replay()
+        torch.cuda.synchronize()
+        assert int(k["cap"]["it"]) == k["n_eager"] + 1
+        d._kept_graph = None
