@@ -919,10 +919,11 @@ class DiffDope:
         # call replays correctly when its counter is put back first -- three calls with the results read in between, six orders of
         # host operations, 0.75-0.83 ms per iteration on cfg2 (tools/graph_fault_repro.py, graph_fault_repro2.py) -- but in the call
         # sequence of tools/bench_opbyop.py the FIRST replay of a freshly captured graph faults on an address 15.8 GB above the
-        # rasteriser's scratch whenever a Python object is stored on this object between the capture and that replay (five variants
-        # of what is stored, graph included or not; without the store, and in the round-5 tree, the same sequence passes; the same
-        # iteration run eagerly in its captured form passes; no host-to-device copy and no BLAS call is among the captured nodes).
-        # That dependence on host-side allocation is not explained, so nothing is replayed once this call has returned.
+        # rasteriser's scratch whenever the graph OR the tensors it was captured with (tables, counter, capture stream) are stored on
+        # this object between the capture and that replay (five variants; storing an unrelated object does not do it; without the
+        # store, and in the round-5 tree, the same sequence passes; the same iteration run eagerly in its captured form passes; no
+        # host-to-device copy and no BLAS call is among the captured nodes).  A fault that depends on which host objects stay
+        # referenced is not explained, so nothing is replayed once this call has returned.
         torch.cuda.current_stream().synchronize()
         mtx_rows = mtx_log[n_eager:].clone()
         for i in range(n_it - n_eager):
