@@ -17,7 +17,7 @@ def run():
     rng = np.random.RandomState(2)
     q_gt, t_gt = syn.random_quat(rng), np.array([0.09, -0.05, -1.8])
     weights = dict(rgb=0.7, depth=1.0, mask=1.0, edge=0.5)
-    R = orc.RenderOracle(pos, tri, proj, H, W, {}, weights, uv=uv, tex=tex, dtype=np.float32, cull_backfaces=True)  # (the engine's visibility rule on a closed mesh)
+    R = orc.RenderOracle(pos, tri, proj, H, W, {}, weights, uv=uv, tex=tex, dtype=np.float32, cull_backfaces=False)  # (both faces: dr.rasterize's rule, the engine's default)
     r = R.render(orc.pose_fwd(np.concatenate([q_gt, t_gt])[:, None].astype(np.float32)))
     cov = r["rast"][0, ..., 3] > 0
     gt = dict(rgb=r["rgb"][0], depth=r["depth"][0], segmentation=np.repeat(cov[..., None], 3, -1).astype(np.float32))

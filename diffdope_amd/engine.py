@@ -46,8 +46,10 @@ class RefineEngine:
             that must reproduce the unsharded run bit for bit passes the unsharded engine's `slices` (ddx.h)
         compat: None = this build's documented arithmetic; "nvdiffrast" = where a deviation from nvdiffrast's published behaviour is
             switchable, nvdiffrast's (D2: the rasterize backward differentiates the unclamped barycentrics; ddx.h DDX_COMPAT_*)
-        cull_backfaces: skip the back faces of a closed mesh while a hypothesis lies inside the view volume (ddx.h
-            no_backface_cull; identical visibility in exact arithmetic).  False = always draw both faces.
+        cull_backfaces: False (default) = both faces of every triangle are drawn, as dr.rasterize does (diffdope.py:198-200).  True =
+            deviation D5: the back faces of a CLOSED mesh are skipped while a hypothesis lies inside the view volume (ddx.h
+            no_backface_cull = 0) -- identical visibility in exact arithmetic, ~8 % faster, but in float32 a back-facing sliver on the
+            silhouette can win a pixel (1 351 of 8 000 random hypotheses differ in some bit: profiles/r5c_cull_sweep.json).
         separate_big_pass: True = the tile pass for large / near-clipped triangles always as its own launch (ddx.h separate_big_pass);
             default: the set-up decides from the expected triangle size (no launch where no large triangle is expected; same results).
         single_stream: True = every launch of a run on the caller's stream (ddx.h single_stream); default: a run of 16 or more
@@ -56,7 +58,7 @@ class RefineEngine:
 
     def __init__(self, pos, tri, proj, resolution, gt, params, lr_mult, lr_sched, weights, uv=None, tex=None,
                  vtx_color=None, optimizer="sgd", adam=(0.9, 0.999, 1e-8), global_batch=None, log_mtx=True, shade_slices=0,
-                 edge_slices=0, cull_backfaces=True, compat=None, separate_big_pass=False, single_stream=False):
+                 edge_slices=0, cull_backfaces=False, compat=None, separate_big_pass=False, single_stream=False):
         self.lib = _lib.load()
         dev = pos.device
         if dev.type != "cuda":

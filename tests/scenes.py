@@ -16,9 +16,9 @@ def make_scene(rows=10, cols=14, H=48, W=64, B=2, tex_size=32, seed=0, dist=2.0,
     q_gt, t_gt = syn.random_quat(rng), np.array([0.05 * dist, -0.03 * dist, -dist])
     weights = dict(rgb=0.7, depth=1.0, mask=1.0)
     kw = dict(uv=uv, tex=tex) if textured else dict(vtx_color=vcol)
-    # cull_backfaces=True: the visibility rule of the fused engine on this closed mesh (deviation D5); tests of the op-level
-    # renderer ops (nvdiffrast semantics: both faces) switch it off
-    R = orc.RenderOracle(pos, tri, proj, H, W, {}, weights, dtype=np.float32, cull_backfaces=True, **kw)
+    # both faces drawn: dr.rasterize's rule (diffdope.py:198-200), the default of RefineEngine, the DiffDope API and the op-level
+    # ops alike; tests of deviation D5 (back faces of the closed mesh culled) set R.cull_backfaces = True and ask the engine for it
+    R = orc.RenderOracle(pos, tri, proj, H, W, {}, weights, dtype=np.float32, cull_backfaces=False, **kw)
     p_gt = np.concatenate([q_gt, t_gt])[:, None].astype(np.float32)
     r = R.render(orc.pose_fwd(p_gt))
     cov = r["rast"][0, ..., 3] > 0

@@ -359,7 +359,7 @@ def test_mesh_with_more_vertices_than_triangles():
     tri = np.arange(len(pos), dtype=np.int32).reshape(-1, 3)
     assert len(pos) == 3 * len(tri)
     w = dict(rgb=0.7, depth=1.0, mask=1.0)
-    R = orc.RenderOracle(pos, tri, sc["proj"], sc["H"], sc["W"], sc["gt"], w, dtype=np.float32, cull_backfaces=True, uv=uv, tex=sc["tex"])
+    R = orc.RenderOracle(pos, tri, sc["proj"], sc["H"], sc["W"], sc["gt"], w, dtype=np.float32, cull_backfaces=False, uv=uv, tex=sc["tex"])
     total, logs, g_ref, r_ref = R.loss_and_grad(sc["params"], sc["lr_mult"])
     covered = r_ref["rast"][..., 3] > 0
     assert covered.sum() > 500 and r_ref["mask"][covered].min() > 0.4  # (no zero holes inside the silhouette)
@@ -562,7 +562,7 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
     keep = np.ones(len(sc["tri"]), bool)
     keep[100:140] = False
     sc_open = dict(sc, tri=sc["tri"][keep])
-    eng, _ = _engine(sc_open, w, [0.1])
+    eng, _ = _engine(sc_open, w, [0.1], cull_backfaces=True)
     l_open, g_open = eng.loss_and_grad()
     torch.cuda.synchronize()
     assert eng.cull_sign == 0
@@ -577,11 +577,12 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
     far = sc["params"].copy()
     far[6, 1] = -200.0
     sc_far = dict(sc, params=far)
-    eng, _ = _engine(sc_far, w, [0.1])
+    eng, _ = _engine(sc_far, w, [0.1], cull_backfaces=True)
     l_far, g_far = eng.loss_and_grad()
     torch.cuda.synchronize()
     assert eng.cull_sign == -1 and eng.status()["outside_view_volume"] == 1  # (reported: hypothesis 1 is not entirely inside)
     R = sc["oracle"]
+    R.cull_backfaces = True
     R.weights = {k: w.get(k) for k in ("rgb", "depth", "mask", "edge")}
     total, logs, g_ref, r_ref = R.loss_and_grad(far, sc["lr_mult"])
     lg = l_far.cpu().numpy()
@@ -595,13 +596,13 @@ def test_backface_culling_of_closed_meshes_is_invisible_and_conditional():
     for second, want in ((sc["tri"] + n, -1), ((sc["tri"] + n)[:, [0, 2, 1]], 0)):
         tri2 = np.concatenate([sc["tri"], second]).astype(np.int32)
         sc2 = dict(sc, pos=pos2, tri=tri2, uv=uv2)
-        eng, _ = _engine(sc2, w, [0.1])
+        eng, _ = _engine(sc2, w, [0.1], cull_backfaces=True)
         eng.loss_and_grad()  # (the mesh is analysed by the first run)
         torch.cuda.synchronize()
         assert eng.cull_sign == want == orc.mesh_cull_sign(pos2, tri2, sc["proj"])
     # (e) a flat two-sided patch next to the solid (edges pair up, the enclosed volume is round-off): no culling
     tri3 = np.concatenate([sc["tri"], sc["tri"][:30] + n, (sc["tri"][:30] + n)[:, [0, 2, 1]]]).astype(np.int32)
-    eng, _ = _engine(dict(sc, pos=pos2, tri=tri3, uv=uv2), w, [0.1])
+    eng, _ = _engine(dict(sc, pos=pos2, tri=tri3, uv=uv2), w, [0.1], cull_backfaces=True)
     eng.loss_and_grad()
     torch.cuda.synchronize()
     assert eng.cull_sign == 0 == orc.mesh_cull_sign(pos2, tri3, sc["proj"])

@@ -9,6 +9,19 @@ import diffdope_amd as dd
 from oracle import oracle as orc
 from tests.scenes import make_scene
 
+# which rasteriser rule the engine-vs-oracle cases run under: FUZZ_CULL=0 (default) both faces, dr.rasterize's rule and the engine's
+# default; FUZZ_CULL=1 deviation D5 (back faces of closed meshes culled), engine and oracle alike
+CULL = bool(int(__import__("os").environ.get("FUZZ_CULL", "0")))
+CULL_ENG = CULL
+
+
+def _RE(*a, **k):
+    import diffdope_amd as _dd
+
+    k.setdefault("cull_backfaces", CULL_ENG)
+    return _dd.RefineEngine(*a, **k)
+
+
 KEYS = ("rgb", "depth", "mask", "edge")
 T = lambda a, **k: torch.tensor(np.ascontiguousarray(a), device="cuda", **k)
 def sweep(n_cases=60, seed0=1000, verbose=True):
@@ -41,9 +54,10 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
             if rng.rand() < float(os.environ.get('FUZZ_NEAR', '0.25')):  # push one hypothesis towards / through the camera plane
                 sc["params"][6, 0] = -float(rng.uniform(0.05, 0.6))
             R = sc["oracle"]
+            R.cull_backfaces = CULL
             if textured and rng.rand() < 0.5:  # any texture size: non-square, not a power of two, down to 1 x 1
                 sc["tex"] = rng.uniform(size=(int(rng.randint(1, 70)), int(rng.randint(1, 70)), 3)).astype(np.float32)
-                R = orc.RenderOracle(sc["pos"], sc["tri"], sc["proj"], H, W, {}, dict(rgb=0.7, depth=1.0, mask=1.0), dtype=np.float32, cull_backfaces=True,
+                R = orc.RenderOracle(sc["pos"], sc["tri"], sc["proj"], H, W, {}, dict(rgb=0.7, depth=1.0, mask=1.0), dtype=np.float32, cull_backfaces=CULL,
                                      uv=sc["uv"], tex=sc["tex"])
                 R.gt = {k: v[None] for k, v in sc["gt"].items()}
                 stats["odd_textures"] = stats.get("odd_textures", 0) + 1
@@ -52,7 +66,7 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
             total, logs, g_ref, _ = R.loss_and_grad(sc["params"], sc["lr_mult"], global_B=G)
             tex = dict(uv=T(sc["uv"]), tex=T(sc["tex"])) if textured else dict(vtx_color=T(sc["vtx_color"]))
             params = T(sc["params"])
-            eng = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, params, T(sc["lr_mult"]), [0.1], weights, global_batch=G, **tex)
+            eng = _RE(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, params, T(sc["lr_mult"]), [0.1], weights, global_batch=G, **tex)
             losses, grad = eng.loss_and_grad()
             torch.cuda.synchronize()
             st = eng.check()
@@ -67,7 +81,7 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                 # float32 oracle's op-by-op backward leaves round-off of 1e-8..2e-8 where the kernels give exact zeros (seeds 5005595,
                 # 5100781, 5102773: its own float64 run gives 1e-17) -- the referee is then the float64 oracle
                 kw64 = dict(uv=sc["uv"], tex=sc["tex"]) if textured else dict(vtx_color=sc["vtx_color"])
-                R64 = orc.RenderOracle(sc["pos"], sc["tri"], sc["proj"], H, W, {}, dict(R.weights), dtype=np.float64, cull_backfaces=True, **kw64)
+                R64 = orc.RenderOracle(sc["pos"], sc["tri"], sc["proj"], H, W, {}, dict(R.weights), dtype=np.float64, cull_backfaces=CULL, **kw64)
                 R64.gt = {k: v.astype(np.float64) for k, v in R.gt.items()}
                 R64.weights = R.weights
                 g64 = R64.loss_and_grad(sc["params"].astype(np.float64), sc["lr_mult"].astype(np.float64), global_B=G)[2]
@@ -90,7 +104,7 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                 R.cull_backfaces = False
                 R.weights = dict(rgb=0.7, depth=1.0, mask=1.0)
                 tot2, _, g2, r2 = R.loss_and_grad(sc["params"], sc["lr_mult"])  # (global batch = B: the torch expressions below)
-                R.cull_backfaces = True
+                R.cull_backfaces = CULL
                 pl = [T(sc["params"][i], requires_grad=True) for i in range(7)]
                 q = torch.stack(pl[:4], dim=0).T
                 q = q / torch.norm(q, dim=1).reshape(-1, 1)
@@ -157,7 +171,7 @@ def sweep(n_cases=60, seed0=1000, verbose=True):
                 lrs3 = [0.05, 0.04, 0.03]
                 R.weights = {k: weights.get(k) for k in KEYS}
                 p3 = T(sc["params"])
-                e3 = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, p3, T(sc["lr_mult"]), lrs3, weights, global_batch=G, **tex)
+                e3 = _RE(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], {k: T(v) for k, v in sc["gt"].items()}, p3, T(sc["lr_mult"]), lrs3, weights, global_batch=G, **tex)
                 for it3, lr3 in enumerate(lrs3):
                     before = p3.cpu().numpy().copy()
                     e3.run(1); e3.finish()
@@ -326,7 +340,7 @@ def sweep_engine_soups(n_cases=200, seed0=0, verbose=True):
         kw = dict(uv=uv, tex=tex) if textured else dict(vtx_color=vcol)
         tag = f"engine soup {case} seed {seed0 + case}: {n_tri} triangles / {nv} vertices, frame {H}x{W}, dist {dist:.2f}, B {B}, {'tex' if textured else 'vcol'} {sorted(weights)}"
         try:
-            R = orc.RenderOracle(pos, tri, proj, H, W, {}, dict(rgb=1.0, depth=1.0, mask=1.0), dtype=np.float32, cull_backfaces=True, **kw)
+            R = orc.RenderOracle(pos, tri, proj, H, W, {}, dict(rgb=1.0, depth=1.0, mask=1.0), dtype=np.float32, cull_backfaces=CULL, **kw)
             q_gt, t_gt = syn.random_quat(rng), np.array([rng.uniform(-0.2, 0.2) * dist, rng.uniform(-0.2, 0.2) * dist, -dist])
             r = R.render(orc.pose_fwd(np.concatenate([q_gt, t_gt])[:, None].astype(np.float32)))
             cov = r["rast"][0, ..., 3] > 0
@@ -341,12 +355,12 @@ def sweep_engine_soups(n_cases=200, seed0=0, verbose=True):
             R.weights = {k: weights.get(k) for k in KEYS}
             total, logs, g_ref, _ = R.loss_and_grad(params, lr_mult)
             texk = dict(uv=T(uv), tex=T(tex)) if textured else dict(vtx_color=T(vcol))
-            eng = dd.RefineEngine(T(pos), T(tri), T(proj), [H, W], {k: T(v) for k, v in gt.items()}, T(params), T(lr_mult), [0.1], weights, **texk)
+            eng = _RE(T(pos), T(tri), T(proj), [H, W], {k: T(v) for k, v in gt.items()}, T(params), T(lr_mult), [0.1], weights, **texk)
             losses, grad = eng.loss_and_grad()
             torch.cuda.synchronize()
             st = eng.check()
             lg, gg = losses.cpu().numpy(), grad.cpu().numpy()
-            ok = bool(np.isfinite(gg).all()) and eng.cull_sign == R._cull_sign
+            ok = bool(np.isfinite(gg).all()) and eng.cull_sign == (R._cull_sign if CULL else 0)
             for i, k in enumerate(KEYS):
                 if k in logs: ok &= bool(np.allclose(lg[i], logs[k], rtol=1e-4, atol=2e-6))  # (atol: round-off of the frame sums)
             gerr = float(np.abs(gg - g_ref).max() / max(np.abs(g_ref).max(), 1e-5))  # (floor: oracle round-off where the true gradient vanishes)
@@ -473,9 +487,10 @@ def sweep_ops(n_cases=300, seed0=0, verbose=True):
                                 dist=float(rng.uniform(1.2, 4.0)), seed=seed0 + case)
                 weights = dict(rgb=0.7, depth=1.0, mask=1.0)
                 R = sc["oracle"]; R.weights = dict(weights, edge=None)
+                R.cull_backfaces = CULL
                 lrs = [0.01, 0.008, 0.006, 0.004]
                 p_t = T(sc["params"])
-                eng = dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [sc["H"], sc["W"]], {k: T(v) for k, v in sc["gt"].items()}, p_t, T(sc["lr_mult"]), lrs,
+                eng = _RE(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [sc["H"], sc["W"]], {k: T(v) for k, v in sc["gt"].items()}, p_t, T(sc["lr_mult"]), lrs,
                                       weights, uv=T(sc["uv"]), tex=T(sc["tex"]), optimizer="adam")
                 m1 = np.zeros_like(sc["params"]); m2 = np.zeros_like(sc["params"])
                 b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-8)
@@ -528,7 +543,7 @@ def sweep_state(n_cases=100, seed0=0, verbose=True):
             tex = dict(uv=T(sc["uv"]), tex=T(sc["tex"])) if sc["textured"] else dict(vtx_color=T(sc["vtx_color"]))
             gt = {k: T(v) for k, v in sc["gt"].items()}
             def engine(params, lr_mult, lo=0, hi=B, **kw):
-                return dd.RefineEngine(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], gt, params, T(lr_mult[lo:hi]), lrs, weights, optimizer=optimizer, **tex, **kw)
+                return _RE(T(sc["pos"]), T(sc["tri"]), T(sc["proj"]), [H, W], gt, params, T(lr_mult[lo:hi]), lrs, weights, optimizer=optimizer, **tex, **kw)
             p_ref = T(sc["params"])
             ref = engine(p_ref, sc["lr_mult"], single_stream=wide)
             ref.run(); ref.finish()
