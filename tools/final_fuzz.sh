@@ -2,7 +2,7 @@
 # tools/final_fuzz.sh <tag> [percent] -- the randomised sweeps on the committed kernels (fresh seeds 8xxxxxx); percent scales the case counts
 # (100 = the full battery of round 4, ~1.5 h of GPU time; the round-5 session ran 30)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-T=${1:-r5c}; P=${2:-30}
+T=${1:-r6d}; P=${2:-30}
 mkdir -p gpurun_out
 n() { echo $(( $1 * P / 100 )); }
 G='MISMATCH\|ERROR\|cases,\|soups,\|bad,\|Traceback'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # final measurement session of the round: everything profiles/r5c_* is made of (run on the GPU box through gpurun)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-T=${1:-r5c}
+T=${1:-r6d}
 O=gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/${T}_pytest_gpu.log 2>&1; tail -3 $O/${T}_pytest_gpu.log
@@ -33,9 +33,10 @@ timeout 120 python tools/launch_sync_cost.py 2>/dev/null | tail -6 > $O/${T}_lau
 timeout 120 python tools/fixed_cost.py 2>/dev/null | tail -9 > $O/${T}_fixed_cost.txt; cat $O/${T}_fixed_cost.txt
 DDX_TRACE=1 DDX_TWO_STREAMS=0 timeout 120 python tools/trace_kernels.py > $O/${T}_trace_cfg2.log 2>&1; cat $O/${T}_trace_cfg2.log
 timeout 300 python tools/large_batch.py > $O/${T}_large_batch.log 2>&1; cat $O/${T}_large_batch.log
+timeout 400 python tools/ab_engine.py . 2>/dev/null > $O/${T}_windows.log; cat $O/${T}_windows.log
 timeout 300 python tools/multi_object_streams.py cfg5 > $O/${T}_multi_object_cfg5.log 2>&1; cat $O/${T}_multi_object_cfg5.log
-timeout 600 python tools/run_kernel_check.py --configs cfg2,cfg4,cfg50k64 --iters 20 > $O/${T}_run_kernel_check.log 2>&1; cat $O/${T}_run_kernel_check.log | cut -c1-200,560-900
 DDX_API_NB=100 timeout 300 python tools/bench_opbyop.py cfg2 --api --graph > $O/${T}_opbyop.txt 2>&1; cat $O/${T}_opbyop.txt
 timeout 900 python tools/cull_sweep.py 1000 0 > $O/${T}_cull_sweep.json 2>$O/${T}_cull_sweep.err; cat $O/${T}_cull_sweep.json
-timeout 2400 bash tools/final_fuzz.sh $T 30 > /dev/null 2>&1; cat $O/${T}_fuzz_final.log
+timeout 1800 bash tools/final_fuzz.sh $T 20 > /dev/null 2>&1; cat $O/${T}_fuzz_final.log
+FUZZ_CULL=1 timeout 900 bash tools/final_fuzz.sh ${T}_cull 8 > /dev/null 2>&1; cat $O/${T}_cull_fuzz_final.log
 echo FINAL DONE
