@@ -210,12 +210,29 @@ struct EngineDev {
                              // the dispatch order in which the wait cannot be satisfied while the shading workgroups fill the chip
 };
 
+// The optimiser head of step_kernel runs at a raised wave priority (s_setprio; 0 = off).  Its tail is one wave's chain of ~500 dependent
+// instructions, and the five workgroups of a CU keep theirs on the same SIMD: a workgroup whose partial rows arrive late shares
+// that SIMD with four neighbours that are already rasterising and used to get a fifth of its issue slots -- the head took 5.1 us in the
+// median and 8.9 / 13.8 us at the 90th percentile / worst, and the late tenth of a launch's workgroups was late BECAUSE of it
+// (tools/trace_tail.py, profiles/r6i_*).  With the priority: 7.1 / 8.4 us; cfg2 one chain 42.8 -> 41.8 us, two chains 40.8 -> 40.3
+// (priority 2 the same; the scan phase of shade_kernel raised likewise: no difference).
+#ifndef DDX_HEAD_PRIO
+#define DDX_HEAD_PRIO 3
+#endif
 #define TRACE_WG 4096
 // stamp i of kernel slot k (0 step, 1 shade, 2 other) for this workgroup: 100 MHz constant clock
 #define STAMP(E, k, wg, i)                                                                                  \
     do {                                                                                                    \
         if ((E).trace && threadIdx.x == 0 && (wg) < TRACE_WG)                                               \
             (E).trace[((size_t)(k) * TRACE_WG + (wg)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();         \
+    } while (0)
+
+// ... and where the workgroup runs (row 2 of the trace, word 7; words 0..6: the head's own stamps of a DDX_TRACE_HEAD build): HW_ID (cu 11:8, sh 12, se 15:13, simd 5:4) | XCC_ID << 32
+#define STAMP_HW(E, wg)                                                                                                  \
+    do {                                                                                                                 \
+        if ((E).trace && threadIdx.x == 0 && (wg) < TRACE_WG)                                                            \
+            (E).trace[((size_t)2 * TRACE_WG + (wg)) * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | \
+                                                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
     } while (0)
 
 struct ddx_engine {
@@ -1815,7 +1832,11 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     __shared__ float snew[8];  // the parameters this iteration is drawn with
     __shared__ float sc[64];   // update_head's scalars; 16..31 = proj
     const int wg_id = b * SL + slot;
+#if DDX_HEAD_PRIO
+    __builtin_amdgcn_s_setprio(DDX_HEAD_PRIO);
+#endif
     STAMP(E, 0, wg_id, 0);
+    STAMP_HW(E, wg_id);
     // (it_arg >= 0: the host names the iteration -- plain stream launches -- and the kernel starts without a dependent scalar load;
     // -1: replayed from a captured graph, whose arguments are frozen: the device counter says which iteration this is)
     const int it = it_arg >= 0 ? it_arg : E.st->it;
@@ -1919,9 +1940,12 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
     tg.ntx = E.L.ntx; tg.nty = E.L.nty; tg.NT = E.L.NT; tg.zwb = E.L.zwb;
     tg.ndc = E.L.ndc;
     STAMP(E, 0, wg_id, 2);
+#if DDX_HEAD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const bool rec = TAB && E.mcost_rec != 0;
     unsigned long long t_m = rec ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    for (int mk = 0; mk < n_my; ++mk) {  // (workgroup-uniform)
+    for (int mk = 0; mk < (DDX_ABLATE >= 4 ? 0 : n_my); ++mk) {  // (workgroup-uniform)
         const int m = meshlet_of(mk);
         // ---- the meshlet's vertices on the matrix core -> LDS (clip + 1/256-pixel window snap); the owner of a vertex also
         // stores it for the antialias pass and the tile pass
@@ -1964,7 +1988,11 @@ __device__ __forceinline__ void step_wg(const EngineDev& E, int b, int slot, int
 #else
         STAMP(E, 0, wg_id, mk == 0 ? 3 : 5);
 #endif
+#if DDX_ABLATE >= 3
+        if ((va[0].x ^ vb[0].y ^ vc[TPL - 1].x ^ t[0] ^ i0[0]) == 0x12345677) tg.flag[0] = 1;  // (measurement build: the vertices are still transformed, stored and read back)
+#else
         scatter_resolve<TPL, NTH, MODE>(tg, d.H, d.W, d.T, t, i0, i1, i2, ok, va, vb, vc, cull);
+#endif
 #ifdef DDX_TRACE_HEAD
         if (mk == 0) STAMP(E, 0, wg_id, 4);
 #else

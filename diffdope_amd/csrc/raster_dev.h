@@ -7,6 +7,14 @@
 #pragma once
 #include "raster.h"
 
+// Measurement builds only (tools/ablate_step.sh): DDX_ABLATE = n leaves out the n innermost stages of the rasteriser -- 1: the
+// fragments (depth + atomicMin), 2: + coverage mask, tile flags, clip-vertex loads, 3: + the triangle predicates and the compaction,
+// 4 (engine.hip): + the meshlet loop (transform) -- so that counter passes over the builds attribute the instructions of a launch
+// stage by stage.  The product is built without it; its frames are wrong with it.
+#ifndef DDX_ABLATE
+#define DDX_ABLATE 0
+#endif
+
 struct ScatterTarget {
     const float* P;            // clip-space vertices, 4 floats each, indexed by the i0 / i1 / i2 handed to the functions below
     unsigned long long* Z;     // zbuf of the hypothesis (zaddr() layout)
@@ -69,8 +77,7 @@ __device__ __forceinline__ scatter_mask_t small_mask(const int2& a, const int2& 
     // the ownership rule (v > 0 || (v == 0 && own)) is folded into the start value: v + own - 1 >= 0
     const int b0 = e0.e00 + (int)e0.own - 1, b1 = e1.e00 + (int)e1.own - 1, b2 = e2.e00 + (int)e2.own - 1;
     scatter_mask_t mask = 0;
-    // (a branch-free path for boxes of at most 2x2 centres -- nearly every triangle of the dense meshes -- that lets
-    // whole waves skip this loop was measured: +-0.5 % on cfg2 / cfg3 / cfg50k64: the kernel waits on its memory levels)
+    // (a branch-free path for boxes of at most 2x2 centres that lets whole waves skip this loop: see small_mask_rel, which has it)
     int idx = 0;
     int r0 = b0, r1 = b1, r2 = b2;
     for (int j = 0; j < nyp; ++j, r0 += e0.sy, r1 += e1.sy, r2 += e2.sy) {
@@ -90,6 +97,10 @@ __device__ __forceinline__ void walk_mask(scatter_mask_t mask, int px0, int py0,
     // one rounded product cannot carry it across one -- the same j as with the correctly rounded reciprocal, eleven instructions less
     // per triangle; k from the two 32-bit halves: (float) of a 64-bit bit index was a six-instruction u64 -> f32 conversion)
     const float rn = __builtin_amdgcn_rcpf((float)nxp);
+#if DDX_ABLATE >= 1
+    if (mask) S.flag[0] = 1;
+    return;
+#endif
     while (mask) {
 #if RASTER_SMALL_PX > 32
         const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
@@ -126,11 +137,12 @@ __device__ __forceinline__ void flag_tiles(unsigned char* flag, int ntx, int tx0
 // in the scope that computed the mask, because hoisting it out costs 2-3 % of the kernel in the compiler's schedule).
 // WALK = 2: ... unless one of the lanes that reached this point owns more than SCATTER_DIRECT_MAX centres, in which case they
 // all hand their masks to the wave's fragment exchange.
+#define SCATTER_FQ 128  // fragments a wave of the compacting variant queues before it resolves them (frames of at most 4096 x 4096 pixels: ddx_engine_create's limit)
 #ifndef SCATTER_DIRECT_MAX
 #define SCATTER_DIRECT_MAX 3  // waves in which no lane owns more fragments than this resolve them lane by lane
 #endif
 // DEFER (the compacting variant of the kernel): a small triangle that is neither degenerate nor culled is only reported
-// (cv.clipped = 2); scatter_small_deferred() resolves it after the wave has packed such triangles into consecutive lanes.
+// (cv.clipped = 2, its pixel box in cv); scatter_resolve packs such triangles into consecutive lanes and resolves them there.
 template <int WALK, bool DEFER = false>
 __device__ __forceinline__ unsigned scatter_one(const ScatterTarget& S, int H, int W, int t, int i0, int i1, int i2, const int2& a, const int2& bq,
                                                 const int2& c, ScatterCov& cv, int cull)
@@ -161,6 +173,10 @@ __device__ __forceinline__ unsigned scatter_one(const ScatterTarget& S, int H, i
     if (cand && small && front) {
         if (DEFER) {
             cv.clipped = 2;
+            cv.px0 = px0; cv.py0 = py0; cv.nxp = nxp | (nyp << 8);  // (the box travels with the survivor's record)
+            cv.mask = (scatter_mask_t)(area < 0);                  // (... which holds its corners in the order of positive area)
+        } else if (DDX_ABLATE >= 2) {
+            S.flag[0] = 1;
         } else {
             // pass 1: coverage of the <= RASTER_SMALL_PX bbox centres as a bit mask -- integer only
             scatter_mask_t mask = small_mask(a, bq, c, area, px0, py0, nxp, nyp);
@@ -209,24 +225,60 @@ __device__ __forceinline__ unsigned scatter_one(const ScatterTarget& S, int H, i
     return range;
 }
 
-// The body of scatter_one for a SMALL, non-degenerate, not culled triangle (see DEFER there): bbox, coverage mask of its
-// <= RASTER_SMALL_PX centres, tile flags, one depth evaluation + atomicMin per covered centre.  Same arithmetic, same results.
-__device__ __forceinline__ void scatter_small_deferred(const ScatterTarget& S, int H, int W, int t, int i0, int i1, int i2, const int2& a,
-                                                       const int2& bq, const int2& c)
+// small_mask for a survivor of the compacting variant: corner a, the other two RELATIVE to it (ab, ac) and already in the order that
+// makes the area positive (scatter_resolve swaps them in the record of a triangle with negative area: the edges of (a, c, b) are the
+// flipped edges of (a, b, c) -- the same lines walked the other way, the same integers, the same ownership rule).  With p = first
+// centre - a:   edge a->b: f2 = ab.x p.y - ab.y p.x;   edge c->a: f1 = ac.y p.x - ac.x p.y;   edge b->c: f0 = area - f1 - f2
+// (the three edge functions of a point sum to the area, exactly, in integers) -- four 24-bit multiplies instead of six, no flip selects.
+__device__ __forceinline__ scatter_mask_t small_mask_rel(int ax, int ay, int abx, int aby, int acx, int acy, int px0, int py0, int nxp, int nyp)
 {
-    const int xmin = min(a.x, min(bq.x, c.x)), xmax = max(a.x, max(bq.x, c.x));
-    const int ymin = min(a.y, min(bq.y, c.y)), ymax = max(a.y, max(bq.y, c.y));
-    int px0 = (xmin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, px1 = (xmax - DDX_SUBPIX / 2) >> 8;
-    int py0 = (ymin - DDX_SUBPIX / 2 + (DDX_SUBPIX - 1)) >> 8, py1 = (ymax - DDX_SUBPIX / 2) >> 8;
-    px0 = max(px0, 0); py0 = max(py0, 0);
-    px1 = min(px1, W - 1); py1 = min(py1, H - 1);
-    const int nxp = px1 - px0 + 1, nyp = py1 - py0 + 1;
-    const int area = __mul24(bq.x - a.x, c.y - a.y) - __mul24(c.x - a.x, bq.y - a.y);
-    const scatter_mask_t mask = small_mask(a, bq, c, area, px0, py0, nxp, nyp);
-    if (!mask) return;  // covers no centre: draws nothing, no tile to flag
-    flag_tiles(S.flag, S.ntx, max(px0 - 1, 0) / DDX_TILE, max(py0 - 1, 0) / DDX_TILE, min(px1 + 1, W - 1) / DDX_TILE, min(py1 + 1, H - 1) / DDX_TILE);
-    const float4 p0 = ld4(S.P + (size_t)i0 * 4), p1 = ld4(S.P + (size_t)i1 * 4), p2 = ld4(S.P + (size_t)i2 * 4);
-    walk_mask(mask, px0, py0, nxp, p0, p1, p2, t, S);
+    const int area = __mul24(abx, acy) - __mul24(acx, aby);  // > 0
+    const int apx = px0 * DDX_SUBPIX + DDX_SUBPIX / 2 - ax, apy = py0 * DDX_SUBPIX + DDX_SUBPIX / 2 - ay;
+    const int f2 = __mul24(abx, apy) - __mul24(aby, apx);
+    const int f1 = __mul24(acy, apx) - __mul24(acx, apy);
+    const int f0 = area - f1 - f2;
+    const int d0x = acx - abx, d0y = acy - aby;  // edge b->c
+    // ownership of the e == 0 line (dy > 0 || (dy == 0 && dx < 0)) folded into the start value: v + own - 1 >= 0
+    const int b0 = f0 + (int)((d0y > 0) || (d0y == 0 && d0x < 0)) - 1;
+    const int b1 = f1 + (int)((acy < 0) || (acy == 0 && acx > 0)) - 1;  // edge c->a: (dx, dy) = -ac
+    const int b2 = f2 + (int)((aby > 0) || (aby == 0 && abx < 0)) - 1;
+    // steps per pixel: sx = -dy * 256, sy = dx * 256
+    const int sx2 = -aby * DDX_SUBPIX, sy2 = abx * DDX_SUBPIX, sx1 = acy * DDX_SUBPIX, sy1 = -acx * DDX_SUBPIX;
+    const int sx0 = -(sx1 + sx2), sy0 = -(sy1 + sy2);
+    // (a branch-free path for boxes of at most 2x2 centres that lets whole waves skip the loop below: +-0.5 % at 64 hypotheses, where the
+    // kernel waits on its memory levels (rounds 3-5); at saturation the launch is VALU-bound and the loop's trips cost what they issue:
+    // 6 of 7 waves of cfg2's survivors qualify, round 6)
+    if (__ballot(nxp > 2 || nyp > 2) == 0ull) {
+        const bool c00 = (b0 | b1 | b2) >= 0;
+        const bool c10 = ((b0 + sx0) | (b1 + sx1) | (b2 + sx2)) >= 0 && nxp > 1;
+        const bool c01 = ((b0 + sy0) | (b1 + sy1) | (b2 + sy2)) >= 0 && nyp > 1;
+        const bool c11 = ((b0 + sx0 + sy0) | (b1 + sx1 + sy1) | (b2 + sx2 + sy2)) >= 0 && nxp > 1 && nyp > 1;
+        return (scatter_mask_t)((unsigned)c00 | ((unsigned)c10 << 1) | (((unsigned)c01 | ((unsigned)c11 << 1)) << nxp));  // bit k = j * nxp + i
+    }
+    scatter_mask_t mask = 0;
+    int idx = 0;
+    int r0 = b0, r1 = b1, r2 = b2;
+    for (int j = 0; j < nyp; ++j, r0 += sy0, r1 += sy1, r2 += sy2) {
+        int v0 = r0, v1 = r1, v2 = r2;
+        for (int i = 0; i < nxp; ++i, ++idx, v0 += sx0, v1 += sx1, v2 += sx2)
+            mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
+    }
+    return mask;
+}
+
+// The compacting variant's second stage (round 6): coverage mask + tile flags of a survivor whose pixel box travels in its record;
+// the covered centres are queued as FRAGMENTS (scatter_resolve) instead of being walked by the lane that owns the triangle.
+__device__ __forceinline__ scatter_mask_t scatter_small_mask(const ScatterTarget& S, int H, int W, int ax, int ay, int abx, int aby, int acx, int acy, int px0,
+                                                             int py0, int nxp, int nyp)
+{
+#if DDX_ABLATE >= 2
+    if (abx == 12345 && nxp == 77 && ax == acy && ay == aby + acx) S.flag[0] = 1;
+    return 0;
+#endif
+    const scatter_mask_t mask = small_mask_rel(ax, ay, abx, aby, acx, acy, px0, py0, nxp, nyp);
+    if (mask)  // (covers no centre: draws nothing, no tile to flag)
+        flag_tiles(S.flag, S.ntx, max(px0 - 1, 0) / DDX_TILE, max(py0 - 1, 0) / DDX_TILE, min(px0 + nxp, W - 1) / DDX_TILE, min(py0 + nyp, H - 1) / DDX_TILE);
+    return mask;
 }
 
 // every lane walks the fragments of its own triangle (clip-space vertices loaded only when it owns a centre)
@@ -276,6 +328,8 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
     constexpr bool COMPACT = MODE == 3;
     // compacting variant: 32 bytes per survivor: first corner, the other two relative to it in 16 bits (a small triangle spans
     // < 2^13 sub-pixels), vertex handles, triangle id
+    static_assert(!COMPACT || 64 * TPL <= 128, "a fragment names its survivor in 7 bits");
+    __shared__ unsigned s_fq[COMPACT ? NTHREADS / 64 : 1][COMPACT ? SCATTER_FQ : 1];  // the wave's fragment queue: pixel x | y << 12 | survivor slot << 24
     __shared__ int4 s_q[COMPACT ? NTHREADS / 64 : 1][2][COMPACT ? 64 * TPL : 1];  // (two planes of 16-byte records: a 32-byte record per lane made every 128-bit access a two-way bank conflict)
     // fragment exchange of one wave: exclusive prefix of the lanes' fragment counts, their coverage masks and triangle records
     __shared__ int s_pref[EXCHANGE ? NTHREADS / 64 : 1][EXCHANGE ? 64 : 1];
@@ -295,6 +349,8 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
         range[k] = scatter_one<(MODE == 0 || MODE == 3) ? 1 : MODE == 2 ? 2 : 0, COMPACT>(S, H, W, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k], cull);
     }
     if (COMPACT) {
+        // survivors: 32 bytes each in two planes -- (first corner, the other two relative to it in 16 bits) and (vertex handles in 10
+        // bits each, triangle id, first pixel of the box, its extent)
         int n_q = 0;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
@@ -305,23 +361,74 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
                 const int slot = n_q + __popcll(m & ((1ull << lane) - 1ull));
                 const unsigned rb = ((unsigned)(vb[k].x - va[k].x) & 0xffffu) | ((unsigned)(vb[k].y - va[k].y) << 16);
                 const unsigned rc = ((unsigned)(vc[k].x - va[k].x) & 0xffffu) | ((unsigned)(vc[k].y - va[k].y) << 16);
-                s_q[wv][0][slot] = make_int4(va[k].x, va[k].y, (int)rb, (int)rc);
-                s_q[wv][1][slot] = make_int4(i0[k], i1[k], i2[k], t[k]);
+                const bool neg = cv[k].mask != 0;  // (negative area: the two relative corners swap places, see small_mask_rel; the vertex handles keep their order)
+                s_q[wv][0][slot] = make_int4(va[k].x, va[k].y, (int)(neg ? rc : rb), (int)(neg ? rb : rc));
+                s_q[wv][1][slot] = make_int4(i0[k] | (i1[k] << 10) | (i2[k] << 20), t[k], cv[k].px0 | (cv[k].py0 << 16), cv[k].nxp);
             }
             n_q += __popcll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // ---- the survivors' covered centres become FRAGMENTS of the wave's queue (4 bytes: pixel, survivor slot), resolved 64 at a
+        // time with one depth evaluation + atomicMin per lane.  (Until round 6 the lane that owned a survivor walked its centres itself:
+        // 46 % of cfg2's survivors own a centre, hardly any more than two, and a wave ran max(count) = 1.5 rounds of the depth code at
+        // 30 % of its lanes for every 64 survivors; queued, the fragments of a meshlet's 128 triangles fill one round.)
+        int n_f = 0;
+        auto drain = [&]() {  // (wave-uniform)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int fb = 0; fb < n_f; fb += 64) {
+                const int fi = fb + lane;
+                if (fi < n_f) {
+                    const unsigned e = s_fq[wv][fi];
+                    const int4 h = s_q[wv][1][e >> 24];
+                    const int px = (int)(e & 4095u), py = (int)((e >> 12) & 4095u);
+                    const float4 p0 = ld4(S.P + (size_t)(h.x & 1023) * 4), p1 = ld4(S.P + (size_t)((h.x >> 10) & 1023) * 4), p2 = ld4(S.P + (size_t)((h.x >> 20) & 1023) * 4);
+                    float zw;
+                    const float fx = __fmaf_rn((float)px, S.ndc.xs, S.ndc.xo), fy = __fmaf_rn((float)py, S.ndc.ys, S.ndc.yo);
+                    if (pixel_depth(p0, p1, p2, fx, fy, zw))
+                        atomicMin(S.Z + zaddr(px, py, S.zwb), ((unsigned long long)depth_key(zw) << 32) | (unsigned)h.y);
+                }
+            }
+            n_f = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
         for (int base = 0; base < n_q; base += 64) {  // (wave-uniform)
             const int idx = base + lane;
+            scatter_mask_t mask = 0;
+            int px0 = 0, py0 = 0, nxp = 1;
             if (idx < n_q) {
                 const int4 g = s_q[wv][0][idx], h = s_q[wv][1][idx];
-                const int2 qa = make_int2(g.x, g.y);
-                const int2 qb = make_int2(g.x + (int)(short)((unsigned)g.z & 0xffffu), g.y + ((int)g.z >> 16));
-                const int2 qc = make_int2(g.x + (int)(short)((unsigned)g.w & 0xffffu), g.y + ((int)g.w >> 16));
-                scatter_small_deferred(S, H, W, h.w, h.x, h.y, h.z, qa, qb, qc);
+                px0 = h.z & 0xffff; py0 = (int)((unsigned)h.z >> 16); nxp = h.w & 255;
+                mask = scatter_small_mask(S, H, W, g.x, g.y, (int)(short)((unsigned)g.z & 0xffffu), (int)g.z >> 16, (int)(short)((unsigned)g.w & 0xffffu), (int)g.w >> 16,
+                                          px0, py0, nxp, h.w >> 8);
+            }
+#if DDX_ABLATE >= 1
+            if (mask) S.flag[0] = 1;
+            mask = 0;
+#endif
+            const float rn = __builtin_amdgcn_rcpf((float)nxp);
+            for (;;) {  // round r queues the r-th covered centre of every lane that has one
+                const unsigned long long bal = __ballot(mask != 0);
+                if (bal == 0ull) break;
+                const int n = __popcll(bal);
+                if (n_f + n > SCATTER_FQ) drain();
+                if (mask) {
+#if RASTER_SMALL_PX > 32
+                    const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+                    const int kb = mlo ? __ffs(mlo) - 1 : 31 + __ffs(mhi);
+#else
+                    const int kb = __ffs((unsigned)mask) - 1;
+#endif
+                    mask &= mask - 1;
+                    const int j = (int)(((float)kb + 0.5f) * rn), i = kb - __mul24(j, nxp);  // kb = j * nxp + i, exact for kb < 64 (walk_mask)
+                    s_fq[wv][n_f + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned)(px0 + i) | ((unsigned)(py0 + j) << 12) | ((unsigned)idx << 24);
+                }
+                n_f += n;
             }
         }
+        if (n_f) drain();
     }
     // ---- fragments.  A lane owns 0..64 covered centres of its triangle, most lanes none: walked lane by lane the wave runs
     // max(count) rounds at ~15 % lane utilisation, and one atomic instruction touches one pixel of up to 64 different
