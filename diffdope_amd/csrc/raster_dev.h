@@ -328,9 +328,9 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
     constexpr bool COMPACT = MODE == 3;
     // compacting variant: 32 bytes per survivor: first corner, the other two relative to it in 16 bits (a small triangle spans
     // < 2^13 sub-pixels), vertex handles, triangle id
-    static_assert(!COMPACT || 64 * TPL <= 128, "a fragment names its survivor in 7 bits");
-    __shared__ unsigned s_fq[COMPACT ? NTHREADS / 64 : 1][COMPACT ? SCATTER_FQ : 1];  // the wave's fragment queue: pixel x | y << 12 | survivor slot << 24
-    __shared__ int4 s_q[COMPACT ? NTHREADS / 64 : 1][2][COMPACT ? 64 * TPL : 1];  // (two planes of 16-byte records: a 32-byte record per lane made every 128-bit access a two-way bank conflict)
+    static_assert(!COMPACT || NTHREADS * TPL <= 1024, "a fragment names its survivor in 10 bits");
+    __shared__ unsigned short s_fq[COMPACT ? NTHREADS / 64 : 1][COMPACT ? SCATTER_FQ : 1];  // the wave's fragment queue: bit of the centre in the survivor's mask | survivor << 6
+    __shared__ int4 s_q[2][COMPACT ? NTHREADS * TPL : 1];  // (two planes of 16-byte records: a 32-byte record per lane made every 128-bit access a two-way bank conflict)
     // fragment exchange of one wave: exclusive prefix of the lanes' fragment counts, their coverage masks and triangle records
     __shared__ int s_pref[EXCHANGE ? NTHREADS / 64 : 1][EXCHANGE ? 64 : 1];
     __shared__ scatter_mask_t s_mask[EXCHANGE ? NTHREADS / 64 : 1][EXCHANGE ? 64 : 1];
@@ -349,8 +349,13 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
         range[k] = scatter_one<(MODE == 0 || MODE == 3) ? 1 : MODE == 2 ? 2 : 0, COMPACT>(S, H, W, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k], cull);
     }
     if (COMPACT) {
-        // survivors: 32 bytes each in two planes -- (first corner, the other two relative to it in 16 bits) and (vertex handles in 10
-        // bits each, triangle id, first pixel of the box, its extent)
+        // survivors: 32 bytes each in two planes -- (first corner, the other two relative to it in 16 bits, in the order of positive
+        // area) and (vertex handles in 10 bits each, triangle id, first pixel of the box, its extent), in the wave's own part of the planes.
+        // (Numbering the WORKGROUP's survivors through -- the four counts behind a barrier, batch i of 64 to wave i % 4: cfg2's ~92 of 128
+        // per wave are a full pass and one at 44 % of the lanes, the workgroup's ~368 five full passes and one at 75 % -- was built and
+        // measured, round 6: another 5 % fewer VALU instructions at saturation, and the barrier gave it back: cfg2 @512 214 = 214 us per
+        // iteration, cfg4 @512 227 -> 222, cfg50k64 55.9 -> 56.9, cfg3 108.6 -> 109.0: profiles/r6m_*.)
+        constexpr int QW = 64 * TPL;
         int n_q = 0;
 #pragma unroll
         for (int k = 0; k < TPL; ++k) {
@@ -358,21 +363,21 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
             if (push) cv[k].clipped = 0;
             const unsigned long long m = __ballot(push);
             if (push) {
-                const int slot = n_q + __popcll(m & ((1ull << lane) - 1ull));
+                const int slot = wv * QW + n_q + __popcll(m & ((1ull << lane) - 1ull));
                 const unsigned rb = ((unsigned)(vb[k].x - va[k].x) & 0xffffu) | ((unsigned)(vb[k].y - va[k].y) << 16);
                 const unsigned rc = ((unsigned)(vc[k].x - va[k].x) & 0xffffu) | ((unsigned)(vc[k].y - va[k].y) << 16);
                 const bool neg = cv[k].mask != 0;  // (negative area: the two relative corners swap places, see small_mask_rel; the vertex handles keep their order)
-                s_q[wv][0][slot] = make_int4(va[k].x, va[k].y, (int)(neg ? rc : rb), (int)(neg ? rb : rc));
-                s_q[wv][1][slot] = make_int4(i0[k] | (i1[k] << 10) | (i2[k] << 20), t[k], cv[k].px0 | (cv[k].py0 << 16), cv[k].nxp);
+                s_q[0][slot] = make_int4(va[k].x, va[k].y, (int)(neg ? rc : rb), (int)(neg ? rb : rc));
+                s_q[1][slot] = make_int4(i0[k] | (i1[k] << 10) | (i2[k] << 20), t[k], cv[k].px0 | (cv[k].py0 << 16), cv[k].nxp);
             }
             n_q += __popcll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- the survivors' covered centres become FRAGMENTS of the wave's queue (4 bytes: pixel, survivor slot), resolved 64 at a
-        // time with one depth evaluation + atomicMin per lane.  (Until round 6 the lane that owned a survivor walked its centres itself:
-        // 46 % of cfg2's survivors own a centre, hardly any more than two, and a wave ran max(count) = 1.5 rounds of the depth code at
-        // 30 % of its lanes for every 64 survivors; queued, the fragments of a meshlet's 128 triangles fill one round.)
+        // ---- the survivors' covered centres become FRAGMENTS of the wave's queue (2 bytes: the centre's bit in the survivor's mask, the
+        // survivor), resolved 64 at a time with one depth evaluation + atomicMin per lane.  (Until round 6 the lane that owned a survivor
+        // walked its centres itself: 46 % of cfg2's survivors own a centre, hardly any more than two, and a wave ran max(count) = 1.5
+        // rounds of the depth code at 30 % of its lanes for every 64 survivors.)
         int n_f = 0;
         auto drain = [&]() {  // (wave-uniform)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -381,8 +386,10 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
                 const int fi = fb + lane;
                 if (fi < n_f) {
                     const unsigned e = s_fq[wv][fi];
-                    const int4 h = s_q[wv][1][e >> 24];
-                    const int px = (int)(e & 4095u), py = (int)((e >> 12) & 4095u);
+                    const int4 h = s_q[1][e >> 6];
+                    const int kb = (int)(e & 63u), nxp = h.w & 255;
+                    const int j = (int)(((float)kb + 0.5f) * __builtin_amdgcn_rcpf((float)nxp)), i = kb - __mul24(j, nxp);  // kb = j * nxp + i, exact for kb < 64 (walk_mask)
+                    const int px = (h.z & 0xffff) + i, py = (int)((unsigned)h.z >> 16) + j;
                     const float4 p0 = ld4(S.P + (size_t)(h.x & 1023) * 4), p1 = ld4(S.P + (size_t)((h.x >> 10) & 1023) * 4), p2 = ld4(S.P + (size_t)((h.x >> 20) & 1023) * 4);
                     float zw;
                     const float fx = __fmaf_rn((float)px, S.ndc.xs, S.ndc.xo), fy = __fmaf_rn((float)py, S.ndc.ys, S.ndc.yo);
@@ -395,20 +402,17 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
             __builtin_amdgcn_wave_barrier();
         };
         for (int base = 0; base < n_q; base += 64) {  // (wave-uniform)
-            const int idx = base + lane;
+            const int sw = wv * QW + base + lane;  // the survivor's place in the planes
             scatter_mask_t mask = 0;
-            int px0 = 0, py0 = 0, nxp = 1;
-            if (idx < n_q) {
-                const int4 g = s_q[wv][0][idx], h = s_q[wv][1][idx];
-                px0 = h.z & 0xffff; py0 = (int)((unsigned)h.z >> 16); nxp = h.w & 255;
-                mask = scatter_small_mask(S, H, W, g.x, g.y, (int)(short)((unsigned)g.z & 0xffffu), (int)g.z >> 16, (int)(short)((unsigned)g.w & 0xffffu), (int)g.w >> 16,
-                                          px0, py0, nxp, h.w >> 8);
+            if (base + lane < n_q) {
+                const int4 gg = s_q[0][sw], h = s_q[1][sw];
+                mask = scatter_small_mask(S, H, W, gg.x, gg.y, (int)(short)((unsigned)gg.z & 0xffffu), (int)gg.z >> 16, (int)(short)((unsigned)gg.w & 0xffffu), (int)gg.w >> 16,
+                                          h.z & 0xffff, (int)((unsigned)h.z >> 16), h.w & 255, h.w >> 8);
             }
 #if DDX_ABLATE >= 1
             if (mask) S.flag[0] = 1;
             mask = 0;
 #endif
-            const float rn = __builtin_amdgcn_rcpf((float)nxp);
             for (;;) {  // round r queues the r-th covered centre of every lane that has one
                 const unsigned long long bal = __ballot(mask != 0);
                 if (bal == 0ull) break;
@@ -422,8 +426,7 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
                     const int kb = __ffs((unsigned)mask) - 1;
 #endif
                     mask &= mask - 1;
-                    const int j = (int)(((float)kb + 0.5f) * rn), i = kb - __mul24(j, nxp);  // kb = j * nxp + i, exact for kb < 64 (walk_mask)
-                    s_fq[wv][n_f + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned)(px0 + i) | ((unsigned)(py0 + j) << 12) | ((unsigned)idx << 24);
+                    s_fq[wv][n_f + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(kb | (sw << 6));
                 }
                 n_f += n;
             }
