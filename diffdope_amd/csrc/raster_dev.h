@@ -37,24 +37,6 @@ __device__ __forceinline__ unsigned long long frag_key(const float4& p0, const f
     return ((unsigned long long)depth_key(bc.zw) << 32) | (unsigned)t;
 }
 
-// 32-bit edge function of a SMALL triangle relative to the bbox corner pixel centre (X0,Y0):
-// e(i,j) = e00 + i*sx + j*sy for the pixel (px0+i, py0+j); `own` = ownership of the e == 0 line.
-struct Edge32 { int e00, sx, sy; bool own; };
-
-__device__ __forceinline__ Edge32 make_edge(int ax, int ay, int bx, int by, int X0, int Y0, bool flip)
-{
-    int dx = bx - ax, dy = by - ay;
-    if (flip) { dx = -dx; dy = -dy; }
-    Edge32 e;
-    // e = dx*(PY-ay) - dy*(PX-ax); all factors < 2^14 for a small triangle near its own bbox: 24-bit multiplies
-    // (full rate; a 32-bit v_mul_lo_u32 issues at quarter rate and this kernel is VALU-issue bound)
-    e.e00 = __mul24(dx, Y0 - ay) - __mul24(dy, X0 - ax);
-    e.sx = -dy * DDX_SUBPIX;
-    e.sy = dx * DDX_SUBPIX;
-    e.own = (dy > 0) || (dy == 0 && dx < 0);
-    return e;
-}
-
 #if RASTER_SMALL_PX > 32
 typedef unsigned long long scatter_mask_t;
 #else
@@ -66,23 +48,44 @@ typedef unsigned scatter_mask_t;
 // of a LARGE triangle (resolved later by the tile pass), ~0u otherwise.
 struct ScatterCov { scatter_mask_t mask; int px0, py0, nxp; int clipped; };  // clipped: a near-plane straddler, resolved by the tile pass
 
-// coverage mask of the <= RASTER_SMALL_PX bbox centres of a small, non-degenerate triangle (integer only)
-__device__ __forceinline__ scatter_mask_t small_mask(const int2& a, const int2& bq, const int2& c, int area, int px0, int py0, int nxp, int nyp)
+// Coverage mask of the <= RASTER_SMALL_PX bbox centres of a small, non-degenerate triangle (integer only; bit k = j * nxp + i <=> pixel
+// (px0 + i, py0 + j)): corner a, the other two RELATIVE to it (ab, ac) and already in the order that makes the area positive (the
+// callers swap them for a triangle with negative area: the edges of (a, c, b) are the flipped edges of (a, b, c) -- the same lines
+// walked the other way, the same integers, the same ownership rule -- rounds 1-5 negated dx, dy and the edge value instead).  All
+// factors < 2^14 for a small triangle near its own bbox: 24-bit multiplies (full rate; a 32-bit v_mul_lo_u32 issues at quarter rate).  With p = first
+// centre - a:   edge a->b: f2 = ab.x p.y - ab.y p.x;   edge c->a: f1 = ac.y p.x - ac.x p.y;   edge b->c: f0 = area - f1 - f2
+// (the three edge functions of a point sum to the area, exactly, in integers) -- four 24-bit multiplies instead of six, no flip selects.
+__device__ __forceinline__ scatter_mask_t small_mask_rel(int ax, int ay, int abx, int aby, int acx, int acy, int px0, int py0, int nxp, int nyp)
 {
-    const bool flip = area < 0;
-    const int X0 = px0 * DDX_SUBPIX + DDX_SUBPIX / 2, Y0 = py0 * DDX_SUBPIX + DDX_SUBPIX / 2;
-    const Edge32 e0 = make_edge(bq.x, bq.y, c.x, c.y, X0, Y0, flip);
-    const Edge32 e1 = make_edge(c.x, c.y, a.x, a.y, X0, Y0, flip);
-    const Edge32 e2 = make_edge(a.x, a.y, bq.x, bq.y, X0, Y0, flip);
-    // the ownership rule (v > 0 || (v == 0 && own)) is folded into the start value: v + own - 1 >= 0
-    const int b0 = e0.e00 + (int)e0.own - 1, b1 = e1.e00 + (int)e1.own - 1, b2 = e2.e00 + (int)e2.own - 1;
+    const int area = __mul24(abx, acy) - __mul24(acx, aby);  // > 0
+    const int apx = px0 * DDX_SUBPIX + DDX_SUBPIX / 2 - ax, apy = py0 * DDX_SUBPIX + DDX_SUBPIX / 2 - ay;
+    const int f2 = __mul24(abx, apy) - __mul24(aby, apx);
+    const int f1 = __mul24(acy, apx) - __mul24(acx, apy);
+    const int f0 = area - f1 - f2;
+    const int d0x = acx - abx, d0y = acy - aby;  // edge b->c
+    // ownership of the e == 0 line (dy > 0 || (dy == 0 && dx < 0)) folded into the start value: v + own - 1 >= 0
+    const int b0 = f0 + (int)((d0y > 0) || (d0y == 0 && d0x < 0)) - 1;
+    const int b1 = f1 + (int)((acy < 0) || (acy == 0 && acx > 0)) - 1;  // edge c->a: (dx, dy) = -ac
+    const int b2 = f2 + (int)((aby > 0) || (aby == 0 && abx < 0)) - 1;
+    // steps per pixel: sx = -dy * 256, sy = dx * 256
+    const int sx2 = -aby * DDX_SUBPIX, sy2 = abx * DDX_SUBPIX, sx1 = acy * DDX_SUBPIX, sy1 = -acx * DDX_SUBPIX;
+    const int sx0 = -(sx1 + sx2), sy0 = -(sy1 + sy2);
+    // (a branch-free path for boxes of at most 2x2 centres that lets whole waves skip the loop below: 6 of 7 waves of cfg2's survivors
+    // qualify.  Rounds 3-5 measured such a path at +-0.5 % with back faces culled; with both faces drawn and this set-up it is worth 0.7 us
+    // of cfg2's 41.8 per iteration at 64 hypotheses and 3 % of the instructions at saturation: profiles/r6q_ab_relall.log, r6h_*)
+    if (__ballot(nxp > 2 || nyp > 2) == 0ull) {
+        const bool c00 = (b0 | b1 | b2) >= 0;
+        const bool c10 = ((b0 + sx0) | (b1 + sx1) | (b2 + sx2)) >= 0 && nxp > 1;
+        const bool c01 = ((b0 + sy0) | (b1 + sy1) | (b2 + sy2)) >= 0 && nyp > 1;
+        const bool c11 = ((b0 + sx0 + sy0) | (b1 + sx1 + sy1) | (b2 + sx2 + sy2)) >= 0 && nxp > 1 && nyp > 1;
+        return (scatter_mask_t)((unsigned)c00 | ((unsigned)c10 << 1) | (((unsigned)c01 | ((unsigned)c11 << 1)) << nxp));  // bit k = j * nxp + i
+    }
     scatter_mask_t mask = 0;
-    // (a branch-free path for boxes of at most 2x2 centres that lets whole waves skip this loop: see small_mask_rel, which has it)
     int idx = 0;
     int r0 = b0, r1 = b1, r2 = b2;
-    for (int j = 0; j < nyp; ++j, r0 += e0.sy, r1 += e1.sy, r2 += e2.sy) {
+    for (int j = 0; j < nyp; ++j, r0 += sy0, r1 += sy1, r2 += sy2) {
         int v0 = r0, v1 = r1, v2 = r2;
-        for (int i = 0; i < nxp; ++i, ++idx, v0 += e0.sx, v1 += e1.sx, v2 += e2.sx)
+        for (int i = 0; i < nxp; ++i, ++idx, v0 += sx0, v1 += sx1, v2 += sx2)
             mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
     }
     return mask;
@@ -179,7 +182,10 @@ __device__ __forceinline__ unsigned scatter_one(const ScatterTarget& S, int H, i
             S.flag[0] = 1;
         } else {
             // pass 1: coverage of the <= RASTER_SMALL_PX bbox centres as a bit mask -- integer only
-            scatter_mask_t mask = small_mask(a, bq, c, area, px0, py0, nxp, nyp);
+            // (relative corners in the order of positive area: see small_mask_rel)
+            const int abx_ = bq.x - a.x, aby_ = bq.y - a.y, acx_ = c.x - a.x, acy_ = c.y - a.y;
+            const bool neg_ = area < 0;
+            scatter_mask_t mask = small_mask_rel(a.x, a.y, neg_ ? acx_ : abx_, neg_ ? acy_ : aby_, neg_ ? abx_ : acx_, neg_ ? aby_ : acy_, px0, py0, nxp, nyp);
             bool walk = WALK == 1;
             if (WALK == 2) {
                 const int cnt = RASTER_SMALL_PX > 32 ? __popcll(mask) : __popc((unsigned)mask);
@@ -223,47 +229,6 @@ __device__ __forceinline__ unsigned scatter_one(const ScatterTarget& S, int H, i
         }
     }
     return range;
-}
-
-// small_mask for a survivor of the compacting variant: corner a, the other two RELATIVE to it (ab, ac) and already in the order that
-// makes the area positive (scatter_resolve swaps them in the record of a triangle with negative area: the edges of (a, c, b) are the
-// flipped edges of (a, b, c) -- the same lines walked the other way, the same integers, the same ownership rule).  With p = first
-// centre - a:   edge a->b: f2 = ab.x p.y - ab.y p.x;   edge c->a: f1 = ac.y p.x - ac.x p.y;   edge b->c: f0 = area - f1 - f2
-// (the three edge functions of a point sum to the area, exactly, in integers) -- four 24-bit multiplies instead of six, no flip selects.
-__device__ __forceinline__ scatter_mask_t small_mask_rel(int ax, int ay, int abx, int aby, int acx, int acy, int px0, int py0, int nxp, int nyp)
-{
-    const int area = __mul24(abx, acy) - __mul24(acx, aby);  // > 0
-    const int apx = px0 * DDX_SUBPIX + DDX_SUBPIX / 2 - ax, apy = py0 * DDX_SUBPIX + DDX_SUBPIX / 2 - ay;
-    const int f2 = __mul24(abx, apy) - __mul24(aby, apx);
-    const int f1 = __mul24(acy, apx) - __mul24(acx, apy);
-    const int f0 = area - f1 - f2;
-    const int d0x = acx - abx, d0y = acy - aby;  // edge b->c
-    // ownership of the e == 0 line (dy > 0 || (dy == 0 && dx < 0)) folded into the start value: v + own - 1 >= 0
-    const int b0 = f0 + (int)((d0y > 0) || (d0y == 0 && d0x < 0)) - 1;
-    const int b1 = f1 + (int)((acy < 0) || (acy == 0 && acx > 0)) - 1;  // edge c->a: (dx, dy) = -ac
-    const int b2 = f2 + (int)((aby > 0) || (aby == 0 && abx < 0)) - 1;
-    // steps per pixel: sx = -dy * 256, sy = dx * 256
-    const int sx2 = -aby * DDX_SUBPIX, sy2 = abx * DDX_SUBPIX, sx1 = acy * DDX_SUBPIX, sy1 = -acx * DDX_SUBPIX;
-    const int sx0 = -(sx1 + sx2), sy0 = -(sy1 + sy2);
-    // (a branch-free path for boxes of at most 2x2 centres that lets whole waves skip the loop below: +-0.5 % at 64 hypotheses, where the
-    // kernel waits on its memory levels (rounds 3-5); at saturation the launch is VALU-bound and the loop's trips cost what they issue:
-    // 6 of 7 waves of cfg2's survivors qualify, round 6)
-    if (__ballot(nxp > 2 || nyp > 2) == 0ull) {
-        const bool c00 = (b0 | b1 | b2) >= 0;
-        const bool c10 = ((b0 + sx0) | (b1 + sx1) | (b2 + sx2)) >= 0 && nxp > 1;
-        const bool c01 = ((b0 + sy0) | (b1 + sy1) | (b2 + sy2)) >= 0 && nyp > 1;
-        const bool c11 = ((b0 + sx0 + sy0) | (b1 + sx1 + sy1) | (b2 + sx2 + sy2)) >= 0 && nxp > 1 && nyp > 1;
-        return (scatter_mask_t)((unsigned)c00 | ((unsigned)c10 << 1) | (((unsigned)c01 | ((unsigned)c11 << 1)) << nxp));  // bit k = j * nxp + i
-    }
-    scatter_mask_t mask = 0;
-    int idx = 0;
-    int r0 = b0, r1 = b1, r2 = b2;
-    for (int j = 0; j < nyp; ++j, r0 += sy0, r1 += sy1, r2 += sy2) {
-        int v0 = r0, v1 = r1, v2 = r2;
-        for (int i = 0; i < nxp; ++i, ++idx, v0 += sx0, v1 += sx1, v2 += sx2)
-            mask |= (scatter_mask_t)((v0 | v1 | v2) >= 0) << idx;
-    }
-    return mask;
 }
 
 // The compacting variant's second stage (round 6): coverage mask + tile flags of a survivor whose pixel box travels in its record;
@@ -345,7 +310,9 @@ __device__ __forceinline__ bool scatter_resolve(const ScatterTarget& S, int H, i
         cv[k].mask = 0; cv[k].px0 = 0; cv[k].py0 = 0; cv[k].nxp = 1; cv[k].clipped = 0;
         if (t[k] >= T || !ok[k]) continue;
         // (plain variant: triangle by triangle -- coverage of both triangles first and all fragments afterwards measured
-        // 2 us slower on cfg2: more atomics in flight at once make the atomicMin stream slower)
+        // 2 us slower on cfg2 in round 2: more atomics in flight at once make the atomicMin stream slower; with the wave's fragments queued
+        // and resolved 64 at a time, as the compacting variant does it, round 6: 41.08 -> 41.25 us one chain, 40.0 -> 39.7 two chains:
+        // tools/experiments/plain_fragment_queue.patch)
         range[k] = scatter_one<(MODE == 0 || MODE == 3) ? 1 : MODE == 2 ? 2 : 0, COMPACT>(S, H, W, t[k], i0[k], i1[k], i2[k], va[k], vb[k], vc[k], cv[k], cull);
     }
     if (COMPACT) {
