@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ablate_step.sh <tag> [B ...]
-# Where do step_kernel's instructions go?  The product and the DDX_ABLATE = 1..4 builds (tools/build_variant.sh a<n> -DDDX_ABLATE=<n>,
+# Where do step_kernel's instructions go?  The product and the DDX_ABLATE = 1..4 builds (python tools/build_variant.py a<n> -DDDX_ABLATE=<n>,
 # built beforehand: raster_dev.h says what each leaves out) over tools/ablate_driver.py: one un-profiled kernel trace (durations) and
 # one SQ counter pass each.  Output gpurun_out/ab_<tag>/<lib>/;  summarise with  python tools/ablate_table.py <tag> [B ...]
 set -u
