@@ -732,8 +732,11 @@ class DiffDope:
         before the call returns).  A loss function must
         then be capture-safe: tensor operations and ddope.add_loss_value only -- no .item() / .cpu(), and no Python-side state
         that has to change every iteration (it would change once).  Default (None / False): eager, as the reference runs it.
-        Measured on cfg2 (64 hypotheses, 640x480, tools/bench_opbyop.py --api): 0.79-0.92 k it/s eager, 0.96-0.99 k captured over
-        101 iterations; no gain at 41 -- capture and instantiation cost about 15 ms per call."""
+        Measured on cfg2 (64 hypotheses, 640x480, tools/bench_opbyop.py --api): 1.1-1.2 k it/s eager, 1.5 k captured over
+        101 iterations; no gain at 41 -- capture and instantiation cost about 15 ms per call.
+        graph=True is EXPERIMENTAL: it is covered by the tests (tests/test_gpu_api.py) and used by tools/bench_opbyop.py, but a graph
+        kept ACROSS calls faulted in one call sequence for a reason that was not found (HISTORY.md round 6, item 4), which is why the
+        graph lives for one call only."""
         self.losses_values = _LossLog()
         self.optimization_results = []
         self._refresh_gt()

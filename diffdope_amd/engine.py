@@ -147,7 +147,11 @@ class RefineEngine:
     def run(self, n=None, use_graph=False):
         """Run n iterations (default: all remaining) asynchronously on the current stream.
         use_graph=k (or True = 1) replays a captured hipGraph of k iterations; with 4 launches per iteration plain
-        stream launches measured 9 % faster than k = 1 and equal to k = 20 on MI355X, so streams are the default."""
+        stream launches measured 9 % faster than k = 1 and equal to k = 20 on MI355X, so streams are the default.
+        Asynchronous with one exception: a run enqueued BEHIND a run that nothing has checked yet (no finish() / check() / losses()
+        in between) first has ddx_engine_run_check look at that run -- a stream synchronise and a 4-byte copy -- because a run whose
+        in-launch tile pass timed out is void and the next one would start from its parameters (ddx.h).  Loops that chain
+        run(k); run(k) without reading anything in between pay that synchronise per call."""
         n = self.max_iters - self.it if n is None else n
         if self._unchecked:  # (a run behind a void one would start from void parameters: ddx.h ddx_engine_run_check)
             self._run_check()
