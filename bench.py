@@ -470,9 +470,11 @@ def main():
                       "step_coalesced_store_lines_per_launch": store_lines, "store_ceiling_Glines_s": STORE_LINE_PEAK_G,
                       "step_store_frac": (store_lines / st_s / 1e9 / STORE_LINE_PEAK_G) if st_s > 0 else None,
                       "sources": "tools/ubench/gather_rate.hip, tools/ubench/store_rate.hip (profiles/r3c_ubench_gather_rate.jsonl, profiles/r4b_ubench_store_rate.jsonl)"},
-            "what_binds": "neither bytes nor issue: a launch begins with two dependent memory levels on a cold L2 (kernel arguments, then its first "
-                          "data: ~3.5 us before useful work, per-workgroup stamps in profiles/), ends with its slowest workgroup, and a kernel "
-                          "boundary costs ~2.4 us; at 512 hypotheses per GPU the same kernels run at 25 us per 64 hypotheses",
+            "what_binds": "at 64 hypotheses no unit is saturated (profiles/r6a_bottleneck.md: every busy fraction 0.3-0.65): step_kernel is a ~9-us "
+                          "floor (launch start, partial rows, the optimiser head's one-wave tail) plus four stages -- transform, triangle predicates, "
+                          "coverage, fragments -- of 3.5-5 us each whose cost follows their instruction count (ablation builds, "
+                          "profiles/r6e_ablate_table.md), and ends with its slowest workgroup (median 15.7, worst 20.4 us); a kernel boundary costs "
+                          "~2.4 us; at 512 hypotheses per GPU the same kernels run at 27 us per 64 hypotheses with the VALU 0.66 and TD / TCP 0.76 busy",
             "model_8d": {"algorithmic_bytes_per_launch": model_bytes, "achieved_GBps": model_bytes / dom_s / 1e9,
                          "ratio_to_hbm_peak": model_bytes / dom_s / 1e9 / HBM_PEAK_GBS,
                          "iteration_ratio_to_hbm_peak": alg["iteration"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
