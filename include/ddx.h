@@ -254,7 +254,9 @@ typedef struct ddx_engine_desc {
      * run BIT FOR BIT passes the unsharded run's counts here (tests/test_gpu_engine.py::test_engine_shard_invariance);
      * with 0 the shards agree with the unsharded run to fp32 rounding of that sum. */
     int32_t shade_slices, edge_slices;
-    /* != 0: draw both faces of every triangle, always.  0 (default): when the mesh is a closed, consistently oriented surface
+    /* != 0: draw both faces of every triangle, always -- dr.rasterize's rule (diffdope/diffdope.py:198-200), what the Python layer
+     * passes unless asked for cull_backfaces=True, and what bench.py and the full-size parity tests run.  A C caller that wants the
+     * reference's results sets this field to 1: a zero-initialised descriptor asks for deviation D5.  0: when the mesh is a closed, consistently oriented surface
      * (checked once, vertices welded by position) the rasteriser skips back-facing triangles of every hypothesis that lies
      * entirely inside the view volume -- they are hidden behind front faces there, so this changes nothing in exact
      * arithmetic (deviation D5) and halves the fragment work.  Environment DDX_NO_CULL=1 also disables. */
